@@ -1,0 +1,262 @@
+/* spmv_amd/api.h -- entry points of libspmv_amd.so.
+ *
+ * Part 1 re-declares, under the reference's own names and signatures, every
+ * function the reference's harness calls on the SpMV + CG path, so that the
+ * harness objects link against this library instead of the reference's
+ * src/spmv, src/solvers and src/io objects. Each declaration cites the reference
+ * declaration it replaces. Linkage (C vs C++) follows the reference header.
+ *
+ * Part 2 is the FFI surface: the same operations as plain `extern "C"`
+ * functions taking only pointers, ints and doubles (structs by pointer), plus
+ * the few things a caller without a HIP binding needs (device buffers, on-stream
+ * timing, the multi-GPU communicator hook and a resident CG state so that a
+ * benchmark can time solves with everything already in HBM).
+ */
+#ifndef SPMV_AMD_API_H
+#define SPMV_AMD_API_H
+
+#include <stddef.h>
+#ifndef __cplusplus
+#include <stdbool.h>
+#endif
+#include "spmv_amd/types.h"
+
+/* ===================================================================== *
+ * Part 1 -- reference-named boundary                                     *
+ * ===================================================================== */
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Process-wide host matrices. Populated by build_csr_struct / the operators'
+ * init, read by calculate_spmv_metrics and by cg_solve_mgpu_partitioned.
+ * reference: include/spmv.h:34,39 ; src/spmv/spmv_cusparse_csr.cu:23 */
+extern CSRMatrix csr_mat;
+extern ELLPACKMatrix ellpack_matrix;
+
+/* reference: include/spmv.h:37-38 (declared there, defined nowhere in src/) */
+int build_ellpack_from_csr_local(CSRMatrix* csr_matrix);
+int ensure_ellpack_structure_built(MatrixData* mat);
+
+/* Operator lookup. Canonical names: "stencil5-csr", "cusparse-csr", "ellpack",
+ * "stencil5-ellpack"; accepted aliases: "stencil5", "csr". Unknown -> NULL.
+ * reference: include/spmv.h:141-150 ; src/spmv/spmv.cu:11-23 */
+SpmvOperator* get_operator(const char* mode);
+
+/* reference: include/spmv.h:159-183 ; src/spmv/spmv_metrics.cu:46-102,190-324 ;
+ * src/spmv/gpu_detection.cu */
+void calculate_spmv_metrics(double execution_time_ms, const MatrixData* mat,
+                            const char* operator_name, BenchmarkMetrics* metrics);
+int get_gpu_properties(BenchmarkMetrics* metrics);
+void print_benchmark_metrics(const BenchmarkMetrics* metrics, FILE* output_file);
+void print_metrics_json(const BenchmarkMetrics* metrics, FILE* output_file);
+void print_metrics_csv(const BenchmarkMetrics* metrics, FILE* output_file);
+
+/* Matrix Market I/O. reference: include/io.h:71-134 ; src/io/io.cu */
+int read_matrix_type(const char* filename);
+void read_matrix_general(MatrixData* mat, const char* filename, int* rows, int* cols, int* nnz,
+                         int** csr_rowptr, int** csr_colind, double** csr_val);
+void read_matrix_symtogen(MatrixData* mat, const char* filename, int* rows, int* cols, int* nnz,
+                          int** csr_rowptr, int** csr_colind, double** csr_val, int* nnz_general);
+int load_matrix_market(const char* filename, MatrixData* mat);
+void convert_csr_to_ellpack(const struct CSRMatrix* csr_matrix,
+                            struct ELLPACKMatrix* ellpack_matrix, int* max_width);
+int write_matrix_market_stencil5(int n, const char* filename);
+
+/* N-run statistics with >2 sigma outlier removal and median.
+ * reference: include/benchmark_stats.h:23-29 ; include/benchmark_stats_mgpu.h:12-15 ;
+ * src/spmv/benchmark_stats.cu ; src/spmv/benchmark_stats_mgpu_partitioned.cu */
+int benchmark_with_stats(int (*run_func)(const double*, double*, double*), const double* x,
+                         double* y, int num_runs, BenchmarkStats* stats);
+int cg_benchmark_with_stats_device(SpmvOperator* spmv_op, MatrixData* mat, double* b, double* x,
+                                   CGConfig config, int num_runs, BenchmarkStats* bench_stats,
+                                   CGStats* final_stats);
+int cg_benchmark_with_stats_mgpu_partitioned(SpmvOperator* spmv_op, MatrixData* mat, double* b,
+                                             double* x, CGConfigMultiGPU config, int num_runs,
+                                             BenchmarkStats* bench_stats,
+                                             CGStatsMultiGPU* final_stats);
+
+/* reference: include/solvers/cg_metrics.h:23-37 ; src/solvers/cg_metrics.cu */
+void export_cg_json(const char* filename, const char* mode, const MatrixData* mat,
+                    const BenchmarkStats* bench_stats, const CGStats* cg_stats);
+void export_cg_mgpu_json(const char* filename, const char* mode, const MatrixData* mat,
+                         const BenchmarkStats* bench_stats, const CGStatsMultiGPU* cg_stats,
+                         int num_gpus);
+void export_cg_csv(const char* filename, const char* mode, const MatrixData* mat,
+                   const BenchmarkStats* bench_stats, const CGStats* cg_stats, bool write_header);
+
+#ifdef __cplusplus
+} /* extern "C" */
+#endif
+
+#ifdef __cplusplus
+/* C++ linkage, as in the reference headers. */
+
+/* reference: include/spmv.h:137-139 */
+extern SpmvOperator SPMV_CSR;               /* "cusparse-csr": own CSR kernels, no vendor library */
+extern SpmvOperator SPMV_STENCIL5_CSR;      /* "stencil5-csr" */
+extern SpmvOperator SPMV_STENCIL_HALO_MGPU; /* "stencil5-halo-mgpu": declared, never defined upstream */
+extern SpmvOperator SPMV_ELLPACK;           /* "ellpack" (new: upstream ships headers only) */
+extern SpmvOperator SPMV_STENCIL5_ELLPACK;  /* "stencil5-ellpack": ELL values, computed columns */
+
+/* COO -> CSR with per-row insertion sort by column; fills csr_mat.
+ * reference: include/spmv_csr.h:47 ; src/spmv/spmv_cusparse_csr.cu:62-170 */
+int build_csr_struct(struct MatrixData* mat);
+
+/* reference: include/spmv_ellpack.h:50-51 (declaration only upstream) */
+int build_ellpack_from_csr_struct(const struct CSRMatrix* csr_matrix, ELLPACKMatrix* ellpack_matrix,
+                                  int* max_width);
+
+/* reference: include/solvers/cg_solver.h:59-77 ; src/solvers/cg_solver.cu:154-378,436-706 */
+int cg_solve(SpmvOperator* spmv_op, MatrixData* mat, const double* b, double* x, CGConfig config,
+             CGStats* stats);
+int cg_solve_device(SpmvOperator* spmv_op, MatrixData* mat, const double* b, double* x,
+                    CGConfig config, CGStats* stats);
+
+/* 1-D row-slab CG over all ranks of the world communicator (see
+ * spmv_amd_comm_set_world; none set = one rank). spmv_op is unused, callers pass
+ * NULL. b and x are full-length host arrays on every rank; on return rank 0's x
+ * holds the gathered solution.
+ * reference: include/solvers/cg_solver_mgpu_partitioned.h:50-51 ;
+ * src/solvers/cg_solver_mgpu_partitioned.cu:236-908 */
+int cg_solve_mgpu_partitioned(SpmvOperator* spmv_op, MatrixData* mat, const double* b, double* x,
+                              CGConfigMultiGPU config, CGStatsMultiGPU* stats);
+#endif /* __cplusplus */
+
+/* ===================================================================== *
+ * Part 2 -- FFI surface (all extern "C", prefix spmv_amd_)               *
+ * ===================================================================== */
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- FFI aliases of the C++-linkage entry points above (configs by pointer) ---- */
+int spmv_amd_build_csr_struct(MatrixData* mat);
+int spmv_amd_build_ellpack_from_csr_struct(const CSRMatrix* csr, ELLPACKMatrix* ell,
+                                           int* max_width);
+int spmv_amd_cg_solve(SpmvOperator* op, MatrixData* mat, const double* b, double* x,
+                      const CGConfig* config, CGStats* stats);
+int spmv_amd_cg_solve_device(SpmvOperator* op, MatrixData* mat, const double* b, double* x,
+                             const CGConfig* config, CGStats* stats);
+int spmv_amd_cg_solve_mgpu_partitioned(MatrixData* mat, const double* b, double* x,
+                                       const CGConfigMultiGPU* config, CGStatsMultiGPU* stats);
+
+/* Drops the host CSR/ELL held in csr_mat / ellpack_matrix (the reference keeps
+ * them for the life of the process; tests that load several matrices need this). */
+void spmv_amd_reset_host_matrices(void);
+
+/* ---- integer helpers that must match the reference bit for bit ---- */
+
+/* CSR start of interior row `row` of an n x n 5-point stencil.
+ * reference: calculate_interior_csr_offset, src/spmv/spmv_stencil_csr_direct.cu:50-67 */
+int spmv_amd_interior_csr_offset(int row, int grid_size);
+
+/* Row slab of `rank`: n / world rows each, the last rank takes the remainder.
+ * reference: src/solvers/cg_solver_mgpu_partitioned.cu:261-268 */
+void spmv_amd_partition_rows(int n, int world, int rank, int* row_offset, int* n_local);
+
+/* ---- device plumbing for callers that have no HIP binding of their own ---- */
+int spmv_amd_device_count(void);
+int spmv_amd_set_device(int device);
+void* spmv_amd_device_alloc(size_t bytes);
+void spmv_amd_device_free(void* d_ptr);
+int spmv_amd_copy_to_device(void* d_dst, const void* h_src, size_t bytes);
+int spmv_amd_copy_to_host(void* h_dst, const void* d_src, size_t bytes);
+int spmv_amd_device_fill_f64(double* d_ptr, size_t count, double value);
+int spmv_amd_device_synchronize(void);
+
+/* ---- operators on synthetic, device-generated matrices ---- */
+
+/* Initialises operator `mode` on the n x n 5-point stencil of
+ * write_matrix_market_stencil5 (centre 5.0, neighbours -1.0) with the CSR/ELL
+ * arrays produced directly in HBM by a generator kernel: same bytes as
+ * load_matrix_market + init would upload, without the host COO/CSR (58 GB at
+ * n = 20000). csr_mat gets the dimensions, its host arrays stay NULL. */
+int spmv_amd_init_stencil5_synthetic(const char* mode, int n);
+
+/* Downloads the device CSR of an initialised CSR-based operator (tests compare
+ * it with build_csr_struct's host result). Any pointer may be NULL. */
+int spmv_amd_download_device_csr(const char* mode, int* row_ptr, int* col_idx, double* values);
+
+/* Launches run_device `reps` times back to back on the operator's stream and
+ * returns each launch's duration from HIP events recorded on that stream. */
+int spmv_amd_time_run_device(const char* mode, const double* d_x, double* d_y, int reps,
+                             float* ms_each);
+
+/* Which kernel variant the last init selected: a static string such as
+ * "stencil5/wave-tile", "stencil5/row-generic", "csr/stream", "csr/wavefront". */
+const char* spmv_amd_operator_variant(const char* mode);
+
+/* Forces a kernel variant at the next init of `mode` (NULL = automatic). */
+int spmv_amd_operator_select_variant(const char* mode, const char* variant);
+
+/* ---- residual history of the most recent CG solve in this process ---- */
+/* Copies ||r_k||, k = 0..iterations, into out (at most cap values); returns how
+ * many the solve recorded. */
+int spmv_amd_cg_last_history(double* out, int cap);
+
+/* ---- multi-GPU communicator ---- */
+typedef struct SpmvAmdComm SpmvAmdComm;
+
+/* Host-side callbacks of a staged communicator: the library moves the halo rows
+ * and the scalars through pinned host memory and calls these on host buffers
+ * (the reference's D2H -> MPI -> H2D scheme, cg_solver_mgpu_partitioned.cu:173-231).
+ * A NULL send/recv pointer means "no neighbour on that side". */
+typedef int (*SpmvAmdHostHaloFn)(void* user, const double* send_prev, const double* send_next,
+                                 double* recv_prev, double* recv_next, int count);
+typedef int (*SpmvAmdHostAllreduceFn)(void* user, double* inout, int count);
+/* root receives counts[r] doubles at displs[r] of recv; every rank sends send[0..n_send). */
+typedef int (*SpmvAmdHostGatherFn)(void* user, const double* send, int n_send, double* recv,
+                                   const int* counts, const int* displs);
+typedef int (*SpmvAmdHostBarrierFn)(void* user);
+
+/* 128-byte RCCL unique id, to be produced on rank 0 and handed to every rank. */
+int spmv_amd_comm_unique_id(void* out_id128);
+/* One process per GPU: RCCL communicator over xGMI; halo rows travel by
+ * ncclSend/ncclRecv on a side stream, dot products by ncclAllReduce. */
+SpmvAmdComm* spmv_amd_comm_create_rccl(int rank, int world, const void* id128);
+SpmvAmdComm* spmv_amd_comm_create_staged(int rank, int world, SpmvAmdHostHaloFn halo,
+                                         SpmvAmdHostAllreduceFn allreduce,
+                                         SpmvAmdHostGatherFn gather, SpmvAmdHostBarrierFn barrier,
+                                         void* user);
+void spmv_amd_comm_destroy(SpmvAmdComm* comm);
+/* The communicator cg_solve_mgpu_partitioned runs over (MPI_COMM_WORLD's role). */
+void spmv_amd_comm_set_world(SpmvAmdComm* comm);
+int spmv_amd_comm_rank(const SpmvAmdComm* comm);
+int spmv_amd_comm_size(const SpmvAmdComm* comm);
+
+/* ---- resident multi-GPU CG (what cg_solve_mgpu_partitioned is built from) ---- */
+typedef struct SpmvAmdCgSlab SpmvAmdCgSlab;
+
+/* Slab of a host matrix: build_csr_struct + slice + upload, as the reference does. */
+SpmvAmdCgSlab* spmv_amd_cg_slab_create(MatrixData* mat, SpmvAmdComm* comm);
+/* Slab of the synthetic n x n stencil, generated in HBM; b = 1, x0 = 0. */
+SpmvAmdCgSlab* spmv_amd_cg_slab_create_stencil5(int n, SpmvAmdComm* comm);
+/* Full-length host vectors as in the reference (each rank uploads its slab);
+ * NULL keeps b = 1 / x0 = 0. */
+int spmv_amd_cg_slab_set_vectors(SpmvAmdCgSlab* s, const double* b_full, const double* x0_full);
+/* One solve from the stored x0; the timed region is the reference's
+ * (cg_solver_mgpu_partitioned.cu:405-413 -> 728-731). */
+int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* config,
+                           CGStatsMultiGPU* stats);
+/* Gathers the solution into x_full on rank 0 (other ranks get their own slab). */
+int spmv_amd_cg_slab_gather(SpmvAmdCgSlab* s, double* x_full);
+int spmv_amd_cg_slab_history(SpmvAmdCgSlab* s, double* out, int cap);
+/* Slab-local SpMV on caller data: uploads x_full's slab + halos, returns y slab. */
+int spmv_amd_cg_slab_spmv(SpmvAmdCgSlab* s, const double* x_full, double* y_local);
+void spmv_amd_cg_slab_info(const SpmvAmdCgSlab* s, int* row_offset, int* n_local, int* local_nnz);
+/* Average duration (HIP events on the solver's stream) of `reps` launches of the
+ * slab SpMV kernel pair on the current direction vector. */
+int spmv_amd_cg_slab_time_spmv(SpmvAmdCgSlab* s, int reps, float* ms_each);
+void spmv_amd_cg_slab_destroy(SpmvAmdCgSlab* s);
+
+/* Library build string ("libspmv_amd <date> gfx950 ..."). */
+const char* spmv_amd_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* SPMV_AMD_API_H */

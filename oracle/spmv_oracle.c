@@ -1,0 +1,516 @@
+/* oracle/spmv_oracle.c -- see spmv_oracle.h. TEST INFRASTRUCTURE ONLY.
+ * Serial, single-threaded C. Build: gcc -O2 -mfma -ffp-contract=off (the only
+ * fused operations are the explicit fma() calls, which mirror nvcc's default
+ * contraction of the reference sources; see the header). */
+#include "spmv_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORACLE_BLOCK 256 /* threads per block in every reference launch (cg_solver.cu:160) */
+
+/* ------------------------------------------------------------------ */
+/* stencil generation (io.cu:322-399)                                  */
+/* ------------------------------------------------------------------ */
+
+long long oracle_stencil5_nnz(int n) { return 5LL * n * n - 4LL * n; }
+
+long long oracle_stencil5_coo(int n, double center, double off, OracleEntry* out) {
+    long long k = 0;
+    for (int gi = 0; gi < n; gi++) {
+        for (int gj = 0; gj < n; gj++) {
+            int idx = gi * n + gj;
+            out[k].row = idx, out[k].col = idx, out[k].value = center, k++;
+            if (gj > 0) out[k].row = idx, out[k].col = idx - 1, out[k].value = off, k++;
+            if (gj < n - 1) out[k].row = idx, out[k].col = idx + 1, out[k].value = off, k++;
+            if (gi > 0) out[k].row = idx, out[k].col = idx - n, out[k].value = off, k++;
+            if (gi < n - 1) out[k].row = idx, out[k].col = idx + n, out[k].value = off, k++;
+        }
+    }
+    return k;
+}
+
+void oracle_stencil5_csr(int n, double center, double off, int* row_ptr, int* col_idx,
+                         double* values) {
+    long long k = 0;
+    for (int gi = 0; gi < n; gi++) {
+        for (int gj = 0; gj < n; gj++) {
+            int idx = gi * n + gj;
+            row_ptr[idx] = (int)k;
+            if (gi > 0) col_idx[k] = idx - n, values[k] = off, k++;
+            if (gj > 0) col_idx[k] = idx - 1, values[k] = off, k++;
+            col_idx[k] = idx, values[k] = center, k++;
+            if (gj < n - 1) col_idx[k] = idx + 1, values[k] = off, k++;
+            if (gi < n - 1) col_idx[k] = idx + n, values[k] = off, k++;
+        }
+    }
+    row_ptr[(long long)n * n] = (int)k;
+}
+
+/* ------------------------------------------------------------------ */
+/* COO -> CSR (spmv_cusparse_csr.cu:62-170)                            */
+/* ------------------------------------------------------------------ */
+
+int oracle_build_csr(const OracleEntry* entries, int rows, int nnz, int* row_ptr, int* col_idx,
+                     double* values) {
+    memset(row_ptr, 0, ((size_t)rows + 1) * sizeof(int));
+    for (int i = 0; i < nnz; ++i) row_ptr[entries[i].row + 1]++;
+    for (int i = 1; i <= rows; ++i) row_ptr[i] += row_ptr[i - 1];
+
+    int* fill = (int*)calloc((size_t)rows, sizeof(int));
+    if (!fill) return 1;
+    for (int i = 0; i < nnz; ++i) {
+        int r = entries[i].row;
+        int dst = row_ptr[r] + fill[r]++;
+        col_idx[dst] = entries[i].col;
+        values[dst] = entries[i].value;
+    }
+    free(fill);
+
+    for (int r = 0; r < rows; ++r) {
+        int lo = row_ptr[r], hi = row_ptr[r + 1];
+        for (int i = lo + 1; i < hi; ++i) {
+            int kc = col_idx[i];
+            double kv = values[i];
+            int j = i - 1;
+            while (j >= lo && col_idx[j] > kc) {
+                col_idx[j + 1] = col_idx[j];
+                values[j + 1] = values[j];
+                j--;
+            }
+            col_idx[j + 1] = kc;
+            values[j + 1] = kv;
+        }
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* SpMV kernels                                                        */
+/* ------------------------------------------------------------------ */
+
+int oracle_interior_csr_offset(int row, int grid_size) {
+    int i = row / grid_size;
+    int j = row % grid_size;
+    int row0_nnz = 3 + (grid_size - 2) * 4 + 3;
+    int interior_row_nnz = 4 + (grid_size - 2) * 5 + 4;
+    int offset = row0_nnz + (i - 1) * interior_row_nnz;
+    offset += 4 + (j - 1) * 5;
+    return offset;
+}
+
+static inline double csr_row_sum(const int* col_idx, const double* values, const double* x, int lo,
+                                 int hi) {
+    double sum = 0.0;
+    for (int k = lo; k < hi; k++) sum = fma(values[k], x[col_idx[k]], sum);
+    return sum;
+}
+
+void oracle_spmv_csr(int rows, const int* row_ptr, const int* col_idx, const double* values,
+                     const double* x, double* y) {
+    for (int r = 0; r < rows; r++) y[r] = csr_row_sum(col_idx, values, x, row_ptr[r], row_ptr[r + 1]);
+}
+
+void oracle_spmv_stencil5(int rows, const int* row_ptr, const int* col_idx, const double* values,
+                          const double* x, double* y, int grid_size, double alpha) {
+    for (int row = 0; row < rows; row++) {
+        /* C division of a non-negative row by grid_size == -1 gives i = -row, so the
+         * interior test fails for every row, exactly as on the GPU. */
+        int i = grid_size != 0 ? row / grid_size : -1;
+        int j = grid_size != 0 ? row % grid_size : 0;
+        double sum;
+        if (i > 0 && i < grid_size - 1 && j > 0 && j < grid_size - 1) {
+            int o = oracle_interior_csr_offset(row, grid_size);
+            sum = values[o + 1] * x[row - 1];
+            sum = fma(values[o + 2], x[row], sum);
+            sum = fma(values[o + 3], x[row + 1], sum);
+            sum = fma(values[o + 0], x[row - grid_size], sum);
+            sum = fma(values[o + 4], x[row + grid_size], sum);
+        } else {
+            sum = csr_row_sum(col_idx, values, x, row_ptr[row], row_ptr[row + 1]);
+        }
+        y[row] = alpha * sum;
+    }
+}
+
+void oracle_spmv_halo(const int* row_ptr, const int* col_idx, const double* values,
+                      const double* x_local, const double* x_halo_prev, const double* x_halo_next,
+                      double* y, int n_local, int row_offset, int N, int grid_size) {
+    (void)N;
+    for (int local_row = 0; local_row < n_local; local_row++) {
+        int row = row_offset + local_row;
+        int i = row / grid_size;
+        int j = row % grid_size;
+        int lo = row_ptr[local_row], hi = row_ptr[local_row + 1];
+        double sum = 0.0;
+        if (i > 0 && i < grid_size - 1 && j > 0 && j < grid_size - 1 && (hi - lo) == 5) {
+            int idx_north = row - grid_size, idx_south = row + grid_size;
+            double vn, vs;
+            if (idx_north >= row_offset && idx_north < row_offset + n_local)
+                vn = x_local[idx_north - row_offset];
+            else if (idx_north >= row_offset - grid_size && idx_north < row_offset)
+                vn = x_halo_prev[idx_north - (row_offset - grid_size)];
+            else
+                vn = 0.0;
+            double vw = x_local[row - 1 - row_offset];
+            double vc = x_local[row - row_offset];
+            double ve = x_local[row + 1 - row_offset];
+            if (idx_south >= row_offset && idx_south < row_offset + n_local)
+                vs = x_local[idx_south - row_offset];
+            else if (idx_south >= row_offset + n_local && idx_south < row_offset + n_local + grid_size)
+                vs = x_halo_next[idx_south - (row_offset + n_local)];
+            else
+                vs = 0.0;
+            sum = values[lo + 1] * vw;
+            sum = fma(values[lo + 2], vc, sum);
+            sum = fma(values[lo + 3], ve, sum);
+            sum = fma(values[lo + 0], vn, sum);
+            sum = fma(values[lo + 4], vs, sum);
+        } else {
+            for (int k = lo; k < hi; k++) {
+                int gc = col_idx[k];
+                double v;
+                if (gc >= row_offset && gc < row_offset + n_local)
+                    v = x_local[gc - row_offset];
+                else if (x_halo_prev && gc >= row_offset - grid_size && gc < row_offset)
+                    v = x_halo_prev[gc - (row_offset - grid_size)];
+                else if (x_halo_next && gc >= row_offset + n_local &&
+                         gc < row_offset + n_local + grid_size)
+                    v = x_halo_next[gc - (row_offset + n_local)];
+                else
+                    v = 0.0;
+                sum = fma(values[k], v, sum);
+            }
+        }
+        y[local_row] = sum;
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* ELLPACK                                                             */
+/* ------------------------------------------------------------------ */
+
+int oracle_ell_width(int rows, const int* row_ptr) {
+    int w = 0;
+    for (int r = 0; r < rows; r++) {
+        int len = row_ptr[r + 1] - row_ptr[r];
+        if (len > w) w = len;
+    }
+    return w;
+}
+
+void oracle_build_ell(int rows, const int* row_ptr, const int* col_idx, const double* values,
+                      int width, int* ell_idx, double* ell_val) {
+    for (int r = 0; r < rows; r++) {
+        int lo = row_ptr[r], len = row_ptr[r + 1] - row_ptr[r];
+        for (int k = 0; k < width; k++) {
+            size_t at = (size_t)r * width + k;
+            if (k < len) {
+                ell_idx[at] = col_idx[lo + k];
+                ell_val[at] = values[lo + k];
+            } else {
+                ell_idx[at] = -1;
+                ell_val[at] = 0.0;
+            }
+        }
+    }
+}
+
+void oracle_spmv_ell(int rows, int width, const int* ell_idx, const double* ell_val,
+                     const double* x, double* y, double alpha, double beta) {
+    for (int r = 0; r < rows; r++) {
+        double sum = 0.0;
+        for (int k = 0; k < width; k++) {
+            size_t at = (size_t)r * width + k;
+            if (ell_idx[at] >= 0) sum = fma(ell_val[at], x[ell_idx[at]], sum);
+        }
+        /* beta == 0 overwrites y (no 0*NaN propagation), as the CSR operators do */
+        y[r] = (beta == 0.0) ? alpha * sum : fma(alpha, sum, beta * y[r]);
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* dot products (cg_solver.cu:110-149, 384-409)                        */
+/* ------------------------------------------------------------------ */
+
+static double block_partial(int n, const double* x, const double* y, int block) {
+    double s[ORACLE_BLOCK];
+    int base = block * ORACLE_BLOCK;
+    for (int t = 0; t < ORACLE_BLOCK; t++) {
+        int i = base + t;
+        s[t] = (i < n) ? x[i] * y[i] : 0.0;
+    }
+    for (int stride = ORACLE_BLOCK / 2; stride > 0; stride >>= 1)
+        for (int t = 0; t < stride; t++) s[t] += s[t + stride];
+    return s[0];
+}
+
+double oracle_dot_host(int n, const double* x, const double* y) {
+    int blocks = (n + ORACLE_BLOCK - 1) / ORACLE_BLOCK;
+    double sum = 0.0;
+    for (int b = 0; b < blocks; b++) sum += block_partial(n, x, y, b);
+    return sum;
+}
+
+double oracle_dot_device(int n, const double* x, const double* y) {
+    int blocks = (n + ORACLE_BLOCK - 1) / ORACLE_BLOCK;
+    double s[ORACLE_BLOCK];
+    for (int t = 0; t < ORACLE_BLOCK; t++) s[t] = 0.0;
+    /* thread t accumulates partials t, t+256, ... in that order */
+    for (int b = 0; b < blocks; b++) s[b % ORACLE_BLOCK] += block_partial(n, x, y, b);
+    for (int stride = ORACLE_BLOCK / 2; stride > 0; stride >>= 1)
+        for (int t = 0; t < stride; t++) s[t] += s[t + stride];
+    return s[0];
+}
+
+/* ------------------------------------------------------------------ */
+/* single-GPU CG (cg_solver.cu:154-378 and :436-706)                   */
+/* ------------------------------------------------------------------ */
+
+static void checksums(int n, const double* x, OracleCGResult* out) {
+    double s = 0.0, q = 0.0;
+    for (int i = 0; i < n; i++) {
+        s += x[i];
+        q += x[i] * x[i]; /* host loop (cg_solver.cu:336-342): plain x86-64 mul + add, no FMA */
+    }
+    out->solution_sum = s;
+    out->solution_norm = sqrt(q);
+}
+
+int oracle_cg(int n, const int* row_ptr, const int* col_idx, const double* values, int grid_size,
+              const double* b, double* x, int max_iters, double tol, int device_form,
+              double* history, int hist_cap, OracleCGResult* out) {
+    double* r = (double*)malloc((size_t)n * sizeof(double));
+    double* p = (double*)malloc((size_t)n * sizeof(double));
+    double* Ap = (double*)malloc((size_t)n * sizeof(double));
+    if (!r || !p || !Ap) return 1;
+    double (*dot)(int, const double*, const double*) = device_form ? oracle_dot_device : oracle_dot_host;
+
+    oracle_spmv_stencil5(n, row_ptr, col_idx, values, x, Ap, grid_size, 1.0);
+    /* axpby_kernel(n, 1.0, b, -1.0, Ap, r): z = alpha*x + beta*y */
+    for (int i = 0; i < n; i++) r[i] = fma(1.0, b[i], -1.0 * Ap[i]);
+    memcpy(p, r, (size_t)n * sizeof(double));
+    double rr_old = dot(n, r, r);
+    double b_norm = sqrt(rr_old);
+    if (history && hist_cap > 0) history[0] = b_norm;
+
+    double residual = b_norm;
+    int converged_flag = 0;
+    int iter;
+    for (iter = 0; iter < max_iters; iter++) {
+        oracle_spmv_stencil5(n, row_ptr, col_idx, values, p, Ap, grid_size, 1.0);
+        double pAp = dot(n, Ap, p);
+        double alpha = rr_old / pAp;
+        for (int i = 0; i < n; i++) x[i] = fma(alpha, p[i], x[i]);
+        for (int i = 0; i < n; i++) r[i] = fma(-alpha, Ap[i], r[i]);
+        double rr_new = dot(n, r, r);
+        double res = sqrt(rr_new);
+        if (!device_form) residual = res;
+        if (history && iter + 1 < hist_cap) history[iter + 1] = res;
+        if (res / b_norm < tol) {
+            residual = res;
+            converged_flag = 1;
+            iter++;
+            break;
+        }
+        double beta = rr_new / rr_old;
+        if (device_form) {
+            for (int i = 0; i < n; i++) p[i] = fma(beta, p[i], r[i]); /* update_p_kernel */
+        } else {
+            for (int i = 0; i < n; i++) p[i] = fma(1.0, r[i], beta * p[i]); /* axpby_kernel */
+        }
+        rr_old = rr_new;
+    }
+    (void)converged_flag;
+    out->iterations = iter;
+    /* device form: final_residual_norm keeps b_norm unless the loop converged (:535,613-619) */
+    out->residual_norm = residual;
+    out->b_norm = b_norm;
+    out->converged = (residual / b_norm < tol) ? 1 : 0;
+    checksums(n, x, out);
+    free(r);
+    free(p);
+    free(Ap);
+    return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* multi-GPU CG, ranks simulated in sequence                           */
+/* ------------------------------------------------------------------ */
+
+void oracle_partition_rows(int n, int world, int rank, int* row_offset, int* n_local) {
+    int nl = n / world;
+    int off = rank * nl;
+    if (rank == world - 1) nl = n - off;
+    *row_offset = off;
+    *n_local = nl;
+}
+
+typedef struct {
+    int row_offset, n_local;
+    int* row_ptr; /* rebased */
+    const int* col_idx;
+    const double* values;
+    double *x, *r, *p, *Ap, *b;
+    double *halo_prev, *halo_next; /* of the vector currently being multiplied */
+} Slab;
+
+static void exchange(Slab* s, int world, int g, int which /*0:x 1:r 2:p*/) {
+    for (int k = 0; k < world; k++) {
+        const double* src_prev = NULL;
+        const double* src_next = NULL;
+        if (k > 0) {
+            Slab* o = &s[k - 1];
+            const double* v = which == 0 ? o->x : which == 1 ? o->r : o->p;
+            src_prev = v + (o->n_local - g); /* neighbour's last grid row */
+        }
+        if (k < world - 1) {
+            Slab* o = &s[k + 1];
+            const double* v = which == 0 ? o->x : which == 1 ? o->r : o->p;
+            src_next = v; /* neighbour's first grid row */
+        }
+        if (src_prev) memcpy(s[k].halo_prev, src_prev, (size_t)g * sizeof(double));
+        if (src_next) memcpy(s[k].halo_next, src_next, (size_t)g * sizeof(double));
+    }
+}
+
+int oracle_cg_partitioned(int n, const int* row_ptr, const int* col_idx, const double* values,
+                          int grid_size, const double* b, double* x, int max_iters, double tol,
+                          int world, double* history, int hist_cap, OracleCGResult* out) {
+    int g = grid_size;
+    Slab* s = (Slab*)calloc((size_t)world, sizeof(Slab));
+    if (!s) return 1;
+    for (int k = 0; k < world; k++) {
+        Slab* L = &s[k];
+        oracle_partition_rows(n, world, k, &L->row_offset, &L->n_local);
+        if (L->n_local < g) return 2; /* the reference sends n_local - grid_size.. : needs a full grid row */
+        /* A slab that starts or ends inside a grid row makes the reference's interior branch read
+         * x_local[-1] / x_local[n_local] (spmv_stencil_partitioned_halo_kernel.cu:56-58: "always
+         * local for interior"), i.e. undefined behaviour; parity is only defined for slabs made of
+         * whole grid rows, which is what every published configuration uses. */
+        if (L->row_offset % g != 0 || L->n_local % g != 0) return 3;
+        int base = row_ptr[L->row_offset];
+        L->row_ptr = (int*)malloc(((size_t)L->n_local + 1) * sizeof(int));
+        for (int i = 0; i <= L->n_local; i++) L->row_ptr[i] = row_ptr[L->row_offset + i] - base;
+        L->col_idx = col_idx + base;
+        L->values = values + base;
+        size_t bytes = (size_t)L->n_local * sizeof(double);
+        L->x = (double*)malloc(bytes), L->r = (double*)calloc(L->n_local, sizeof(double));
+        L->p = (double*)calloc(L->n_local, sizeof(double)), L->Ap = (double*)malloc(bytes);
+        L->b = (double*)malloc(bytes);
+        memcpy(L->x, x + L->row_offset, bytes);
+        memcpy(L->b, b + L->row_offset, bytes);
+        L->halo_prev = k > 0 ? (double*)malloc((size_t)g * sizeof(double)) : NULL;
+        L->halo_next = k < world - 1 ? (double*)malloc((size_t)g * sizeof(double)) : NULL;
+    }
+
+#define FOR_RANKS for (int k = 0; k < world; k++)
+#define SPMV(vec)                                                                                \
+    FOR_RANKS oracle_spmv_halo(s[k].row_ptr, s[k].col_idx, s[k].values, s[k].vec, s[k].halo_prev, \
+                               s[k].halo_next, s[k].Ap, s[k].n_local, s[k].row_offset, n, g)
+
+    exchange(s, world, g, 0);
+    SPMV(x);
+    /* axpy_kernel(-1.0, Ap, b): y = alpha*x + y ; then r = b */
+    FOR_RANKS for (int i = 0; i < s[k].n_local; i++) s[k].b[i] = fma(-1.0, s[k].Ap[i], s[k].b[i]);
+    FOR_RANKS memcpy(s[k].r, s[k].b, (size_t)s[k].n_local * sizeof(double));
+    FOR_RANKS memcpy(s[k].p, s[k].r, (size_t)s[k].n_local * sizeof(double));
+    exchange(s, world, g, 2); /* r halos copied into the p halos == halos of p = r */
+
+    double rs_old = 0.0;
+    FOR_RANKS rs_old += oracle_dot_host(s[k].n_local, s[k].r, s[k].r);
+    double b_norm = sqrt(rs_old);
+    if (history && hist_cap > 0) history[0] = b_norm;
+
+    out->converged = 0;
+    out->b_norm = b_norm;
+    int iter;
+    for (iter = 0; iter < max_iters; iter++) {
+        SPMV(p);
+        double pAp = 0.0;
+        FOR_RANKS pAp += oracle_dot_host(s[k].n_local, s[k].p, s[k].Ap);
+        double alpha = rs_old / pAp;
+        FOR_RANKS for (int i = 0; i < s[k].n_local; i++) s[k].x[i] = fma(alpha, s[k].p[i], s[k].x[i]);
+        FOR_RANKS for (int i = 0; i < s[k].n_local; i++) s[k].r[i] = fma(-alpha, s[k].Ap[i], s[k].r[i]);
+        double rs_new = 0.0;
+        FOR_RANKS rs_new += oracle_dot_host(s[k].n_local, s[k].r, s[k].r);
+        double res = sqrt(rs_new);
+        if (history && iter + 1 < hist_cap) history[iter + 1] = res;
+        if (res / b_norm < tol) {
+            iter++;
+            out->converged = 1;
+            out->iterations = iter;
+            out->residual_norm = res;
+            break;
+        }
+        double beta = rs_new / rs_old;
+        /* axpby_kernel(1.0, r, beta, p): y = alpha*x + beta*y */
+        FOR_RANKS for (int i = 0; i < s[k].n_local; i++) s[k].p[i] = fma(1.0, s[k].r[i], beta * s[k].p[i]);
+        exchange(s, world, g, 2);
+        rs_old = rs_new;
+    }
+    if (iter == max_iters && !out->converged) {
+        out->iterations = iter;
+        out->residual_norm = sqrt(rs_old);
+    }
+    FOR_RANKS memcpy(x + s[k].row_offset, s[k].x, (size_t)s[k].n_local * sizeof(double));
+    checksums(n, x, out);
+
+    FOR_RANKS {
+        free(s[k].row_ptr), free(s[k].x), free(s[k].r), free(s[k].p), free(s[k].Ap), free(s[k].b);
+        free(s[k].halo_prev), free(s[k].halo_next);
+    }
+    free(s);
+#undef SPMV
+#undef FOR_RANKS
+    return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* harness statistics and metrics                                      */
+/* ------------------------------------------------------------------ */
+
+static int cmp_double(const void* a, const void* b) {
+    double da = *(const double*)a, db = *(const double*)b;
+    return (da > db) - (da < db);
+}
+
+static double mean_of(const double* t, int c) {
+    double s = 0.0;
+    for (int i = 0; i < c; i++) s += t[i];
+    return s / c;
+}
+
+static double std_of(const double* t, int c, double mean) {
+    double q = 0.0;
+    for (int i = 0; i < c; i++) q += (t[i] - mean) * (t[i] - mean);
+    return sqrt(q / c);
+}
+
+int oracle_bench_stats(const double* times, int count, OracleBenchStats* out) {
+    if (count < 3) return -1;
+    double mean = mean_of(times, count), sd = std_of(times, count, mean);
+    double* kept = (double*)malloc((size_t)count * sizeof(double));
+    int m = 0;
+    for (int i = 0; i < count; i++)
+        if (fabs(times[i] - mean) <= 2.0 * sd) kept[m++] = times[i];
+    out->mean_ms = mean_of(kept, m);
+    out->std_dev_ms = std_of(kept, m, out->mean_ms);
+    qsort(kept, m, sizeof(double), cmp_double);
+    out->median_ms = (m % 2 == 0) ? (kept[m / 2 - 1] + kept[m / 2]) / 2.0 : kept[m / 2];
+    out->min_ms = kept[0];
+    out->max_ms = kept[m - 1];
+    out->valid_runs = m;
+    out->outliers_removed = count - m;
+    free(kept);
+    return 0;
+}
+
+void oracle_spmv_metrics(double ms, int rows, int cols, int nnz, double* gflops, double* gbs) {
+    double secs = ms / 1000.0;
+    *gflops = (2.0 * nnz / secs) / 1e9;
+    double bytes = (double)nnz * 8.0 + ((double)nnz * 4.0 + ((double)rows + 1.0) * 4.0) +
+                   (double)cols * 8.0 + (double)rows * 8.0;
+    *gbs = (bytes / secs) / 1e9;
+}
