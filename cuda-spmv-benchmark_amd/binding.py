@@ -1,0 +1,429 @@
+"""ctypes binding of libspmv_amd.so, used by tests/, bench.py and __graft_entry__.py.
+
+This module is plumbing only: every compute call goes through the C-ABI declared in
+include/spmv_amd/api.h into hand-written HIP kernels. There is no CPU fallback; if the
+library has not been built, or no GPU is visible when a compute entry point is called, the
+call fails loudly.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG_DIR, "lib", "libspmv_amd.so")
+
+ENTRY_DTYPE = np.dtype([("row", np.int32), ("col", np.int32), ("value", np.float64)], align=True)
+assert ENTRY_DTYPE.itemsize == 16
+COMM_ID_BYTES = 256
+
+
+# ---------------------------------------------------------------- structs (include/spmv_amd/types.h)
+class MatrixData(C.Structure):
+    _fields_ = [("rows", C.c_int), ("cols", C.c_int), ("nnz", C.c_int), ("grid_size", C.c_int), ("entries", C.c_void_p)]
+
+
+class CSRMatrix(C.Structure):
+    _fields_ = [("nb_rows", C.c_int), ("nb_cols", C.c_int), ("nb_nonzeros", C.c_int), ("row_ptr", C.POINTER(C.c_int)), ("col_indices", C.POINTER(C.c_int)), ("values", C.POINTER(C.c_double))]
+
+
+class ELLPACKMatrix(C.Structure):
+    _fields_ = [("nb_rows", C.c_int), ("nb_cols", C.c_int), ("ell_width", C.c_int), ("grid_size", C.c_int), ("indices", C.POINTER(C.c_int)), ("nb_nonzeros", C.c_int), ("values", C.POINTER(C.c_double))]
+
+
+INIT_FN = C.CFUNCTYPE(C.c_int, C.POINTER(MatrixData))
+RUN_TIMED_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_double))
+RUN_DEVICE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)
+FREE_FN = C.CFUNCTYPE(None)
+
+
+class SpmvOperator(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("init", INIT_FN), ("run_timed", RUN_TIMED_FN), ("run_device", RUN_DEVICE_FN), ("free", FREE_FN)]
+
+
+class BenchmarkStats(C.Structure):
+    _fields_ = [("median_ms", C.c_double), ("mean_ms", C.c_double), ("std_dev_ms", C.c_double), ("min_ms", C.c_double), ("max_ms", C.c_double), ("valid_runs", C.c_int), ("outliers_removed", C.c_int)]
+
+
+class CGConfig(C.Structure):
+    _fields_ = [("max_iters", C.c_int), ("tolerance", C.c_double), ("verbose", C.c_int), ("enable_detailed_timers", C.c_int)]
+
+
+class CGStats(C.Structure):
+    _fields_ = [("iterations", C.c_int), ("residual_norm", C.c_double), ("time_total_ms", C.c_double), ("time_spmv_ms", C.c_double), ("time_blas1_ms", C.c_double), ("time_reductions_ms", C.c_double), ("converged", C.c_int), ("solution_sum", C.c_double), ("solution_norm", C.c_double)]
+
+
+CGConfigMultiGPU = CGConfig  # same layout (include/spmv_amd/types.h)
+
+
+class CGStatsMultiGPU(C.Structure):
+    _fields_ = [
+        ("iterations", C.c_int), ("residual_norm", C.c_double), ("time_total_ms", C.c_double), ("time_spmv_ms", C.c_double),
+        ("time_blas1_ms", C.c_double), ("time_reductions_ms", C.c_double), ("time_allreduce_ms", C.c_double),
+        ("time_allgather_ms", C.c_double), ("converged", C.c_int), ("time_dot_rs_initial_ms", C.c_double),
+        ("time_dot_pAp_ms", C.c_double), ("time_dot_rs_new_ms", C.c_double), ("time_axpy_update_x_ms", C.c_double),
+        ("time_axpy_update_r_ms", C.c_double), ("time_axpby_update_p_ms", C.c_double), ("time_initial_r_ms", C.c_double),
+        ("solution_sum", C.c_double), ("solution_norm", C.c_double),
+    ]
+
+
+HALO_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int)
+GATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_int))
+BARRIER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p)
+
+# Every extern "C" symbol include/spmv_amd/api.h declares (the CPU test-suite checks them all).
+DECLARED_SYMBOLS = [
+    "csr_mat", "ellpack_matrix", "build_ellpack_from_csr_local", "ensure_ellpack_structure_built", "get_operator",
+    "calculate_spmv_metrics", "get_gpu_properties", "print_benchmark_metrics", "print_metrics_json", "print_metrics_csv",
+    "read_matrix_type", "read_matrix_general", "read_matrix_symtogen", "load_matrix_market", "convert_csr_to_ellpack",
+    "write_matrix_market_stencil5", "benchmark_with_stats", "cg_benchmark_with_stats_device",
+    "cg_benchmark_with_stats_mgpu_partitioned", "export_cg_json", "export_cg_mgpu_json", "export_cg_csv",
+    "spmv_amd_build_csr_struct", "spmv_amd_build_ellpack_from_csr_struct", "spmv_amd_cg_solve", "spmv_amd_cg_solve_device",
+    "spmv_amd_cg_solve_mgpu_partitioned", "spmv_amd_reset_host_matrices", "spmv_amd_interior_csr_offset",
+    "spmv_amd_partition_rows", "spmv_amd_device_count", "spmv_amd_set_device", "spmv_amd_device_alloc", "spmv_amd_device_free",
+    "spmv_amd_copy_to_device", "spmv_amd_copy_to_host", "spmv_amd_device_fill_f64", "spmv_amd_device_synchronize",
+    "spmv_amd_init_stencil5_synthetic", "spmv_amd_download_device_csr", "spmv_amd_time_run_device", "spmv_amd_operator_variant",
+    "spmv_amd_operator_select_variant", "spmv_amd_cg_last_history", "spmv_amd_comm_unique_id", "spmv_amd_comm_create_rccl",
+    "spmv_amd_comm_create_staged", "spmv_amd_comm_destroy", "spmv_amd_comm_set_world", "spmv_amd_comm_rank", "spmv_amd_comm_size",
+    "spmv_amd_cg_slab_create", "spmv_amd_cg_slab_create_stencil5", "spmv_amd_cg_slab_set_vectors", "spmv_amd_cg_slab_solve",
+    "spmv_amd_cg_slab_gather", "spmv_amd_cg_slab_history", "spmv_amd_cg_slab_spmv", "spmv_amd_cg_slab_info",
+    "spmv_amd_cg_slab_time_spmv", "spmv_amd_cg_slab_destroy", "spmv_amd_version", "spmv_amd_write_stencil5_values",
+]
+# C++-linkage entry points kept under the reference's own names (Itanium-mangled).
+DECLARED_CXX_SYMBOLS = [
+    "SPMV_CSR", "SPMV_STENCIL5_CSR", "SPMV_STENCIL_HALO_MGPU", "SPMV_ELLPACK", "SPMV_STENCIL5_ELLPACK",
+    "_Z16build_csr_structP10MatrixData",
+    "_Z29build_ellpack_from_csr_structPK9CSRMatrixP13ELLPACKMatrixPi",
+    "_Z8cg_solveP12SpmvOperatorP10MatrixDataPKdPd8CGConfigP7CGStats",
+    "_Z15cg_solve_deviceP12SpmvOperatorP10MatrixDataPKdPd8CGConfigP7CGStats",
+    "_Z25cg_solve_mgpu_partitionedP12SpmvOperatorP10MatrixDataPKdPd16CGConfigMultiGPUP15CGStatsMultiGPU",
+]
+
+
+def build(force=False):
+    """Compiles libspmv_amd.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    if force:
+        subprocess.check_call(["make", "-C", PKG_DIR, "clean"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", PKG_DIR, "-j8"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("libspmv_amd.so was not produced by the build")
+
+
+_lib = None
+
+
+def lib():
+    """The loaded library. Raises if it has not been built: there is no fallback path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc)")
+    L = C.CDLL(LIB_PATH)
+    L.get_operator.restype = C.POINTER(SpmvOperator)
+    L.get_operator.argtypes = [C.c_char_p]
+    L.spmv_amd_version.restype = C.c_char_p
+    L.spmv_amd_operator_variant.restype = C.c_char_p
+    L.spmv_amd_operator_variant.argtypes = [C.c_char_p]
+    L.spmv_amd_operator_select_variant.argtypes = [C.c_char_p, C.c_char_p]
+    L.spmv_amd_device_alloc.restype = C.c_void_p
+    L.spmv_amd_device_alloc.argtypes = [C.c_size_t]
+    L.spmv_amd_device_free.argtypes = [C.c_void_p]
+    L.spmv_amd_copy_to_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    L.spmv_amd_copy_to_host.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    L.spmv_amd_device_fill_f64.argtypes = [C.c_void_p, C.c_size_t, C.c_double]
+    L.spmv_amd_init_stencil5_synthetic.argtypes = [C.c_char_p, C.c_int]
+    L.spmv_amd_download_device_csr.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.spmv_amd_time_run_device.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_float)]
+    L.spmv_amd_cg_solve.argtypes = [C.POINTER(SpmvOperator), C.POINTER(MatrixData), C.c_void_p, C.c_void_p, C.POINTER(CGConfig), C.POINTER(CGStats)]
+    L.spmv_amd_cg_solve_device.argtypes = L.spmv_amd_cg_solve.argtypes
+    L.spmv_amd_cg_solve_mgpu_partitioned.argtypes = [C.POINTER(MatrixData), C.c_void_p, C.c_void_p, C.POINTER(CGConfig), C.POINTER(CGStatsMultiGPU)]
+    L.spmv_amd_cg_last_history.argtypes = [C.c_void_p, C.c_int]
+    L.spmv_amd_comm_unique_id.argtypes = [C.c_void_p]
+    L.spmv_amd_comm_create_rccl.restype = C.c_void_p
+    L.spmv_amd_comm_create_rccl.argtypes = [C.c_int, C.c_int, C.c_void_p]
+    L.spmv_amd_comm_create_staged.restype = C.c_void_p
+    L.spmv_amd_comm_create_staged.argtypes = [C.c_int, C.c_int, HALO_FN, ALLREDUCE_FN, GATHER_FN, BARRIER_FN, C.c_void_p]
+    L.spmv_amd_comm_destroy.argtypes = [C.c_void_p]
+    L.spmv_amd_comm_set_world.argtypes = [C.c_void_p]
+    L.spmv_amd_cg_slab_create.restype = C.c_void_p
+    L.spmv_amd_cg_slab_create.argtypes = [C.POINTER(MatrixData), C.c_void_p]
+    L.spmv_amd_cg_slab_create_stencil5.restype = C.c_void_p
+    L.spmv_amd_cg_slab_create_stencil5.argtypes = [C.c_int, C.c_void_p]
+    L.spmv_amd_cg_slab_set_vectors.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.spmv_amd_cg_slab_solve.argtypes = [C.c_void_p, C.POINTER(CGConfig), C.POINTER(CGStatsMultiGPU)]
+    L.spmv_amd_cg_slab_gather.argtypes = [C.c_void_p, C.c_void_p]
+    L.spmv_amd_cg_slab_history.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    L.spmv_amd_cg_slab_spmv.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.spmv_amd_cg_slab_info.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.spmv_amd_cg_slab_time_spmv.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float)]
+    L.spmv_amd_cg_slab_destroy.argtypes = [C.c_void_p]
+    L.load_matrix_market.argtypes = [C.c_char_p, C.POINTER(MatrixData)]
+    L.write_matrix_market_stencil5.argtypes = [C.c_int, C.c_char_p]
+    L.spmv_amd_write_stencil5_values.argtypes = [C.c_int, C.c_char_p, C.c_char_p, C.c_char_p]
+    L.read_matrix_type.argtypes = [C.c_char_p]
+    L.spmv_amd_partition_rows.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.benchmark_with_stats.argtypes = [RUN_TIMED_FN, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(BenchmarkStats)]
+    _lib = L
+    return L
+
+
+def require_gpu():
+    if lib().spmv_amd_device_count() < 1:
+        raise RuntimeError("no HIP device visible: libspmv_amd has no CPU path")
+
+
+def csr_mat():
+    return CSRMatrix.in_dll(lib(), "csr_mat")
+
+
+def ellpack_matrix():
+    return ELLPACKMatrix.in_dll(lib(), "ellpack_matrix")
+
+
+# ---------------------------------------------------------------- host-side helpers
+class HostMatrix:
+    """A MatrixData whose entries live in a numpy array owned by this object."""
+
+    def __init__(self, entries, rows, cols, grid_size=-1):
+        self.entries = np.ascontiguousarray(entries, dtype=ENTRY_DTYPE)
+        self.c = MatrixData(int(rows), int(cols), len(self.entries), int(grid_size), self.entries.ctypes.data)
+
+    @property
+    def ptr(self):
+        return C.byref(self.c)
+
+
+def load_matrix_market(path):
+    m = MatrixData()
+    rc = lib().load_matrix_market(os.fsencode(path), C.byref(m))
+    if rc != 0:
+        raise IOError(f"load_matrix_market({path}) -> {rc}")
+    e = np.ctypeslib.as_array((C.c_byte * (16 * m.nnz)).from_address(m.entries)).view(ENTRY_DTYPE).copy()
+    C.CDLL(None).free(C.c_void_p(m.entries))
+    return HostMatrix(e, m.rows, m.cols, m.grid_size)
+
+
+def host_csr_arrays():
+    """Copies of the process-wide csr_mat built by build_csr_struct."""
+    m = csr_mat()
+    rp = np.ctypeslib.as_array(m.row_ptr, shape=(m.nb_rows + 1,)).copy()
+    ci = np.ctypeslib.as_array(m.col_indices, shape=(m.nb_nonzeros,)).copy()
+    va = np.ctypeslib.as_array(m.values, shape=(m.nb_nonzeros,)).copy()
+    return rp, ci, va
+
+
+def host_ell_arrays():
+    m = ellpack_matrix()
+    n = m.nb_rows * m.ell_width
+    return m.ell_width, np.ctypeslib.as_array(m.indices, shape=(n,)).copy(), np.ctypeslib.as_array(m.values, shape=(n,)).copy()
+
+
+def partition_rows(n, world, rank):
+    off, nl = C.c_int(), C.c_int()
+    lib().spmv_amd_partition_rows(n, world, rank, C.byref(off), C.byref(nl))
+    return off.value, nl.value
+
+
+# ---------------------------------------------------------------- device-side helpers
+class DeviceVector:
+    def __init__(self, count, fill=None):
+        self.count = int(count)
+        self.ptr = lib().spmv_amd_device_alloc(self.count * 8)
+        if fill is not None:
+            lib().spmv_amd_device_fill_f64(self.ptr, self.count, float(fill))
+
+    @classmethod
+    def from_host(cls, a):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        v = cls(len(a))
+        lib().spmv_amd_copy_to_device(v.ptr, a.ctypes.data, a.nbytes)
+        return v
+
+    def to_host(self):
+        out = np.empty(self.count, dtype=np.float64)
+        lib().spmv_amd_device_synchronize()
+        lib().spmv_amd_copy_to_host(out.ctypes.data, self.ptr, out.nbytes)
+        return out
+
+    def free(self):
+        if self.ptr:
+            lib().spmv_amd_device_free(self.ptr)
+            self.ptr = None
+
+
+class Operator:
+    """get_operator(name) with numpy-friendly wrappers around the vtable."""
+
+    def __init__(self, name):
+        self.name = name
+        p = lib().get_operator(name.encode())
+        if not p:
+            raise KeyError(name)
+        self.op = p
+        self.rows = self.cols = 0
+
+    @property
+    def canonical_name(self):
+        return self.op.contents.name.decode()
+
+    def init(self, host_matrix):
+        require_gpu()
+        rc = self.op.contents.init(host_matrix.ptr)
+        self.rows, self.cols = host_matrix.c.rows, host_matrix.c.cols
+        return rc
+
+    def init_synthetic(self, n):
+        require_gpu()
+        rc = lib().spmv_amd_init_stencil5_synthetic(self.name.encode(), int(n))
+        self.rows = self.cols = n * n
+        return rc
+
+    def run_timed(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        assert len(x) == self.cols
+        y = np.zeros(self.rows, dtype=np.float64)
+        ms = C.c_double()
+        rc = self.op.contents.run_timed(x.ctypes.data, y.ctypes.data, C.byref(ms))
+        if rc != 0:
+            raise RuntimeError(f"run_timed -> {rc}")
+        return y, ms.value
+
+    def run_device(self, d_x, d_y):
+        return self.op.contents.run_device(d_x.ptr, d_y.ptr)
+
+    def time_device(self, d_x, d_y, reps):
+        ms = (C.c_float * reps)()
+        rc = lib().spmv_amd_time_run_device(self.name.encode(), d_x.ptr, d_y.ptr, reps, ms)
+        if rc != 0:
+            raise RuntimeError(f"time_run_device -> {rc}")
+        return np.array(ms[:], dtype=np.float64)
+
+    def variant(self):
+        return lib().spmv_amd_operator_variant(self.name.encode()).decode()
+
+    def select_variant(self, variant):
+        return lib().spmv_amd_operator_select_variant(self.name.encode(), None if variant is None else variant.encode())
+
+    def download_csr(self, rows, nnz):
+        rp = np.empty(rows + 1, dtype=np.int32)
+        ci = np.empty(nnz, dtype=np.int32)
+        va = np.empty(nnz, dtype=np.float64)
+        rc = lib().spmv_amd_download_device_csr(self.name.encode(), rp.ctypes.data, ci.ctypes.data, va.ctypes.data)
+        assert rc == 0
+        return rp, ci, va
+
+    def free(self):
+        self.op.contents.free()
+
+
+def cg_solve(op, host_matrix, b, x0, max_iters=1000, tol=1e-6, device=True, verbose=0, timers=0):
+    """cg_solve_device (device=True) or cg_solve through the C-ABI; returns x, history, stats."""
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    x = np.ascontiguousarray(x0, dtype=np.float64).copy()
+    cfg = CGConfig(max_iters, tol, verbose, timers)
+    st = CGStats()
+    fn = lib().spmv_amd_cg_solve_device if device else lib().spmv_amd_cg_solve
+    rc = fn(op.op, host_matrix.ptr, b.ctypes.data, x.ctypes.data, C.byref(cfg), C.byref(st))
+    if rc != 0:
+        raise RuntimeError(f"cg_solve -> {rc}")
+    hist = np.zeros(max_iters + 1, dtype=np.float64)
+    count = lib().spmv_amd_cg_last_history(hist.ctypes.data, len(hist))
+    return x, hist[:count].copy(), st
+
+
+class Comm:
+    """Owner of an SpmvAmdComm handle (and of the ctypes callbacks of a staged one)."""
+
+    def __init__(self, handle, keep=()):
+        self.handle = handle
+        self._keep = keep
+
+    @classmethod
+    def rccl(cls, rank, world, id_bytes):
+        buf = C.create_string_buffer(bytes(id_bytes), COMM_ID_BYTES)
+        h = lib().spmv_amd_comm_create_rccl(rank, world, buf)
+        return cls(h)
+
+    @classmethod
+    def staged(cls, rank, world, halo, allreduce, gather=None, barrier=None):
+        cbs = (HALO_FN(halo), ALLREDUCE_FN(allreduce), GATHER_FN(gather) if gather else GATHER_FN(), BARRIER_FN(barrier) if barrier else BARRIER_FN())
+        h = lib().spmv_amd_comm_create_staged(rank, world, cbs[0], cbs[1], cbs[2], cbs[3], None)
+        if not h:
+            raise RuntimeError("spmv_amd_comm_create_staged failed")
+        return cls(h, cbs)
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(COMM_ID_BYTES)
+        lib().spmv_amd_comm_unique_id(buf)
+        return buf.raw
+
+    def destroy(self):
+        if self.handle:
+            lib().spmv_amd_comm_destroy(self.handle)
+            self.handle = None
+
+
+class CgSlab:
+    """Resident multi-GPU CG state (spmv_amd_cg_slab_*)."""
+
+    def __init__(self, handle, n_rows):
+        if not handle:
+            raise RuntimeError("spmv_amd_cg_slab_create failed")
+        self.h = handle
+        self.n_rows = n_rows
+        off, nl, nz = C.c_int(), C.c_int(), C.c_int()
+        lib().spmv_amd_cg_slab_info(self.h, C.byref(off), C.byref(nl), C.byref(nz))
+        self.row_offset, self.n_local, self.local_nnz = off.value, nl.value, nz.value
+
+    @classmethod
+    def from_matrix(cls, host_matrix, comm=None):
+        require_gpu()
+        return cls(lib().spmv_amd_cg_slab_create(host_matrix.ptr, comm.handle if comm else None), host_matrix.c.rows)
+
+    @classmethod
+    def stencil5(cls, n, comm=None):
+        require_gpu()
+        return cls(lib().spmv_amd_cg_slab_create_stencil5(int(n), comm.handle if comm else None), n * n)
+
+    def set_vectors(self, b=None, x0=None):
+        b = None if b is None else np.ascontiguousarray(b, dtype=np.float64)
+        x0 = None if x0 is None else np.ascontiguousarray(x0, dtype=np.float64)
+        lib().spmv_amd_cg_slab_set_vectors(self.h, None if b is None else b.ctypes.data, None if x0 is None else x0.ctypes.data)
+
+    def solve(self, max_iters=1000, tol=1e-6, verbose=0, timers=0):
+        cfg = CGConfig(max_iters, tol, verbose, timers)
+        st = CGStatsMultiGPU()
+        rc = lib().spmv_amd_cg_slab_solve(self.h, C.byref(cfg), C.byref(st))
+        if rc != 0:
+            raise RuntimeError(f"cg_slab_solve -> {rc}")
+        return st
+
+    def history(self, cap=1001):
+        h = np.zeros(cap, dtype=np.float64)
+        count = lib().spmv_amd_cg_slab_history(self.h, h.ctypes.data, cap)
+        return h[: min(count, cap)].copy()
+
+    def gather(self):
+        x = np.zeros(self.n_rows, dtype=np.float64)
+        lib().spmv_amd_cg_slab_gather(self.h, x.ctypes.data)
+        return x
+
+    def spmv(self, x_full):
+        x_full = np.ascontiguousarray(x_full, dtype=np.float64)
+        y = np.zeros(self.n_local, dtype=np.float64)
+        lib().spmv_amd_cg_slab_spmv(self.h, x_full.ctypes.data, y.ctypes.data)
+        return y
+
+    def time_spmv(self, reps):
+        ms = (C.c_float * reps)()
+        lib().spmv_amd_cg_slab_time_spmv(self.h, reps, ms)
+        return np.array(ms[:], dtype=np.float64)
+
+    def destroy(self):
+        if self.h:
+            lib().spmv_amd_cg_slab_destroy(self.h)
+            self.h = None

@@ -1,0 +1,352 @@
+// cg_kernels.hip -- BLAS1, reductions and scalar steps of Conjugate Gradient on gfx950.
+//
+// Element-wise arithmetic follows the reference kernels with nvcc's contraction written
+// out as explicit fma() (file compiled with -ffp-contract=off):
+//   axpy_kernel          y = fma(a, x, y)               cg_solver.cu:38-43 ; mgpu :125-130
+//   axpby_kernel         z = fma(a, x, b*y)             cg_solver.cu:48-54 ; mgpu :136-140
+//   axpy_kernel_device   y = fma(*a, x, y)              cg_solver.cu:59-64
+//   axpy_sub_kernel_dev  y = fma(-(*a), x, y)           cg_solver.cu:69-74
+//   update_p_kernel      p = fma(*b, p, r)              cg_solver.cu:90-95
+// Reductions use a fixed shape (grid-stride lanes -> wave shuffle tree -> one partial per
+// wave -> single-block tree), so a solve is bit-reproducible run to run; the summation order
+// differs from the reference's 256-wide blocks, which SURVEY.md section 8 allows (1e-10).
+//
+// All streaming kernels move 16 bytes per lane and use a capped grid with a grid-stride loop.
+#include "kernels.hpp"
+
+namespace spmv_amd {
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kWavesPerBlock = 4;
+constexpr int kStreamBlocks = 2048;  // 256 CUs x 8 blocks: memory-bound grid cap
+constexpr int kPartials = kStreamBlocks * kWavesPerBlock;
+
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    return v;
+}
+
+// Runs body(i) for pairs (2i, 2i+1) with 16-byte accesses, and the odd tail element.
+#define SPMV_AMD_STREAM_LOOP(n)                                                     \
+    const size_t pairs = (n) >> 1;                                                  \
+    const size_t stride = (size_t)gridDim.x * kBlock;                               \
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < pairs; i += stride)
+
+__global__ __launch_bounds__(kBlock) void fill_kernel(double* __restrict__ d, size_t n, double value) {
+    SPMV_AMD_STREAM_LOOP(n) {
+        d2 v = {value, value};
+        reinterpret_cast<d2*>(d)[i] = v;
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) d[n - 1] = value;
+}
+
+__global__ __launch_bounds__(kBlock) void axpy_kernel(size_t n, double a, const double* __restrict__ x,
+                                                      double* __restrict__ y) {
+    SPMV_AMD_STREAM_LOOP(n) {
+        const d2 xv = reinterpret_cast<const d2*>(x)[i];
+        d2 yv = reinterpret_cast<d2*>(y)[i];
+        yv.x = fma(a, xv.x, yv.x);
+        yv.y = fma(a, xv.y, yv.y);
+        reinterpret_cast<d2*>(y)[i] = yv;
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) y[n - 1] = fma(a, x[n - 1], y[n - 1]);
+}
+
+__global__ __launch_bounds__(kBlock) void axpby_kernel(size_t n, double a, const double* __restrict__ x,
+                                                       double b, const double* y, double* z) {
+    SPMV_AMD_STREAM_LOOP(n) {
+        const d2 xv = reinterpret_cast<const d2*>(x)[i];
+        const d2 yv = reinterpret_cast<const d2*>(y)[i];
+        d2 zv;
+        zv.x = fma(a, xv.x, b * yv.x);
+        zv.y = fma(a, xv.y, b * yv.y);
+        reinterpret_cast<d2*>(z)[i] = zv;
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) z[n - 1] = fma(a, x[n - 1], b * y[n - 1]);
+}
+
+template <bool kSubtract>
+__global__ __launch_bounds__(kBlock) void axpy_dev_kernel(size_t n, const double* __restrict__ d_a,
+                                                          const double* __restrict__ x,
+                                                          double* __restrict__ y) {
+    const double a = kSubtract ? -(*d_a) : *d_a;
+    SPMV_AMD_STREAM_LOOP(n) {
+        const d2 xv = reinterpret_cast<const d2*>(x)[i];
+        d2 yv = reinterpret_cast<d2*>(y)[i];
+        yv.x = fma(a, xv.x, yv.x);
+        yv.y = fma(a, xv.y, yv.y);
+        reinterpret_cast<d2*>(y)[i] = yv;
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) y[n - 1] = fma(a, x[n - 1], y[n - 1]);
+}
+
+__global__ __launch_bounds__(kBlock) void update_p_dev_kernel(size_t n, const double* __restrict__ r,
+                                                              const double* __restrict__ d_b,
+                                                              double* __restrict__ p) {
+    const double b = *d_b;
+    SPMV_AMD_STREAM_LOOP(n) {
+        const d2 rv = reinterpret_cast<const d2*>(r)[i];
+        d2 pv = reinterpret_cast<d2*>(p)[i];
+        pv.x = fma(b, pv.x, rv.x);
+        pv.y = fma(b, pv.y, rv.y);
+        reinterpret_cast<d2*>(p)[i] = pv;
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) p[n - 1] = fma(b, p[n - 1], r[n - 1]);
+}
+
+// One partial per wave: lanes accumulate their grid-stride elements in order, then a tree.
+__global__ __launch_bounds__(kBlock) void dot_partials_kernel(size_t n, const double* __restrict__ x,
+                                                              const double* __restrict__ y,
+                                                              double* __restrict__ partials) {
+    double acc = 0.0;
+    SPMV_AMD_STREAM_LOOP(n) {
+        const d2 xv = reinterpret_cast<const d2*>(x)[i];
+        const d2 yv = reinterpret_cast<const d2*>(y)[i];
+        acc = fma(xv.x, yv.x, acc);
+        acc = fma(xv.y, yv.y, acc);
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) acc = fma(x[n - 1], y[n - 1], acc);
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) partials[blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)] = acc;
+}
+
+// Single block: thread t sums partials t, t+256, ... then a 256-wide tree in LDS.
+__global__ __launch_bounds__(kBlock) void reduce_partials_kernel(const double* __restrict__ partials,
+                                                                 int count, double* __restrict__ out,
+                                                                 const int* __restrict__ skip_flag) {
+    __shared__ double s[kBlock];
+    if (skip_flag != nullptr && *skip_flag != 0) return;
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < count; i += kBlock) acc += partials[i];
+    s[threadIdx.x] = acc;
+    __syncthreads();
+    for (int stride = kBlock / 2; stride > 0; stride >>= 1) {
+        if ((int)threadIdx.x < stride) s[threadIdx.x] += s[threadIdx.x + stride];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out = s[0];
+}
+
+__global__ void scalar_divide_kernel(const double* num, const double* den, double* out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) *out = (*num) / (*den);
+}
+
+__global__ void check_convergence_kernel(const double* rr_new, double b_norm, double tol,
+                                         int* converged, double* residual) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        *residual = sqrt(*rr_new);
+        const double rel = (*residual) / b_norm;
+        *converged = (rel < tol) ? 1 : 0;
+    }
+}
+
+// ---- fused steps of the slab solver ----
+
+__global__ __launch_bounds__(kBlock) void cg_init_residual_kernel(size_t n, const double* __restrict__ b,
+                                                                  const double* __restrict__ Ap,
+                                                                  double* __restrict__ r,
+                                                                  double* __restrict__ p,
+                                                                  double* __restrict__ partials) {
+    double acc = 0.0;
+    SPMV_AMD_STREAM_LOOP(n) {
+        const d2 bv = reinterpret_cast<const d2*>(b)[i];
+        const d2 av = reinterpret_cast<const d2*>(Ap)[i];
+        d2 rv;
+        rv.x = fma(-1.0, av.x, bv.x);  // axpy_kernel(-1.0, Ap, b) then r = b (mgpu :475-476)
+        rv.y = fma(-1.0, av.y, bv.y);
+        reinterpret_cast<d2*>(r)[i] = rv;
+        reinterpret_cast<d2*>(p)[i] = rv;
+        acc = fma(rv.x, rv.x, acc);
+        acc = fma(rv.y, rv.y, acc);
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        const double rv = fma(-1.0, Ap[n - 1], b[n - 1]);
+        r[n - 1] = rv;
+        p[n - 1] = rv;
+        acc = fma(rv, rv, acc);
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) partials[blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)] = acc;
+}
+
+__global__ __launch_bounds__(kBlock) void cg_update_xr_kernel(size_t n, const CgScalars* __restrict__ s,
+                                                              const double* __restrict__ p,
+                                                              const double* __restrict__ Ap,
+                                                              double* __restrict__ x,
+                                                              double* __restrict__ r,
+                                                              double* __restrict__ partials) {
+    if (s->converged) return;
+    const double alpha = s->alpha;
+    double acc = 0.0;
+    SPMV_AMD_STREAM_LOOP(n) {
+        const d2 pv = reinterpret_cast<const d2*>(p)[i];
+        const d2 av = reinterpret_cast<const d2*>(Ap)[i];
+        d2 xv = reinterpret_cast<d2*>(x)[i];
+        d2 rv = reinterpret_cast<d2*>(r)[i];
+        xv.x = fma(alpha, pv.x, xv.x);
+        xv.y = fma(alpha, pv.y, xv.y);
+        rv.x = fma(-alpha, av.x, rv.x);
+        rv.y = fma(-alpha, av.y, rv.y);
+        reinterpret_cast<d2*>(x)[i] = xv;
+        reinterpret_cast<d2*>(r)[i] = rv;
+        acc = fma(rv.x, rv.x, acc);
+        acc = fma(rv.y, rv.y, acc);
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        x[n - 1] = fma(alpha, p[n - 1], x[n - 1]);
+        const double rv = fma(-alpha, Ap[n - 1], r[n - 1]);
+        r[n - 1] = rv;
+        acc = fma(rv, rv, acc);
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) partials[blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)] = acc;
+}
+
+__global__ __launch_bounds__(kBlock) void cg_update_p_kernel(size_t n, const CgScalars* __restrict__ s,
+                                                             const double* __restrict__ r,
+                                                             double* __restrict__ p) {
+    if (s->converged) return;
+    const double beta = s->beta;
+    SPMV_AMD_STREAM_LOOP(n) {
+        const d2 rv = reinterpret_cast<const d2*>(r)[i];
+        d2 pv = reinterpret_cast<d2*>(p)[i];
+        pv.x = fma(1.0, rv.x, beta * pv.x);
+        pv.y = fma(1.0, rv.y, beta * pv.y);
+        reinterpret_cast<d2*>(p)[i] = pv;
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) p[n - 1] = fma(1.0, r[n - 1], beta * p[n - 1]);
+}
+
+// rr_new holds the (all-reduced) initial r.r: b_norm = sqrt, history[0], rr_old.
+__global__ void cg_scalars_init_kernel(CgScalars* s, double* history) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    s->rr_old = s->rr_new;
+    s->b_norm = sqrt(s->rr_new);
+    s->residual = s->b_norm;
+    s->converged = 0;
+    s->iterations = 0;
+    if (history != nullptr && s->max_history > 0) history[0] = s->b_norm;
+}
+
+// pAp holds the (all-reduced) p.Ap: alpha = rr_old / pAp (host division in the reference,
+// cg_solver_mgpu_partitioned.cu:589; scalar_divide_kernel in cg_solver.cu:564).
+__global__ void cg_scalars_alpha_kernel(CgScalars* s) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (s->converged) return;
+    s->alpha = s->rr_old / s->pAp;
+}
+
+// rr_new holds the (all-reduced) new r.r: stopping test (strict <, on ||r||/||r0||), iteration
+// count including the converging iteration, beta, rr_old <- rr_new (mgpu :652-676,716).
+__global__ void cg_scalars_step_kernel(CgScalars* s, double tol, double* history) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (s->converged) return;
+    const double res = sqrt(s->rr_new);
+    s->residual = res;
+    s->iterations += 1;
+    if (history != nullptr && s->iterations < s->max_history) history[s->iterations] = res;
+    if (res / s->b_norm < tol) {
+        s->converged = 1;
+        return;
+    }
+    s->beta = s->rr_new / s->rr_old;
+    s->rr_old = s->rr_new;
+}
+
+inline unsigned stream_grid(size_t n) {
+    const size_t want = ((n >> 1) + kBlock - 1) / kBlock;
+    return (unsigned)(want < 1 ? 1 : (want > (size_t)kStreamBlocks ? (size_t)kStreamBlocks : want));
+}
+
+}  // namespace
+
+void launch_fill(double* d, size_t n, double value, hipStream_t stream) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(fill_kernel, dim3(stream_grid(n)), dim3(kBlock), 0, stream, d, n, value);
+}
+
+void launch_axpy(size_t n, double a, const double* x, double* y, hipStream_t stream) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(axpy_kernel, dim3(stream_grid(n)), dim3(kBlock), 0, stream, n, a, x, y);
+}
+
+void launch_axpby(size_t n, double a, const double* x, double b, const double* y, double* z,
+                  hipStream_t stream) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(axpby_kernel, dim3(stream_grid(n)), dim3(kBlock), 0, stream, n, a, x, b, y, z);
+}
+
+void launch_axpy_dev(size_t n, const double* d_a, const double* x, double* y, bool subtract,
+                     hipStream_t stream) {
+    if (n == 0) return;
+    if (subtract)
+        hipLaunchKernelGGL(axpy_dev_kernel<true>, dim3(stream_grid(n)), dim3(kBlock), 0, stream, n, d_a, x, y);
+    else
+        hipLaunchKernelGGL(axpy_dev_kernel<false>, dim3(stream_grid(n)), dim3(kBlock), 0, stream, n, d_a, x, y);
+}
+
+void launch_update_p_dev(size_t n, const double* r, const double* d_b, double* p, hipStream_t stream) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(update_p_dev_kernel, dim3(stream_grid(n)), dim3(kBlock), 0, stream, n, r, d_b, p);
+}
+
+size_t dot_scratch_doubles() { return kPartials; }
+int cg_partial_count() { return kPartials; }
+
+void launch_dot(size_t n, const double* x, const double* y, double* scratch, double* d_result,
+                hipStream_t stream) {
+    // Always the full fixed grid, so that every partial slot is rewritten on every call.
+    hipLaunchKernelGGL(dot_partials_kernel, dim3(kStreamBlocks), dim3(kBlock), 0, stream, n, x, y, scratch);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(kBlock), 0, stream, scratch, kPartials,
+                       d_result, (const int*)nullptr);
+}
+
+void launch_scalar_divide(const double* d_num, const double* d_den, double* d_out, hipStream_t stream) {
+    hipLaunchKernelGGL(scalar_divide_kernel, dim3(1), dim3(1), 0, stream, d_num, d_den, d_out);
+}
+
+void launch_check_convergence(const double* d_rr_new, double b_norm, double tol, int* d_converged,
+                              double* d_residual, hipStream_t stream) {
+    hipLaunchKernelGGL(check_convergence_kernel, dim3(1), dim3(1), 0, stream, d_rr_new, b_norm, tol,
+                       d_converged, d_residual);
+}
+
+void launch_cg_init_residual(size_t n, const double* b, const double* Ap, double* r, double* p,
+                             double* partials, hipStream_t stream) {
+    hipLaunchKernelGGL(cg_init_residual_kernel, dim3(kStreamBlocks), dim3(kBlock), 0, stream, n, b, Ap,
+                       r, p, partials);
+}
+
+void launch_cg_update_xr(size_t n, const CgScalars* s, const double* p, const double* Ap, double* x,
+                         double* r, double* partials, hipStream_t stream) {
+    hipLaunchKernelGGL(cg_update_xr_kernel, dim3(kStreamBlocks), dim3(kBlock), 0, stream, n, s, p, Ap,
+                       x, r, partials);
+}
+
+void launch_cg_update_p(size_t n, const CgScalars* s, const double* r, double* p, hipStream_t stream) {
+    hipLaunchKernelGGL(cg_update_p_kernel, dim3(kStreamBlocks), dim3(kBlock), 0, stream, n, s, r, p);
+}
+
+void launch_reduce_partials(const double* partials, int count, double* d_out, const int* d_skip_flag,
+                            hipStream_t stream) {
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(kBlock), 0, stream, partials, count, d_out,
+                       d_skip_flag);
+}
+
+void launch_cg_scalars_init(CgScalars* s, double* history, hipStream_t stream) {
+    hipLaunchKernelGGL(cg_scalars_init_kernel, dim3(1), dim3(1), 0, stream, s, history);
+}
+
+void launch_cg_scalars_alpha(CgScalars* s, hipStream_t stream) {
+    hipLaunchKernelGGL(cg_scalars_alpha_kernel, dim3(1), dim3(1), 0, stream, s);
+}
+
+void launch_cg_scalars_step(CgScalars* s, double tol, double* history, hipStream_t stream) {
+    hipLaunchKernelGGL(cg_scalars_step_kernel, dim3(1), dim3(1), 0, stream, s, tol, history);
+}
+
+}  // namespace spmv_amd

@@ -1,0 +1,278 @@
+// cg_single.hip -- single-GPU Conjugate Gradient over any SpmvOperator.
+//
+//   cg_solve        <- reference src/solvers/cg_solver.cu:154-378  (host scalars; SpMV through
+//                      run_timed with the direction vector travelling host<->device each iteration)
+//   cg_solve_device <- reference src/solvers/cg_solver.cu:436-706  (device scalars; SpMV through
+//                      run_device; one 4-byte flag read-back per iteration)
+//
+// Same algebra, stopping rule (||r_k|| / ||r_0|| < tol, strict, the converging iteration is
+// counted), statistics and verbose output as the reference. Differences: the BLAS1 kernels move
+// 16 bytes per lane, and dot products use a fixed two-stage shape (cg_kernels.hip) instead of
+// 256-wide blocks + host/strided final sum, which changes results at the 1e-15 level only.
+#include <math.h>
+
+#include <vector>
+
+#include "device_runtime.hpp"
+
+using namespace spmv_amd;
+
+namespace spmv_amd {
+std::vector<double>& last_cg_history() {
+    static std::vector<double> h;
+    return h;
+}
+}  // namespace spmv_amd
+
+namespace {
+
+constexpr hipStream_t kStream = nullptr;  // default stream, shared with the operators
+
+struct Vectors {
+    double *x = nullptr, *b = nullptr, *r = nullptr, *p = nullptr, *Ap = nullptr;
+    double* scratch = nullptr;
+    void alloc(size_t n) {
+        x = device_alloc<double>(n);
+        b = device_alloc<double>(n);
+        r = device_alloc<double>(n);
+        p = device_alloc<double>(n);
+        Ap = device_alloc<double>(n);
+        scratch = device_alloc<double>(dot_scratch_doubles());
+    }
+    void release() {
+        device_release(x);
+        device_release(b);
+        device_release(r);
+        device_release(p);
+        device_release(Ap);
+        device_release(scratch);
+    }
+};
+
+void fill_solution_checksums(const double* x, int n, double* sum, double* norm) {
+    double s = 0.0, q = 0.0;
+    for (int i = 0; i < n; i++) {
+        s += x[i];
+        q += x[i] * x[i];
+    }
+    *sum = s;
+    *norm = sqrt(q);
+}
+
+void print_breakdown(const char* tag, const CGStats* st) {
+    printf("[%s] Converged: %s\n", tag, st->converged ? "YES" : "NO");
+    printf("[%s] Iterations: %d\n", tag, st->iterations);
+    printf("[%s] Final residual: %e\n", tag, st->residual_norm);
+    printf("[%s] Time breakdown:\n", tag);
+    printf("     Total:      %.3f ms\n", st->time_total_ms);
+    printf("     SpMV:       %.3f ms (%.1f%%)\n", st->time_spmv_ms, 100.0 * st->time_spmv_ms / st->time_total_ms);
+    printf("     BLAS1:      %.3f ms (%.1f%%)\n", st->time_blas1_ms, 100.0 * st->time_blas1_ms / st->time_total_ms);
+    printf("     Reductions: %.3f ms (%.1f%%)\n", st->time_reductions_ms,
+           100.0 * st->time_reductions_ms / st->time_total_ms);
+}
+
+}  // namespace
+
+int cg_solve(SpmvOperator* spmv_op, MatrixData* mat, const double* b, double* x, CGConfig config,
+             CGStats* stats) {
+    const int n = mat->rows;
+    Vectors v;
+    v.alloc((size_t)n);
+    double* d_scalar = device_alloc<double>(1);
+    upload(v.x, x, (size_t)n);
+    upload(v.b, b, (size_t)n);
+    std::vector<double> h_in((size_t)n), h_out((size_t)n);
+    std::vector<double>& hist = last_cg_history();
+    hist.clear();
+
+    EventTimer total, part;
+    double t_spmv = 0.0, t_blas = 0.0, t_red = 0.0;
+    auto host_dot = [&](const double* a, const double* c) {
+        part.begin(kStream);
+        launch_dot((size_t)n, a, c, v.scratch, d_scalar, kStream);
+        double h = 0.0;
+        download(&h, d_scalar, 1);
+        part.end(kStream);
+        t_red += part.elapsed_ms();
+        return h;
+    };
+    auto host_spmv = [&](const double* d_in, double* d_out) {
+        double kernel_ms = 0.0;
+        part.begin(kStream);
+        download(h_in.data(), d_in, (size_t)n);
+        spmv_op->run_timed(h_in.data(), h_out.data(), &kernel_ms);
+        upload(d_out, h_out.data(), (size_t)n);
+        part.end(kStream);
+        t_spmv += part.elapsed_ms();
+    };
+    auto timed_blas = [&](auto&& launch) {
+        part.begin(kStream);
+        launch();
+        part.end(kStream);
+        t_blas += part.elapsed_ms();
+    };
+
+    total.begin(kStream);
+    host_spmv(v.x, v.Ap);
+    timed_blas([&] { launch_axpby((size_t)n, 1.0, v.b, -1.0, v.Ap, v.r, kStream); });
+    HIP_CHECK(hipMemcpyAsync(v.p, v.r, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, kStream));
+    double rr_old = host_dot(v.r, v.r);
+    const double b_norm = sqrt(rr_old);
+    hist.push_back(b_norm);
+    if (config.verbose >= 1) printf("[CG] Initial residual: %e\n", b_norm);
+
+    int iter;
+    double residual_norm = b_norm;
+    for (iter = 0; iter < config.max_iters; iter++) {
+        host_spmv(v.p, v.Ap);
+        const double pAp = host_dot(v.Ap, v.p);
+        const double alpha = rr_old / pAp;
+        timed_blas([&] { launch_axpy((size_t)n, alpha, v.p, v.x, kStream); });
+        timed_blas([&] { launch_axpy((size_t)n, -alpha, v.Ap, v.r, kStream); });
+        const double rr_new = host_dot(v.r, v.r);
+        residual_norm = sqrt(rr_new);
+        hist.push_back(residual_norm);
+        const double rel = residual_norm / b_norm;
+        if (config.verbose >= 2)
+            printf("[CG] Iter %3d: residual = %e (rel = %e)\n", iter + 1, residual_norm, rel);
+        if (rel < config.tolerance) {
+            iter++;
+            break;
+        }
+        const double beta = rr_new / rr_old;
+        timed_blas([&] { launch_axpby((size_t)n, 1.0, v.r, beta, v.p, v.p, kStream); });
+        rr_old = rr_new;
+    }
+    total.end(kStream);
+    const float total_ms = total.elapsed_ms();
+    download(x, v.x, (size_t)n);
+
+    stats->iterations = iter;
+    stats->residual_norm = residual_norm;
+    stats->time_total_ms = total_ms;
+    stats->time_spmv_ms = t_spmv;
+    stats->time_blas1_ms = t_blas;
+    stats->time_reductions_ms = t_red;
+    stats->converged = (residual_norm / b_norm < config.tolerance) ? 1 : 0;
+    fill_solution_checksums(x, n, &stats->solution_sum, &stats->solution_norm);
+    if (config.verbose >= 1) print_breakdown("CG", stats);
+
+    v.release();
+    device_release(d_scalar);
+    return 0;
+}
+
+int cg_solve_device(SpmvOperator* spmv_op, MatrixData* mat, const double* b, double* x,
+                    CGConfig config, CGStats* stats) {
+    if (!spmv_op->run_device) {
+        fprintf(stderr, "[ERROR] Operator '%s' does not support device-native interface\n",
+                spmv_op->name);
+        return 1;
+    }
+    const int n = mat->rows;
+    Vectors v;
+    v.alloc((size_t)n);
+    // device scalars: rr_old, rr_new, pAp, alpha, beta, residual | converged flag | history
+    double* d_s = device_alloc<double>(6);
+    double *d_rr_old = d_s, *d_rr_new = d_s + 1, *d_pAp = d_s + 2, *d_alpha = d_s + 3,
+           *d_beta = d_s + 4, *d_residual = d_s + 5;
+    int* d_converged = device_alloc<int>(1);
+    const int hist_cap = config.max_iters + 1;
+    double* d_hist = device_alloc<double>((size_t)hist_cap);
+    upload(v.x, x, (size_t)n);
+    upload(v.b, b, (size_t)n);
+
+    EventTimer total, part;
+    double t_spmv = 0.0, t_blas = 0.0, t_red = 0.0;
+    const bool detail = config.enable_detailed_timers != 0;
+    auto region = [&](double& bucket, bool always, auto&& launch) {
+        part.begin(kStream);
+        launch();
+        part.end(kStream);
+        if (always || detail) bucket += part.elapsed_ms();
+    };
+
+    total.begin(kStream);
+    region(t_spmv, true, [&] { spmv_op->run_device(v.x, v.Ap); });
+    region(t_blas, true, [&] { launch_axpby((size_t)n, 1.0, v.b, -1.0, v.Ap, v.r, kStream); });
+    HIP_CHECK(hipMemcpyAsync(v.p, v.r, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, kStream));
+    region(t_red, false, [&] { launch_dot((size_t)n, v.r, v.r, v.scratch, d_rr_old, kStream); });
+
+    double h_rr_old = 0.0;
+    download(&h_rr_old, d_rr_old, 1);
+    const double b_norm = sqrt(h_rr_old);
+    upload(d_hist, &b_norm, 1);
+    if (config.verbose >= 1) printf("[CG-DEVICE] Initial residual: %e\n", b_norm);
+
+    int iter;
+    double final_residual_norm = b_norm;
+    for (iter = 0; iter < config.max_iters; iter++) {
+        region(t_spmv, false, [&] { spmv_op->run_device(v.p, v.Ap); });
+        region(t_red, false, [&] { launch_dot((size_t)n, v.Ap, v.p, v.scratch, d_pAp, kStream); });
+        launch_scalar_divide(d_rr_old, d_pAp, d_alpha, kStream);
+        region(t_blas, false, [&] { launch_axpy_dev((size_t)n, d_alpha, v.p, v.x, false, kStream); });
+        region(t_blas, false, [&] { launch_axpy_dev((size_t)n, d_alpha, v.Ap, v.r, true, kStream); });
+        region(t_red, false, [&] { launch_dot((size_t)n, v.r, v.r, v.scratch, d_rr_new, kStream); });
+        launch_check_convergence(d_rr_new, b_norm, config.tolerance, d_converged, d_residual, kStream);
+        HIP_CHECK(hipMemcpyAsync(d_hist + iter + 1, d_residual, sizeof(double),
+                                 hipMemcpyDeviceToDevice, kStream));
+
+        int h_converged = 0;
+        download(&h_converged, d_converged, 1);
+        if (config.verbose >= 2) {
+            double h_res = 0.0;
+            download(&h_res, d_residual, 1);
+            printf("[CG-DEVICE] Iter %3d: residual = %e (rel = %e)\n", iter + 1, h_res, h_res / b_norm);
+            final_residual_norm = h_res;
+        }
+        if (h_converged) {
+            if (config.verbose < 2) download(&final_residual_norm, d_residual, 1);
+            iter++;
+            break;
+        }
+        launch_scalar_divide(d_rr_new, d_rr_old, d_beta, kStream);
+        region(t_blas, false, [&] { launch_update_p_dev((size_t)n, v.r, d_beta, v.p, kStream); });
+        HIP_CHECK(hipMemcpyAsync(d_rr_old, d_rr_new, sizeof(double), hipMemcpyDeviceToDevice, kStream));
+    }
+    total.end(kStream);
+    const float total_ms = total.elapsed_ms();
+    HIP_CHECK(hipGetLastError());
+    download(x, v.x, (size_t)n);
+
+    std::vector<double>& hist = last_cg_history();
+    hist.assign((size_t)iter + 1, 0.0);
+    download(hist.data(), d_hist, hist.size());
+
+    stats->iterations = iter;
+    stats->residual_norm = final_residual_norm;
+    stats->time_total_ms = total_ms;
+    stats->time_spmv_ms = t_spmv;
+    stats->time_blas1_ms = t_blas;
+    stats->time_reductions_ms = t_red;
+    stats->converged = (final_residual_norm / b_norm < config.tolerance) ? 1 : 0;
+    fill_solution_checksums(x, n, &stats->solution_sum, &stats->solution_norm);
+    if (config.verbose >= 1) print_breakdown("CG-DEVICE", stats);
+
+    v.release();
+    device_release(d_s);
+    device_release(d_converged);
+    device_release(d_hist);
+    return 0;
+}
+
+extern "C" int spmv_amd_cg_solve(SpmvOperator* op, MatrixData* mat, const double* b, double* x,
+                                 const CGConfig* config, CGStats* stats) {
+    return cg_solve(op, mat, b, x, *config, stats);
+}
+
+extern "C" int spmv_amd_cg_solve_device(SpmvOperator* op, MatrixData* mat, const double* b,
+                                        double* x, const CGConfig* config, CGStats* stats) {
+    return cg_solve_device(op, mat, b, x, *config, stats);
+}
+
+extern "C" int spmv_amd_cg_last_history(double* out, int cap) {
+    const std::vector<double>& h = last_cg_history();
+    const int count = (int)h.size();
+    for (int i = 0; i < count && i < cap; ++i) out[i] = h[i];
+    return count;
+}

@@ -1,0 +1,228 @@
+// comm.hip -- see comm.hpp.
+#include "comm.hpp"
+
+#include <rccl/rccl.h>
+#include <string.h>
+
+#include <vector>
+
+#include "device_runtime.hpp"
+
+#define RCCL_CHECK(call)                                                                         \
+    do {                                                                                         \
+        ncclResult_t spmv_amd_rc_ = (call);                                                      \
+        if (spmv_amd_rc_ != ncclSuccess) {                                                       \
+            fprintf(stderr, "RCCL error: %s, %s line %d\n", ncclGetErrorString(spmv_amd_rc_),    \
+                    __FILE__, __LINE__);                                                         \
+            exit(EXIT_FAILURE);                                                                  \
+        }                                                                                        \
+    } while (0)
+
+namespace {
+
+using spmv_amd::device_alloc;
+using spmv_amd::device_release;
+
+struct SelfComm final : SpmvAmdComm {
+    void halo_exchange(const double*, const double*, double*, double*, int, hipStream_t) override {}
+    void allreduce_sum(double*, int, hipStream_t) override {}
+    void gather_to_root(const double* d_local, int n_local, double* h_full, const int*,
+                        const int* displs) override {
+        HIP_CHECK(hipMemcpy(h_full + (displs ? displs[0] : 0), d_local,
+                            (size_t)n_local * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    void barrier() override {}
+    const char* transport() const override { return "self"; }
+};
+
+struct RcclComm final : SpmvAmdComm {
+    ncclComm_t p2p = nullptr;   // halo rows
+    ncclComm_t coll = nullptr;  // all-reduce, gather
+    ~RcclComm() override {
+        if (p2p) ncclCommDestroy(p2p);
+        if (coll) ncclCommDestroy(coll);
+    }
+    void halo_exchange(const double* d_send_prev, const double* d_send_next, double* d_recv_prev,
+                       double* d_recv_next, int count, hipStream_t stream) override {
+        if (world == 1) return;
+        RCCL_CHECK(ncclGroupStart());
+        if (rank > 0) {
+            RCCL_CHECK(ncclSend(d_send_prev, (size_t)count, ncclDouble, rank - 1, p2p, stream));
+            RCCL_CHECK(ncclRecv(d_recv_prev, (size_t)count, ncclDouble, rank - 1, p2p, stream));
+        }
+        if (rank < world - 1) {
+            RCCL_CHECK(ncclSend(d_send_next, (size_t)count, ncclDouble, rank + 1, p2p, stream));
+            RCCL_CHECK(ncclRecv(d_recv_next, (size_t)count, ncclDouble, rank + 1, p2p, stream));
+        }
+        RCCL_CHECK(ncclGroupEnd());
+    }
+    void allreduce_sum(double* d_buf, int count, hipStream_t stream) override {
+        if (world == 1) return;
+        RCCL_CHECK(ncclAllReduce(d_buf, d_buf, (size_t)count, ncclDouble, ncclSum, coll, stream));
+    }
+    void gather_to_root(const double* d_local, int n_local, double* h_full, const int* counts,
+                        const int* displs) override {
+        hipStream_t s = nullptr;
+        if (rank == 0) {
+            HIP_CHECK(hipMemcpy(h_full + displs[0], d_local, (size_t)n_local * sizeof(double),
+                                hipMemcpyDeviceToHost));
+            int widest = 0;
+            for (int r = 1; r < world; ++r) widest = counts[r] > widest ? counts[r] : widest;
+            double* d_tmp = device_alloc<double>((size_t)widest);
+            for (int r = 1; r < world; ++r) {
+                RCCL_CHECK(ncclRecv(d_tmp, (size_t)counts[r], ncclDouble, r, coll, s));
+                HIP_CHECK(hipStreamSynchronize(s));
+                HIP_CHECK(hipMemcpy(h_full + displs[r], d_tmp, (size_t)counts[r] * sizeof(double),
+                                    hipMemcpyDeviceToHost));
+            }
+            device_release(d_tmp);
+        } else {
+            RCCL_CHECK(ncclSend(d_local, (size_t)n_local, ncclDouble, 0, coll, s));
+            HIP_CHECK(hipStreamSynchronize(s));
+        }
+    }
+    void barrier() override {
+        if (world == 1) return;
+        double* d = device_alloc<double>(1);
+        HIP_CHECK(hipMemset(d, 0, sizeof(double)));
+        RCCL_CHECK(ncclAllReduce(d, d, 1, ncclDouble, ncclSum, coll, nullptr));
+        HIP_CHECK(hipStreamSynchronize(nullptr));
+        device_release(d);
+    }
+    const char* transport() const override { return "rccl"; }
+};
+
+struct StagedComm final : SpmvAmdComm {
+    SpmvAmdHostHaloFn halo_fn = nullptr;
+    SpmvAmdHostAllreduceFn allreduce_fn = nullptr;
+    SpmvAmdHostGatherFn gather_fn = nullptr;
+    SpmvAmdHostBarrierFn barrier_fn = nullptr;
+    void* user = nullptr;
+    double* pinned = nullptr;  // [send_prev | send_next | recv_prev | recv_next]
+    size_t pinned_count = 0;
+
+    ~StagedComm() override {
+        if (pinned) (void)hipHostFree(pinned);
+    }
+    void reserve(size_t count) {
+        if (count <= pinned_count) return;
+        if (pinned) HIP_CHECK(hipHostFree(pinned));
+        HIP_CHECK(hipHostMalloc((void**)&pinned, 4 * count * sizeof(double), hipHostMallocDefault));
+        pinned_count = count;
+    }
+    void halo_exchange(const double* d_send_prev, const double* d_send_next, double* d_recv_prev,
+                       double* d_recv_next, int count, hipStream_t stream) override {
+        if (world == 1) return;
+        reserve((size_t)count);
+        const size_t bytes = (size_t)count * sizeof(double);
+        double* sp = pinned;
+        double* sn = pinned + pinned_count;
+        double* rp = pinned + 2 * pinned_count;
+        double* rn = pinned + 3 * pinned_count;
+        const bool prev = rank > 0, next = rank < world - 1;
+        if (prev) HIP_CHECK(hipMemcpyAsync(sp, d_send_prev, bytes, hipMemcpyDeviceToHost, stream));
+        if (next) HIP_CHECK(hipMemcpyAsync(sn, d_send_next, bytes, hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+        if (halo_fn(user, prev ? sp : nullptr, next ? sn : nullptr, prev ? rp : nullptr,
+                    next ? rn : nullptr, count) != 0) {
+            fprintf(stderr, "[comm/staged] halo callback failed\n");
+            exit(EXIT_FAILURE);
+        }
+        if (prev) HIP_CHECK(hipMemcpyAsync(d_recv_prev, rp, bytes, hipMemcpyHostToDevice, stream));
+        if (next) HIP_CHECK(hipMemcpyAsync(d_recv_next, rn, bytes, hipMemcpyHostToDevice, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+    }
+    void allreduce_sum(double* d_buf, int count, hipStream_t stream) override {
+        if (world == 1) return;
+        std::vector<double> h((size_t)count);
+        HIP_CHECK(hipMemcpyAsync(h.data(), d_buf, h.size() * sizeof(double), hipMemcpyDeviceToHost,
+                                 stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+        if (allreduce_fn(user, h.data(), count) != 0) {
+            fprintf(stderr, "[comm/staged] allreduce callback failed\n");
+            exit(EXIT_FAILURE);
+        }
+        HIP_CHECK(hipMemcpyAsync(d_buf, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice,
+                                 stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+    }
+    void gather_to_root(const double* d_local, int n_local, double* h_full, const int* counts,
+                        const int* displs) override {
+        std::vector<double> mine((size_t)n_local);
+        HIP_CHECK(hipMemcpy(mine.data(), d_local, mine.size() * sizeof(double), hipMemcpyDeviceToHost));
+        if (world == 1 || gather_fn == nullptr) {
+            memcpy(h_full + displs[rank], mine.data(), mine.size() * sizeof(double));
+            return;
+        }
+        if (gather_fn(user, mine.data(), n_local, h_full, counts, displs) != 0) {
+            fprintf(stderr, "[comm/staged] gather callback failed\n");
+            exit(EXIT_FAILURE);
+        }
+    }
+    void barrier() override {
+        if (world > 1 && barrier_fn) barrier_fn(user);
+    }
+    const char* transport() const override { return "staged"; }
+};
+
+SelfComm g_self;
+SpmvAmdComm* g_world = nullptr;
+
+}  // namespace
+
+namespace spmv_amd {
+SpmvAmdComm* self_comm() { return &g_self; }
+SpmvAmdComm* world_comm() { return g_world ? g_world : &g_self; }
+}  // namespace spmv_amd
+
+// The id handed around is two RCCL unique ids back to back (p2p + collective communicator).
+static_assert(2 * NCCL_UNIQUE_ID_BYTES == 256, "unique id blob is 256 bytes");
+
+extern "C" int spmv_amd_comm_unique_id(void* out_id256) {
+    ncclUniqueId a, b;
+    RCCL_CHECK(ncclGetUniqueId(&a));
+    RCCL_CHECK(ncclGetUniqueId(&b));
+    memcpy(out_id256, &a, NCCL_UNIQUE_ID_BYTES);
+    memcpy((char*)out_id256 + NCCL_UNIQUE_ID_BYTES, &b, NCCL_UNIQUE_ID_BYTES);
+    return 0;
+}
+
+extern "C" SpmvAmdComm* spmv_amd_comm_create_rccl(int rank, int world, const void* id256) {
+    RcclComm* c = new RcclComm();
+    c->rank = rank;
+    c->world = world;
+    if (world > 1) {
+        ncclUniqueId a, b;
+        memcpy(&a, id256, NCCL_UNIQUE_ID_BYTES);
+        memcpy(&b, (const char*)id256 + NCCL_UNIQUE_ID_BYTES, NCCL_UNIQUE_ID_BYTES);
+        RCCL_CHECK(ncclCommInitRank(&c->p2p, world, a, rank));
+        RCCL_CHECK(ncclCommInitRank(&c->coll, world, b, rank));
+    }
+    return c;
+}
+
+extern "C" SpmvAmdComm* spmv_amd_comm_create_staged(int rank, int world, SpmvAmdHostHaloFn halo,
+                                                    SpmvAmdHostAllreduceFn allreduce,
+                                                    SpmvAmdHostGatherFn gather,
+                                                    SpmvAmdHostBarrierFn barrier, void* user) {
+    if (world > 1 && (halo == nullptr || allreduce == nullptr)) return nullptr;
+    StagedComm* c = new StagedComm();
+    c->rank = rank;
+    c->world = world;
+    c->halo_fn = halo;
+    c->allreduce_fn = allreduce;
+    c->gather_fn = gather;
+    c->barrier_fn = barrier;
+    c->user = user;
+    return c;
+}
+
+extern "C" void spmv_amd_comm_destroy(SpmvAmdComm* comm) {
+    if (comm == nullptr || comm == &g_self) return;
+    if (comm == g_world) g_world = nullptr;
+    delete comm;
+}
+
+extern "C" void spmv_amd_comm_set_world(SpmvAmdComm* comm) { g_world = comm; }
+extern "C" int spmv_amd_comm_rank(const SpmvAmdComm* comm) { return comm ? comm->rank : 0; }
+extern "C" int spmv_amd_comm_size(const SpmvAmdComm* comm) { return comm ? comm->world : 1; }

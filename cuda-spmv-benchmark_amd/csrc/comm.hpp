@@ -1,0 +1,42 @@
+// comm.hpp -- the communicator the multi-GPU CG runs over (the role MPI_COMM_WORLD plays in
+// reference src/solvers/cg_solver_mgpu_partitioned.cu). One process per GPU.
+//
+// Two transports behind one interface:
+//  * RcclComm   -- device-native: neighbour halo rows by ncclSend/ncclRecv (one group per
+//                  exchange, xGMI point-to-point links), dot products by ncclAllReduce on device
+//                  scalars. Two RCCL communicators are created so that the halo exchange (side
+//                  stream) and the all-reduce (compute stream) never queue behind one another.
+//  * StagedComm -- the reference's own scheme (D2H -> host exchange -> H2D,
+//                  cg_solver_mgpu_partitioned.cu:173-231) with the host exchange supplied by the
+//                  caller as callbacks (e.g. an MPI or a gloo binding). Used where RCCL cannot
+//                  run (several ranks sharing one GPU in tests).
+//  * no communicator / world == 1 -- SelfComm, every collective is the identity.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "spmv_amd.h"
+
+struct SpmvAmdComm {
+    int rank = 0;
+    int world = 1;
+    virtual ~SpmvAmdComm() {}
+    // Exchanges `count` doubles with rank-1 (send_prev/recv_prev) and rank+1 (send_next/recv_next);
+    // pointers are device pointers, NULL where there is no neighbour. Ordered on `stream`.
+    virtual void halo_exchange(const double* d_send_prev, const double* d_send_next,
+                               double* d_recv_prev, double* d_recv_next, int count,
+                               hipStream_t stream) = 0;
+    // In-place sum over all ranks of `count` device doubles, ordered on `stream`.
+    virtual void allreduce_sum(double* d_buf, int count, hipStream_t stream) = 0;
+    // Every rank contributes n_local device doubles; rank 0 receives them in h_full at displs[r].
+    virtual void gather_to_root(const double* d_local, int n_local, double* h_full,
+                                const int* counts, const int* displs) = 0;
+    virtual void barrier() = 0;
+    virtual const char* transport() const = 0;
+};
+
+namespace spmv_amd {
+// The communicator cg_solve_mgpu_partitioned uses; never NULL (SelfComm by default).
+SpmvAmdComm* world_comm();
+SpmvAmdComm* self_comm();
+}  // namespace spmv_amd

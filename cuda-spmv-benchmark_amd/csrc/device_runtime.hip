@@ -1,0 +1,104 @@
+// device_runtime.hip -- see device_runtime.hpp.
+#include "device_runtime.hpp"
+
+#include <vector>
+
+#include "stencil_geometry.hpp"
+
+namespace spmv_amd {
+
+LaunchShape current_launch_shape() {
+    static int cached_device = -1;
+    static LaunchShape cached;
+    int dev = 0;
+    HIP_CHECK(hipGetDevice(&dev));
+    if (dev != cached_device) {
+        hipDeviceProp_t prop;
+        HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+        cached.compute_units = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        // 5248 B of LDS per wave x 4 waves per block: seven blocks (28 waves) fit one CU's 160 KiB
+        cached.blocks_per_cu = 7;
+        cached_device = dev;
+    }
+    return cached;
+}
+
+void DeviceCsr::upload_slab(const CSRMatrix& host, int row_offset, int n_local, int grid_size) {
+    release();
+    const long long base = host.row_ptr[row_offset];
+    const long long local_nnz = (long long)host.row_ptr[row_offset + n_local] - base;
+    row_ptr = device_alloc<int>((size_t)n_local + 1);
+    col_idx = device_alloc<int>((size_t)local_nnz);
+    values = device_alloc<double>((size_t)local_nnz);
+    if (base == 0) {
+        upload(row_ptr, host.row_ptr, (size_t)n_local + 1);
+    } else {
+        std::vector<int> rebased((size_t)n_local + 1);
+        for (int i = 0; i <= n_local; ++i) rebased[i] = host.row_ptr[row_offset + i] - (int)base;
+        upload(row_ptr, rebased.data(), rebased.size());
+    }
+    upload(col_idx, host.col_indices + base, (size_t)local_nnz);
+    upload(values, host.values + base, (size_t)local_nnz);
+    view = SlabCsr{};
+    view.row_ptr = row_ptr;
+    view.col_idx = col_idx;
+    view.values = values;
+    view.n_local = n_local;
+    view.row_offset = row_offset;
+    view.nnz_local = local_nnz;
+    view.nnz_base = base;
+    view.n_global = host.nb_rows;
+    view.grid_size = grid_size;
+    view.verified_stencil = false;
+}
+
+void DeviceCsr::generate_stencil5(int n, int row_offset, int n_local, double center, double off,
+                                  hipStream_t stream) {
+    release();
+    const long long base = stencil_row_start_flat(row_offset, n);
+    const long long end = stencil_row_start_flat((long long)row_offset + n_local, n);
+    const long long local_nnz = end - base;
+    row_ptr = device_alloc<int>((size_t)n_local + 1);
+    col_idx = device_alloc<int>((size_t)local_nnz);
+    values = device_alloc<double>((size_t)local_nnz);
+    launch_generate_stencil5_csr(n, row_offset, n_local, base, center, off, row_ptr, col_idx, values,
+                                 stream);
+    view = SlabCsr{};
+    view.row_ptr = row_ptr;
+    view.col_idx = col_idx;
+    view.values = values;
+    view.n_local = n_local;
+    view.row_offset = row_offset;
+    view.nnz_local = local_nnz;
+    view.nnz_base = base;
+    view.n_global = n * n;
+    view.grid_size = n;
+    view.verified_stencil = false;
+}
+
+void DeviceCsr::verify_stencil(hipStream_t stream) {
+    view.verified_stencil = false;
+    const int n = view.grid_size;
+    if (n < 2 || (long long)n * n != view.n_global) return;
+    // the pattern's total must also match, or the analytic offsets would run past the arrays
+    if (stencil_row_start_flat((long long)view.row_offset + view.n_local, n) -
+            stencil_row_start_flat(view.row_offset, n) != view.nnz_local)
+        return;
+    int* d_flag = device_alloc<int>(1);
+    HIP_CHECK(hipMemsetAsync(d_flag, 0, sizeof(int), stream));
+    launch_verify_stencil5_csr(view, d_flag, stream);
+    int h_flag = 1;
+    HIP_CHECK(hipMemcpyAsync(&h_flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    device_release(d_flag);
+    view.verified_stencil = (h_flag == 0);
+}
+
+void DeviceCsr::release() {
+    device_release(row_ptr);
+    device_release(col_idx);
+    device_release(values);
+    view = SlabCsr{};
+}
+
+}  // namespace spmv_amd

@@ -1,0 +1,130 @@
+// kernels.hpp -- host-callable launchers of the HIP kernels (gfx950 only).
+// Every launcher enqueues on the given stream and returns; none synchronises.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+
+namespace spmv_amd {
+
+// A row slab of a CSR matrix resident in HBM. For a single-GPU operator the slab
+// is the whole matrix (row_offset = 0, nnz_base = 0, no halos).
+struct SlabCsr {
+    const int* row_ptr = nullptr;    // n_local + 1 entries, rebased so row_ptr[0] == 0
+    const int* col_idx = nullptr;    // GLOBAL column indices
+    const double* values = nullptr;
+    int n_local = 0;                 // rows in the slab
+    int row_offset = 0;              // global index of local row 0
+    long long nnz_local = 0;
+    long long nnz_base = 0;          // global CSR position of the slab's first entry
+    int n_global = 0;                // rows of the whole matrix
+    int grid_size = -1;              // n of the n x n stencil, <= 0 if not a stencil
+    bool verified_stencil = false;   // structure checked against the complete 5-point pattern
+    // x is addressed as x[col - row_offset]; indices in [-halo_before, n_local + halo_after)
+    // are readable, anything else contributes 0 (reference halo kernel semantics).
+    int halo_before = 0;
+    int halo_after = 0;
+};
+
+struct LaunchShape {
+    int compute_units = 256;
+    int blocks_per_cu = 7;
+};
+
+// ---- structure ----
+// Fills row_ptr/col_idx/values of the slab [row_offset, row_offset+n_local) of the
+// n x n 5-point stencil (centre/off values as given), rows sorted by column.
+void launch_generate_stencil5_csr(int n, int row_offset, int n_local, long long nnz_base,
+                                  double center, double off, int* row_ptr, int* col_idx,
+                                  double* values, hipStream_t stream);
+// Sets *d_mismatch (int, zeroed by the caller) to non-zero if any row of the slab deviates
+// from the complete 5-point pattern of an n x n grid.
+void launch_verify_stencil5_csr(const SlabCsr& m, int* d_mismatch, hipStream_t stream);
+
+// ---- STENCIL5 SpMV ----
+// y[r] = alpha * (A x)[r]. d_dot_partials, if non-null, receives one partial of
+// sum_r x[r]*y_unscaled[r] per launched wave (fixed shape: waves = launch_stencil5_waves()).
+enum class Stencil5Variant { Auto, WaveTile, RowGeneric };
+int launch_stencil5_waves(const LaunchShape& shape);
+// first_row/last_row restrict the launch to local rows [first_row, last_row) (multiples of
+// 128 or the slab end); used to split interior rows from halo-dependent rows.
+void launch_stencil5_spmv(const SlabCsr& m, const double* x, double* y, double alpha,
+                          int first_row, int last_row, double* d_dot_partials,
+                          const int* d_skip_flag, Stencil5Variant variant,
+                          const LaunchShape& shape, hipStream_t stream);
+
+// ---- CSR SpMV ----
+enum class CsrVariant { Auto, RowScalar, Wavefront, SubWave4, SubWave8, SubWave16, SubWave32 };
+void launch_csr_spmv(const SlabCsr& m, const double* x, double* y, double alpha,
+                     CsrVariant variant, hipStream_t stream);
+
+// ---- ELLPACK SpMV (device layout: slot-major, element (r,k) at [k * rows + r]) ----
+void launch_ell_transpose(int rows, int width, const int* idx_rowmajor, const double* val_rowmajor,
+                          int* idx_slotmajor, double* val_slotmajor, hipStream_t stream);
+void launch_ell_spmv(int rows, int width, const int* idx, const double* val, const double* x,
+                     double* y, double alpha, double beta, hipStream_t stream);
+// Interior rows take W,C,E,N,S from slots 1,2,3,0,4 with computed columns; others walk slots.
+void launch_ell_stencil5_spmv(int rows, int width, int grid_size, const int* idx,
+                              const double* val, const double* x, double* y, double alpha,
+                              double beta, hipStream_t stream);
+
+// ---- BLAS1 + reductions for CG ----
+// Device scalars of one CG solve, laid out in one small allocation.
+struct CgScalars {
+    double rr_old;
+    double rr_new;
+    double pAp;
+    double b_norm;
+    double residual;
+    double alpha;
+    double beta;
+    int converged;
+    int iterations;
+    int max_history;
+    int pad;
+};
+
+void launch_fill(double* d, size_t n, double value, hipStream_t stream);
+// y = y + a*x   (reference axpy_kernel, cg_solver.cu:38-43)
+void launch_axpy(size_t n, double a, const double* x, double* y, hipStream_t stream);
+// z = a*x + b*y (reference axpby_kernel, cg_solver.cu:48-54)
+void launch_axpby(size_t n, double a, const double* x, double b, const double* y, double* z,
+                  hipStream_t stream);
+// y += (*d_a)*x ; y -= (*d_a)*x ; p = r + (*d_b)*p (cg_solver.cu:59-95)
+void launch_axpy_dev(size_t n, const double* d_a, const double* x, double* y, bool subtract,
+                     hipStream_t stream);
+void launch_update_p_dev(size_t n, const double* r, const double* d_b, double* p,
+                         hipStream_t stream);
+// result = sum x[i]*y[i], fixed reduction shape (deterministic run to run). scratch must
+// hold dot_scratch_doubles() doubles.
+size_t dot_scratch_doubles();
+void launch_dot(size_t n, const double* x, const double* y, double* scratch, double* d_result,
+                hipStream_t stream);
+// *d_out = (*d_num) / (*d_den)   (scalar_divide_kernel, cg_solver.cu:414-419)
+void launch_scalar_divide(const double* d_num, const double* d_den, double* d_out,
+                          hipStream_t stream);
+// check_convergence_kernel (cg_solver.cu:424-431)
+void launch_check_convergence(const double* d_rr_new, double b_norm, double tol, int* d_converged,
+                              double* d_residual, hipStream_t stream);
+
+// ---- fused CG steps of the slab solver (all skip their work when s->converged) ----
+// r = b - Ap ; p = r ; partials of r.r
+void launch_cg_init_residual(size_t n, const double* b, const double* Ap, double* r, double* p,
+                             double* partials, hipStream_t stream);
+// alpha = rr_old / pAp ; x += alpha p ; r -= alpha Ap ; partials of r.r
+void launch_cg_update_xr(size_t n, const CgScalars* s, const double* p, const double* Ap,
+                         double* x, double* r, double* partials, hipStream_t stream);
+// p = 1.0*r + beta*p (axpby form of the multi-GPU reference, cg_solver_mgpu_partitioned.cu:136-140)
+void launch_cg_update_p(size_t n, const CgScalars* s, const double* r, double* p,
+                        hipStream_t stream);
+int cg_partial_count();  // partial slots written by the two kernels above
+// *d_out = sum of partials[0..count) in a fixed order (single block).
+void launch_reduce_partials(const double* partials, int count, double* d_out,
+                            const int* d_skip_flag, hipStream_t stream);
+// After the (all-reduced) r.r is known: b_norm (first call), residual, history, convergence
+// flag, beta, rr_old <- rr_new, iteration counter.
+void launch_cg_scalars_init(CgScalars* s, double* history, hipStream_t stream);
+void launch_cg_scalars_alpha(CgScalars* s, hipStream_t stream);
+void launch_cg_scalars_step(CgScalars* s, double tol, double* history, hipStream_t stream);
+
+}  // namespace spmv_amd

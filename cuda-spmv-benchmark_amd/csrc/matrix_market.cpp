@@ -1,0 +1,250 @@
+// matrix_market.cpp -- Matrix Market coordinate reader and the 5-point stencil writer.
+// Same file format, comment protocol ("% STENCIL_GRID_SIZE n") and 0-based Entry output as
+// reference src/io/io.cu; the text of write_matrix_market_stencil5 is byte-identical to the
+// reference writer's (checked against oracle/_ref in tests/test_io_host.py).
+//
+// Deliberate differences from the reference reader, all on error paths or unfinished code:
+//  * load_matrix_market returns non-zero when the file cannot be opened or is truncated
+//    (upstream returns 0 with an unfilled MatrixData, io.cu:73-93);
+//  * symmetric files fill mat->entries with the expanded general matrix (upstream builds CSR
+//    arrays that load_matrix_market then discards and leaves mat->entries unset, io.cu:189-310).
+#include <ctype.h>
+#include <errno.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "spmv_amd.h"
+
+namespace {
+
+// Whitespace-separated token reader over a large stdio buffer; what fscanf("%d %d %le") sees.
+class TokenReader {
+public:
+    explicit TokenReader(FILE* f) : f_(f), buf_(1 << 20), pos_(0), len_(0) {}
+    bool next(char* out, size_t cap) {
+        int c;
+        do {
+            c = get();
+        } while (c != EOF && isspace(c));
+        if (c == EOF) return false;
+        size_t n = 0;
+        while (c != EOF && !isspace(c)) {
+            if (n + 1 < cap) out[n++] = (char)c;
+            c = get();
+        }
+        out[n] = '\0';
+        return true;
+    }
+    bool next_int(int* v) {
+        char t[64];
+        if (!next(t, sizeof t)) return false;
+        char* end = nullptr;
+        errno = 0;
+        long x = strtol(t, &end, 10);
+        if (end == t || errno != 0) return false;
+        *v = (int)x;
+        return true;
+    }
+    bool next_double(double* v) {
+        char t[128];
+        if (!next(t, sizeof t)) return false;
+        char* end = nullptr;
+        *v = strtod(t, &end);
+        return end != t;
+    }
+
+private:
+    int get() {
+        if (pos_ == len_) {
+            len_ = fread(buf_.data(), 1, buf_.size(), f_);
+            pos_ = 0;
+            if (len_ == 0) return EOF;
+        }
+        return (unsigned char)buf_[pos_++];
+    }
+    FILE* f_;
+    std::vector<char> buf_;
+    size_t pos_, len_;
+};
+
+// Skips the '%' header, picks up the stencil comment, parses the size line.
+bool read_header(FILE* f, int* rows, int* cols, int* nnz, int* grid_size) {
+    char line[MAX_LINE_LENGTH];
+    *grid_size = -1;
+    while (fgets(line, sizeof line, f) != nullptr) {
+        if (line[0] == '%') {
+            if (strstr(line, "STENCIL_GRID_SIZE") != nullptr)
+                sscanf(line, "%% STENCIL_GRID_SIZE %d", grid_size);
+            continue;
+        }
+        return sscanf(line, "%d %d %d", rows, cols, nnz) == 3;
+    }
+    return false;
+}
+
+void fail(MatrixData* mat) {
+    mat->rows = mat->cols = mat->nnz = 0;
+    mat->grid_size = -1;
+    mat->entries = nullptr;
+}
+
+}  // namespace
+
+extern "C" int read_matrix_type(const char* filename) {
+    FILE* f = fopen(filename, "r");
+    if (!f) {
+        fprintf(stderr, "Error opening file\n");
+        return -1;
+    }
+    int type = -1;
+    char line[MAX_LINE_LENGTH];
+    while (fgets(line, sizeof line, f) != nullptr && line[0] == '%') {
+        if (strstr(line, "general") != nullptr) {
+            type = 1;
+            break;
+        }
+        if (strstr(line, "symmetric") != nullptr) {
+            type = 2;
+            break;
+        }
+    }
+    if (type < 0) fprintf(stderr, "Error opening file\n");
+    fclose(f);
+    return type;
+}
+
+extern "C" void read_matrix_general(MatrixData* mat, const char* filename, int* rows, int* cols,
+                                    int* nnz, int** csr_rowptr, int** csr_colind,
+                                    double** csr_val) {
+    (void)csr_rowptr, (void)csr_colind, (void)csr_val;  // unused upstream as well
+    fail(mat);
+    FILE* f = fopen(filename, "r");
+    if (!f) {
+        fprintf(stderr, "Error opening file\n");
+        return;
+    }
+    int grid_size = -1;
+    if (!read_header(f, rows, cols, nnz, &grid_size) || *nnz < 0) {
+        fprintf(stderr, "Error reading matrix size line\n");
+        fclose(f);
+        return;
+    }
+    Entry* entries = (Entry*)malloc(((size_t)*nnz ? (size_t)*nnz : 1) * sizeof(Entry));
+    if (!entries) {
+        fprintf(stderr, "Allocation failed at line %d\n", __LINE__);
+        exit(1);
+    }
+    TokenReader in(f);
+    for (int k = 0; k < *nnz; ++k) {
+        int r, c;
+        double v;
+        const int got = in.next_int(&r) ? (in.next_int(&c) ? (in.next_double(&v) ? 3 : 2) : 1) : 0;
+        if (got != 3) {
+            fprintf(stderr, "Error reading matrix entry %d (expected 3 items, got %d)\n", k, got);
+            free(entries);
+            fclose(f);
+            return;
+        }
+        entries[k].row = r - 1;
+        entries[k].col = c - 1;
+        entries[k].value = v;
+    }
+    fclose(f);
+    mat->entries = entries;
+    mat->rows = *rows;
+    mat->cols = *cols;
+    mat->nnz = *nnz;
+    mat->grid_size = grid_size;
+}
+
+extern "C" void read_matrix_symtogen(MatrixData* mat, const char* filename, int* rows, int* cols,
+                                     int* nnz, int** csr_rowptr, int** csr_colind,
+                                     double** csr_val, int* nnz_general) {
+    // Read the stored triangle, then mirror every off-diagonal entry right after itself.
+    MatrixData tri;
+    read_matrix_general(&tri, filename, rows, cols, nnz, nullptr, nullptr, nullptr);
+    fail(mat);
+    if (csr_rowptr) *csr_rowptr = nullptr;
+    if (csr_colind) *csr_colind = nullptr;
+    if (csr_val) *csr_val = nullptr;
+    *nnz_general = 0;
+    if (tri.entries == nullptr) return;
+    size_t diag = 0;
+    for (int k = 0; k < tri.nnz; ++k) diag += tri.entries[k].row == tri.entries[k].col;
+    const size_t full = 2 * (size_t)tri.nnz - diag;
+    Entry* out = (Entry*)malloc((full ? full : 1) * sizeof(Entry));
+    if (!out) {
+        fprintf(stderr, "Memory allocation error\n");
+        free(tri.entries);
+        return;
+    }
+    size_t w = 0;
+    for (int k = 0; k < tri.nnz; ++k) {
+        const Entry e = tri.entries[k];
+        out[w++] = e;
+        if (e.row != e.col) out[w++] = Entry{e.col, e.row, e.value};
+    }
+    free(tri.entries);
+    *nnz_general = (int)full;
+    mat->entries = out;
+    mat->rows = tri.rows;
+    mat->cols = tri.cols;
+    mat->nnz = (int)full;
+    mat->grid_size = tri.grid_size;
+}
+
+extern "C" int load_matrix_market(const char* filename, MatrixData* mat) {
+    printf("Loading matrix: %s\n", filename);
+    int rows = 0, cols = 0, nnz = 0, nnz_general = 0;
+    const int type = read_matrix_type(filename);
+    if (type == 2)
+        read_matrix_symtogen(mat, filename, &rows, &cols, &nnz, nullptr, nullptr, nullptr,
+                             &nnz_general);
+    else
+        read_matrix_general(mat, filename, &rows, &cols, &nnz, nullptr, nullptr, nullptr);
+    return mat->entries != nullptr ? 0 : 1;
+}
+
+namespace {
+// One grid point's lines in the writer's order: centre, left, right, top, bottom.
+int write_stencil5(int n, const char* filename, const char* center, const char* off) {
+    const long long N = (long long)n * n;
+    const long long nnz = 5LL * n * n - 4LL * n;
+    FILE* f = fopen(filename, "w");
+    if (!f) {
+        perror("fopen");
+        exit(1);
+    }
+    std::vector<char> big(1 << 20);
+    setvbuf(f, big.data(), _IOFBF, big.size());
+    fprintf(f, "%%%%MatrixMarket matrix coordinate real general\n");
+    fprintf(f, "%% STENCIL_GRID_SIZE %d\n", n);
+    fprintf(f, "%lld %lld %lld\n", N, N, n == 1 ? 1LL : nnz);
+    for (int gi = 0; gi < n; ++gi) {
+        for (int gj = 0; gj < n; ++gj) {
+            const long long id = (long long)gi * n + gj + 1;  // 1-based
+            fprintf(f, "%lld %lld %s\n", id, id, center);
+            if (gj > 0) fprintf(f, "%lld %lld %s\n", id, id - 1, off);
+            if (gj < n - 1) fprintf(f, "%lld %lld %s\n", id, id + 1, off);
+            if (gi > 0) fprintf(f, "%lld %lld %s\n", id, id - n, off);
+            if (gi < n - 1) fprintf(f, "%lld %lld %s\n", id, id + n, off);
+        }
+    }
+    fclose(f);
+    printf("Matrix generated: %s (%lldx%lld, %lld nnz)\n", filename, N, N, n == 1 ? 1LL : nnz);
+    return 0;
+}
+}  // namespace
+
+extern "C" int write_matrix_market_stencil5(int n, const char* filename) {
+    return write_stencil5(n, filename, "5.0", "-1.0");
+}
+
+// Older convention of the shipped matrix/example81x81.mtx (centre -4.0): used to regenerate
+// that fixture, see tests/golden/make_golden.py.
+extern "C" int spmv_amd_write_stencil5_values(int n, const char* filename, const char* center_text,
+                                              const char* off_text) {
+    return write_stencil5(n, filename, center_text, off_text);
+}

@@ -1,0 +1,436 @@
+// operators.hip -- the SpmvOperator tables behind get_operator().
+//
+//   "stencil5-csr"     <- reference SPMV_STENCIL5_CSR, src/spmv/spmv_stencil_csr_direct.cu:194-307
+//   "cusparse-csr"     <- reference SPMV_CSR, src/spmv/spmv_cusparse_csr.cu:182-327 (the cuSPARSE
+//                         call is replaced by this build's own CSR kernels; the name is kept so that
+//                         calculate_spmv_metrics and the harness scripts keep working)
+//   "ellpack",
+//   "stencil5-ellpack" <- reference include/spmv_ellpack.h, include/spmv_stencil.h:25-42 (headers only)
+//
+// Lifecycle, ownership and error behaviour follow the reference: init builds the host CSR
+// through build_csr_struct (kept in csr_mat for the other operators), uploads it, and allocates
+// the x/y staging vectors; run_timed copies x in, times the kernel alone with events, copies y
+// out; run_device enqueues on the default stream and returns; free drops device memory only.
+// One live instance per operator per process (file-static state, as upstream).
+#include <string.h>
+
+#include "device_runtime.hpp"
+#include "stencil_geometry.hpp"
+
+using namespace spmv_amd;
+
+namespace {
+
+constexpr hipStream_t kDefaultStream = nullptr;  // the reference launches on the default stream
+
+struct CsrBackedOperator {
+    const char* tag;
+    DeviceCsr A;
+    double* dX = nullptr;
+    double* dY = nullptr;
+    int rows = 0, cols = 0;
+    bool ready = false;
+    Stencil5Variant stencil_variant = Stencil5Variant::Auto;
+    CsrVariant csr_variant = CsrVariant::Auto;
+    const char* variant_name = "uninitialised";
+
+    void alloc_vectors() {
+        dX = device_alloc<double>((size_t)cols);
+        dY = device_alloc<double>((size_t)rows);
+    }
+    int init_from_host(MatrixData* mat) {
+        if (build_csr_struct(mat) != EXIT_SUCCESS) return EXIT_FAILURE;
+        drop();
+        rows = csr_mat.nb_rows;
+        cols = csr_mat.nb_cols;
+        A.upload_slab(csr_mat, 0, rows, mat->grid_size);
+        A.view.halo_after = cols - rows;  // x is readable on [0, cols)
+        alloc_vectors();
+        ready = true;
+        return 0;
+    }
+    int init_synthetic(int n) {
+        drop();
+        if (n < 1 || (long long)n * n > 0x7fffffffLL || 5LL * n * n - 4LL * n > 0x7fffffffLL) {
+            fprintf(stderr, "[%s] grid %d does not fit 32-bit CSR indices\n", tag, n);
+            return EXIT_FAILURE;
+        }
+        rows = cols = n * n;
+        A.generate_stencil5(n, 0, rows, 5.0, -1.0, kDefaultStream);
+        // dimensions for calculate_spmv_metrics; the host arrays do not exist on this path
+        spmv_amd_reset_host_matrices();
+        csr_mat.nb_rows = rows;
+        csr_mat.nb_cols = cols;
+        csr_mat.nb_nonzeros = (int)A.view.nnz_local;
+        alloc_vectors();
+        ready = true;
+        return 0;
+    }
+    void drop() {
+        A.release();
+        device_release(dX);
+        device_release(dY);
+        ready = false;
+        variant_name = "uninitialised";
+    }
+};
+
+CsrBackedOperator g_stencil{"stencil5-csr"};
+CsrBackedOperator g_csr{"cusparse-csr"};
+
+// ---- stencil5-csr ----------------------------------------------------------------
+
+void stencil_pick_variant() {
+    const bool tile = g_stencil.A.view.verified_stencil && g_stencil.A.view.grid_size >= 128 &&
+                      g_stencil.stencil_variant != Stencil5Variant::RowGeneric;
+    g_stencil.variant_name = tile ? "stencil5/wave-tile"
+                             : g_stencil.A.view.verified_stencil ? "stencil5/row-generic"
+                                                                 : "stencil5/row-generic(csr-loop)";
+}
+
+int stencil_init(MatrixData* mat) {
+    printf("[stencil5-csr] Initializing (computed offsets, wave-tile kernel on gfx950)\n");
+    if (g_stencil.init_from_host(mat) != 0) return EXIT_FAILURE;
+    g_stencil.A.verify_stencil(kDefaultStream);
+    stencil_pick_variant();
+    printf("[stencil5-csr] %d rows, %d nnz, grid %dx%d, variant %s\n", csr_mat.nb_rows,
+           csr_mat.nb_nonzeros, mat->grid_size, mat->grid_size, g_stencil.variant_name);
+    return 0;
+}
+
+int stencil_run_device(const double* d_x, double* d_y) {
+    if (!g_stencil.ready) {
+        fprintf(stderr, "[stencil5-csr] run before init\n");
+        return EXIT_FAILURE;
+    }
+    launch_stencil5_spmv(g_stencil.A.view, d_x, d_y, /*alpha=*/1.0, 0, g_stencil.rows, nullptr,
+                         nullptr, g_stencil.stencil_variant, current_launch_shape(), kDefaultStream);
+    return 0;
+}
+
+template <int (*RunDevice)(const double*, double*), CsrBackedOperator* Op>
+int run_timed_generic(const double* x, double* y, double* kernel_time_ms) {
+    if (!Op->ready) {
+        fprintf(stderr, "[%s] run before init\n", Op->tag);
+        return EXIT_FAILURE;
+    }
+    upload(Op->dX, x, (size_t)Op->cols);
+    EventTimer t;
+    t.begin(kDefaultStream);
+    RunDevice(Op->dX, Op->dY);
+    t.end(kDefaultStream);
+    *kernel_time_ms = (double)t.elapsed_ms();
+    HIP_CHECK(hipGetLastError());
+    download(y, Op->dY, (size_t)Op->rows);
+    return 0;
+}
+
+void stencil_free() {
+    printf("[stencil5-csr] Cleaning up\n");
+    g_stencil.drop();
+}
+
+// ---- cusparse-csr ----------------------------------------------------------------
+
+const char* csr_variant_name(CsrVariant v, const SlabCsr& m) {
+    if (v == CsrVariant::Auto) {
+        const double avg = m.n_local > 0 ? (double)m.nnz_local / m.n_local : 0.0;
+        v = avg <= 2.0    ? CsrVariant::RowScalar
+            : avg <= 4.0  ? CsrVariant::SubWave4
+            : avg <= 8.0  ? CsrVariant::SubWave8
+            : avg <= 16.0 ? CsrVariant::SubWave16
+            : avg <= 32.0 ? CsrVariant::SubWave32
+                          : CsrVariant::Wavefront;
+    }
+    switch (v) {
+        case CsrVariant::RowScalar: return "csr/row-scalar";
+        case CsrVariant::SubWave4: return "csr/subwave4";
+        case CsrVariant::SubWave8: return "csr/subwave8";
+        case CsrVariant::SubWave16: return "csr/subwave16";
+        case CsrVariant::SubWave32: return "csr/subwave32";
+        default: return "csr/wavefront";
+    }
+}
+
+int csr_init(MatrixData* mat) {
+    if (g_csr.init_from_host(mat) != 0) return EXIT_FAILURE;
+    g_csr.variant_name = csr_variant_name(g_csr.csr_variant, g_csr.A.view);
+    printf("[cusparse-csr] %d rows, %d nnz, variant %s\n", csr_mat.nb_rows, csr_mat.nb_nonzeros,
+           g_csr.variant_name);
+    return EXIT_SUCCESS;
+}
+
+int csr_run_device(const double* d_x, double* d_y) {
+    if (!g_csr.ready) {
+        fprintf(stderr, "[cusparse-csr] run before init\n");
+        return EXIT_FAILURE;
+    }
+    launch_csr_spmv(g_csr.A.view, d_x, d_y, /*alpha=*/1.0, g_csr.csr_variant, kDefaultStream);
+    return EXIT_SUCCESS;
+}
+
+void csr_free() {
+    printf("[CSR] Cleaning up\n");
+    g_csr.drop();
+}
+
+// ---- ellpack / stencil5-ellpack -----------------------------------------------------
+
+struct EllOperator {
+    const char* tag;
+    bool stencil_fast_path;
+    int* idx = nullptr;    // slot-major
+    double* val = nullptr; // slot-major
+    double* dX = nullptr;
+    double* dY = nullptr;
+    int rows = 0, cols = 0, width = 0, grid_size = -1;
+    bool verified = false;
+    bool ready = false;
+    const char* variant_name = "uninitialised";
+    void drop() {
+        device_release(idx);
+        device_release(val);
+        device_release(dX);
+        device_release(dY);
+        ready = false;
+        variant_name = "uninitialised";
+    }
+    void pick() {
+        variant_name = (stencil_fast_path && verified && grid_size >= 3) ? "ell/stencil5-direct"
+                                                                        : "ell/slot-major";
+    }
+};
+
+EllOperator g_ell{"ellpack", false};
+EllOperator g_ell_stencil{"stencil5-ellpack", true};
+
+__global__ void csr_to_ell_slotmajor_kernel(SlabCsr m, int width, int* __restrict__ idx,
+                                            double* __restrict__ val) {
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= m.n_local) return;
+    const int lo = m.row_ptr[r], len = m.row_ptr[r + 1] - lo;
+    for (int k = 0; k < width; ++k) {
+        const bool live = k < len;
+        idx[(long long)k * m.n_local + r] = live ? m.col_idx[lo + k] : -1;
+        val[(long long)k * m.n_local + r] = live ? m.values[lo + k] : 0.0;
+    }
+}
+
+int ell_init_common(EllOperator& op, MatrixData* mat) {
+    if (ensure_ellpack_structure_built(mat) != EXIT_SUCCESS) return EXIT_FAILURE;
+    op.drop();
+    const ELLPACKMatrix& E = ellpack_matrix;
+    op.rows = E.nb_rows, op.cols = E.nb_cols, op.width = E.ell_width, op.grid_size = mat->grid_size;
+    const size_t slots = (size_t)op.rows * op.width;
+    int* idx_rm = device_alloc<int>(slots);
+    double* val_rm = device_alloc<double>(slots);
+    upload(idx_rm, E.indices, slots);
+    upload(val_rm, E.values, slots);
+    op.idx = device_alloc<int>(slots);
+    op.val = device_alloc<double>(slots);
+    launch_ell_transpose(op.rows, op.width, idx_rm, val_rm, op.idx, op.val, kDefaultStream);
+    HIP_CHECK(hipStreamSynchronize(kDefaultStream));
+    device_release(idx_rm);
+    device_release(val_rm);
+    op.verified = false;
+    if (op.stencil_fast_path && csr_mat.row_ptr != nullptr) {
+        DeviceCsr probe;  // structure check on the CSR the ELL was built from
+        probe.upload_slab(csr_mat, 0, op.rows, mat->grid_size);
+        probe.verify_stencil(kDefaultStream);
+        op.verified = probe.view.verified_stencil;
+        probe.release();
+    }
+    op.dX = device_alloc<double>((size_t)op.cols);
+    op.dY = device_alloc<double>((size_t)op.rows);
+    op.ready = true;
+    op.pick();
+    printf("[%s] %d rows, width %d, variant %s\n", op.tag, op.rows, op.width, op.variant_name);
+    return 0;
+}
+
+int ell_init_synthetic(EllOperator& op, int n) {
+    op.drop();
+    DeviceCsr src;
+    if ((long long)n * n > 0x7fffffffLL || 5LL * n * n > 0x7fffffffLL) return EXIT_FAILURE;
+    src.generate_stencil5(n, 0, n * n, 5.0, -1.0, kDefaultStream);
+    op.rows = op.cols = n * n;
+    op.width = n >= 3 ? 5 : (n == 2 ? 3 : 1);
+    op.grid_size = n;
+    const size_t slots = (size_t)op.rows * op.width;
+    op.idx = device_alloc<int>(slots);
+    op.val = device_alloc<double>(slots);
+    hipLaunchKernelGGL(csr_to_ell_slotmajor_kernel, dim3((op.rows + 255) / 256), dim3(256), 0,
+                       kDefaultStream, src.view, op.width, op.idx, op.val);
+    HIP_CHECK(hipStreamSynchronize(kDefaultStream));
+    src.release();
+    op.verified = true;
+    spmv_amd_reset_host_matrices();
+    csr_mat.nb_rows = csr_mat.nb_cols = op.rows;
+    csr_mat.nb_nonzeros = (int)(5LL * n * n - 4LL * n);
+    op.dX = device_alloc<double>((size_t)op.cols);
+    op.dY = device_alloc<double>((size_t)op.rows);
+    op.ready = true;
+    op.pick();
+    return 0;
+}
+
+int ell_run(EllOperator& op, const double* d_x, double* d_y) {
+    if (!op.ready) {
+        fprintf(stderr, "[%s] run before init\n", op.tag);
+        return EXIT_FAILURE;
+    }
+    if (op.stencil_fast_path && op.verified)
+        launch_ell_stencil5_spmv(op.rows, op.width, op.grid_size, op.idx, op.val, d_x, d_y, 1.0, 0.0,
+                                 kDefaultStream);
+    else
+        launch_ell_spmv(op.rows, op.width, op.idx, op.val, d_x, d_y, 1.0, 0.0, kDefaultStream);
+    return 0;
+}
+
+int ell_run_timed(EllOperator& op, const double* x, double* y, double* kernel_time_ms) {
+    if (!op.ready) return EXIT_FAILURE;
+    upload(op.dX, x, (size_t)op.cols);
+    EventTimer t;
+    t.begin(kDefaultStream);
+    ell_run(op, op.dX, op.dY);
+    t.end(kDefaultStream);
+    *kernel_time_ms = (double)t.elapsed_ms();
+    HIP_CHECK(hipGetLastError());
+    download(y, op.dY, (size_t)op.rows);
+    return 0;
+}
+
+int ellg_init(MatrixData* m) { return ell_init_common(g_ell, m); }
+int ellg_run_timed(const double* x, double* y, double* ms) { return ell_run_timed(g_ell, x, y, ms); }
+int ellg_run_device(const double* x, double* y) { return ell_run(g_ell, x, y); }
+void ellg_free() { g_ell.drop(); }
+int ells_init(MatrixData* m) { return ell_init_common(g_ell_stencil, m); }
+int ells_run_timed(const double* x, double* y, double* ms) { return ell_run_timed(g_ell_stencil, x, y, ms); }
+int ells_run_device(const double* x, double* y) { return ell_run(g_ell_stencil, x, y); }
+void ells_free() { g_ell_stencil.drop(); }
+
+// ---- name table ------------------------------------------------------------------
+
+enum class Which { None, Stencil, Csr, Ell, EllStencil };
+
+Which which_operator(const char* mode) {
+    if (!mode) return Which::None;
+    if (!strcmp(mode, "stencil5-csr") || !strcmp(mode, "stencil5")) return Which::Stencil;
+    if (!strcmp(mode, "cusparse-csr") || !strcmp(mode, "csr")) return Which::Csr;
+    if (!strcmp(mode, "ellpack")) return Which::Ell;
+    if (!strcmp(mode, "stencil5-ellpack")) return Which::EllStencil;
+    return Which::None;
+}
+
+}  // namespace
+
+SpmvOperator SPMV_STENCIL5_CSR = {"stencil5-csr", stencil_init,
+                                  run_timed_generic<stencil_run_device, &g_stencil>,
+                                  stencil_run_device, stencil_free};
+SpmvOperator SPMV_CSR = {"cusparse-csr", csr_init, run_timed_generic<csr_run_device, &g_csr>,
+                         csr_run_device, csr_free};
+SpmvOperator SPMV_ELLPACK = {"ellpack", ellg_init, ellg_run_timed, ellg_run_device, ellg_free};
+SpmvOperator SPMV_STENCIL5_ELLPACK = {"stencil5-ellpack", ells_init, ells_run_timed,
+                                      ells_run_device, ells_free};
+// Upstream declares this table under __has_include(<mpi.h>) and never defines it; here the
+// multi-GPU SpMV lives in the slab solver (cg_slab.hip), so the name resolves to the
+// single-GPU stencil operator.
+SpmvOperator SPMV_STENCIL_HALO_MGPU = {"stencil5-halo-mgpu", stencil_init,
+                                       run_timed_generic<stencil_run_device, &g_stencil>,
+                                       stencil_run_device, stencil_free};
+
+extern "C" SpmvOperator* get_operator(const char* mode) {
+    switch (which_operator(mode)) {
+        case Which::Stencil: return &SPMV_STENCIL5_CSR;
+        case Which::Csr: return &SPMV_CSR;
+        case Which::Ell: return &SPMV_ELLPACK;
+        case Which::EllStencil: return &SPMV_STENCIL5_ELLPACK;
+        default: break;
+    }
+    if (mode && !strcmp(mode, "stencil5-halo-mgpu")) return &SPMV_STENCIL_HALO_MGPU;
+    return nullptr;
+}
+
+extern "C" int spmv_amd_init_stencil5_synthetic(const char* mode, int n) {
+    switch (which_operator(mode)) {
+        case Which::Stencil:
+            if (g_stencil.init_synthetic(n) != 0) return EXIT_FAILURE;
+            g_stencil.A.verify_stencil(kDefaultStream);
+            stencil_pick_variant();
+            return 0;
+        case Which::Csr:
+            if (g_csr.init_synthetic(n) != 0) return EXIT_FAILURE;
+            HIP_CHECK(hipStreamSynchronize(kDefaultStream));
+            g_csr.variant_name = csr_variant_name(g_csr.csr_variant, g_csr.A.view);
+            return 0;
+        case Which::Ell: return ell_init_synthetic(g_ell, n);
+        case Which::EllStencil: return ell_init_synthetic(g_ell_stencil, n);
+        default: return EXIT_FAILURE;
+    }
+}
+
+extern "C" int spmv_amd_download_device_csr(const char* mode, int* row_ptr, int* col_idx,
+                                            double* values) {
+    CsrBackedOperator* op = which_operator(mode) == Which::Stencil ? &g_stencil
+                            : which_operator(mode) == Which::Csr   ? &g_csr
+                                                                   : nullptr;
+    if (!op || !op->ready) return EXIT_FAILURE;
+    HIP_CHECK(hipDeviceSynchronize());
+    if (row_ptr) download(row_ptr, op->A.row_ptr, (size_t)op->rows + 1);
+    if (col_idx) download(col_idx, op->A.col_idx, (size_t)op->A.view.nnz_local);
+    if (values) download(values, op->A.values, (size_t)op->A.view.nnz_local);
+    return 0;
+}
+
+extern "C" int spmv_amd_time_run_device(const char* mode, const double* d_x, double* d_y, int reps,
+                                        float* ms_each) {
+    SpmvOperator* op = get_operator(mode);
+    if (!op || reps <= 0) return EXIT_FAILURE;
+    EventTimer t;
+    for (int i = 0; i < reps; ++i) {
+        t.begin(kDefaultStream);
+        if (op->run_device(d_x, d_y) != 0) return EXIT_FAILURE;
+        t.end(kDefaultStream);
+        ms_each[i] = t.elapsed_ms();
+    }
+    HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+extern "C" const char* spmv_amd_operator_variant(const char* mode) {
+    switch (which_operator(mode)) {
+        case Which::Stencil: return g_stencil.variant_name;
+        case Which::Csr: return g_csr.variant_name;
+        case Which::Ell: return g_ell.variant_name;
+        case Which::EllStencil: return g_ell_stencil.variant_name;
+        default: return "unknown-operator";
+    }
+}
+
+extern "C" int spmv_amd_operator_select_variant(const char* mode, const char* variant) {
+    const bool automatic = variant == nullptr || !strcmp(variant, "auto");
+    switch (which_operator(mode)) {
+        case Which::Stencil:
+            if (automatic) g_stencil.stencil_variant = Stencil5Variant::Auto;
+            else if (!strcmp(variant, "wave-tile")) g_stencil.stencil_variant = Stencil5Variant::WaveTile;
+            else if (!strcmp(variant, "row-generic")) g_stencil.stencil_variant = Stencil5Variant::RowGeneric;
+            else return EXIT_FAILURE;
+            if (g_stencil.ready) stencil_pick_variant();
+            return 0;
+        case Which::Csr: {
+            CsrVariant v;
+            if (automatic) v = CsrVariant::Auto;
+            else if (!strcmp(variant, "row-scalar")) v = CsrVariant::RowScalar;
+            else if (!strcmp(variant, "wavefront")) v = CsrVariant::Wavefront;
+            else if (!strcmp(variant, "subwave4")) v = CsrVariant::SubWave4;
+            else if (!strcmp(variant, "subwave8")) v = CsrVariant::SubWave8;
+            else if (!strcmp(variant, "subwave16")) v = CsrVariant::SubWave16;
+            else if (!strcmp(variant, "subwave32")) v = CsrVariant::SubWave32;
+            else return EXIT_FAILURE;
+            g_csr.csr_variant = v;
+            if (g_csr.ready) g_csr.variant_name = csr_variant_name(v, g_csr.A.view);
+            return 0;
+        }
+        default: return EXIT_FAILURE;
+    }
+}

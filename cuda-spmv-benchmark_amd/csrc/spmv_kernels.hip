@@ -1,0 +1,496 @@
+// spmv_kernels.hip -- hand-written gfx950 kernels for the three SpMV operators.
+//
+// Arithmetic contract (numerical-semantics checklist): every
+// multiply-add below is an explicit fma() and the file is compiled with
+// -ffp-contract=off, so the order and fusing of operations is exactly
+//   interior stencil rows : t = vW*xW ; fma(vC,xC,t) ; fma(vE,xE,t) ; fma(vN,xN,t) ; fma(vS,xS,t)
+//                           (reference src/spmv/spmv_stencil_csr_direct.cu:105-109 under nvcc -fmad)
+//   every other row       : sum = 0 ; sum = fma(v[k], x[col[k]], sum) for ascending k
+//                           (reference :116-119 ; cg_solver_mgpu_partitioned.cu:49-52)
+// which is what oracle/spmv_oracle.c evaluates on the CPU.
+//
+// Memory contract: STENCIL5 is HBM-bound at 56 B per interior row (40 B values, 8 B x,
+// 8 B y). The wave-tile kernel streams `values` with fully coalesced 16-byte loads,
+// transposes them through a wave-private LDS strip, reads x/y as 16-byte pairs and
+// keeps the +-grid_size neighbour rows L2-resident by giving each XCD a contiguous
+// band of tiles (blockIdx % 8 is only a locality label, never a correctness input).
+#include "kernels.hpp"
+#include "stencil_geometry.hpp"
+
+namespace spmv_amd {
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kWavesPerBlock = 4;
+constexpr int kTileRows = 128;           // rows per wave-tile: two per lane
+constexpr int kLdsDoublesPerWave = 656;  // 640 values + 2 alignment slack, 5248 B per wave
+
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+// x[col - row_offset] if that index is readable, else 0 (halo kernel semantics,
+// reference src/spmv/spmv_stencil_partitioned_halo_kernel.cu:77-94).
+__device__ __forceinline__ double x_at(const double* __restrict__ x, long long local_col,
+                                       int lo, int hi) {
+    return (local_col >= lo && local_col < hi) ? x[local_col] : 0.0;
+}
+
+// One row, evaluated the way the reference kernels do: computed offset and computed
+// columns for interior rows of a verified stencil, the CSR loop otherwise.
+template <bool kAnalyticInterior>
+__device__ __forceinline__ double row_reference(const SlabCsr& m, const double* __restrict__ x,
+                                                int local_row, int i, int j) {
+    const int n = m.grid_size;
+    if (kAnalyticInterior && stencil_is_interior(i, j, n)) {
+        const long long o = stencil_row_start(i, j, n) - m.nnz_base;
+        const double* __restrict__ v = m.values + o;
+        const double* __restrict__ xl = x + local_row;
+        double sum = v[1] * xl[-1];
+        sum = fma(v[2], xl[0], sum);
+        sum = fma(v[3], xl[1], sum);
+        sum = fma(v[0], xl[-n], sum);
+        sum = fma(v[4], xl[n], sum);
+        return sum;
+    }
+    const int lo = -m.halo_before, hi = m.n_local + m.halo_after;
+    const int k0 = m.row_ptr[local_row], k1 = m.row_ptr[local_row + 1];
+    double sum = 0.0;
+    for (int k = k0; k < k1; ++k)
+        sum = fma(m.values[k], x_at(x, (long long)m.col_idx[k] - m.row_offset, lo, hi), sum);
+    return sum;
+}
+
+// ---------------------------------------------------------------------------------
+// STENCIL5, wave-tile variant. One wave owns 128 consecutive rows at a time; waves are
+// persistent and walk the tiles of their XCD's band round-robin.
+// ---------------------------------------------------------------------------------
+template <bool kVecXY, bool kVecNS, bool kDot>
+__global__ __launch_bounds__(kBlock) void stencil5_wavetile_kernel(
+    SlabCsr m, const double* __restrict__ x, double* __restrict__ y, double alpha, int first_row,
+    int last_row, double* __restrict__ dot_partials, const int* __restrict__ skip_flag) {
+    __shared__ __attribute__((aligned(16))) double lds[kWavesPerBlock * kLdsDoublesPerWave];
+    if (skip_flag != nullptr && *skip_flag != 0) return;
+
+    const int lane = threadIdx.x & 63;
+    const int wave_in_block = threadIdx.x >> 6;
+    double* __restrict__ wlds = lds + wave_in_block * kLdsDoublesPerWave;
+    const int n = m.grid_size;
+
+    const int tile_first = first_row / kTileRows;
+    const int tile_end = (last_row + kTileRows - 1) / kTileRows;
+    const int per_band = (tile_end - tile_first + 7) >> 3;
+    const int band_lo = tile_first + (int)(blockIdx.x & 7) * per_band;
+    const int band_hi = min(band_lo + per_band, tile_end);
+    const int waves_per_band = (int)(gridDim.x >> 3) * kWavesPerBlock;
+    const int q = (int)(blockIdx.x >> 3) * kWavesPerBlock + wave_in_block;
+
+    double dot_acc = 0.0;
+    for (int t = band_lo + q; t < band_hi; t += waves_per_band) {
+        const int l0 = t * kTileRows;
+        const int g0 = m.row_offset + l0;
+        const int i0 = g0 / n;
+        const int j0 = g0 - i0 * n;
+        const bool pure = l0 >= first_row && l0 + kTileRows <= last_row && i0 >= 1 &&
+                          i0 <= n - 2 && j0 >= 1 && j0 + kTileRows - 1 <= n - 2;
+        if (pure) {
+            // -- values: 640 consecutive doubles starting at s0, fetched as aligned 16-byte pairs
+            const long long s0 = stencil_gridrow_base(i0, n) + 5LL * j0 - 1 - m.nnz_base;
+            const int sh = (int)(s0 & 1);
+            const d2* __restrict__ vsrc = reinterpret_cast<const d2*>(m.values + (s0 - sh));
+            const d2 c0 = vsrc[lane];
+            const d2 c1 = vsrc[64 + lane];
+            const d2 c2 = vsrc[128 + lane];
+            const d2 c3 = vsrc[192 + lane];
+            const d2 c4 = vsrc[256 + lane];
+            d2 c5 = {0.0, 0.0};
+            if (sh != 0 && lane == 0) c5 = vsrc[320];
+
+            // -- x: centre pair, north pair, south pair, plus the two row-edge scalars
+            const double* __restrict__ xl = x + l0 + 2 * lane;
+            d2 xc, xn, xs;
+            if (kVecXY) {
+                xc = *reinterpret_cast<const d2*>(xl);
+            } else {
+                xc.x = xl[0];
+                xc.y = xl[1];
+            }
+            if (kVecNS) {
+                xn = *reinterpret_cast<const d2*>(xl - n);
+                xs = *reinterpret_cast<const d2*>(xl + n);
+            } else {
+                xn.x = xl[-n];
+                xn.y = xl[1 - n];
+                xs.x = xl[n];
+                xs.y = xl[n + 1];
+            }
+            double edge = 0.0;
+            if (lane == 0) edge = xl[-1];
+            if (lane == 63) edge = xl[2];
+
+            // -- transpose values through the wave's LDS strip
+            d2* __restrict__ w2 = reinterpret_cast<d2*>(wlds);
+            w2[lane] = c0;
+            w2[64 + lane] = c1;
+            w2[128 + lane] = c2;
+            w2[192 + lane] = c3;
+            w2[256 + lane] = c4;
+            if (sh != 0 && lane == 0) w2[320] = c5;
+            __builtin_amdgcn_wave_barrier();
+            const double* __restrict__ v = wlds + sh + 10 * lane;
+            const double a0 = v[0], a1 = v[1], a2 = v[2], a3 = v[3], a4 = v[4];
+            const double b0 = v[5], b1 = v[6], b2 = v[7], b3 = v[8], b4 = v[9];
+            __builtin_amdgcn_wave_barrier();
+
+            double w = __shfl_up(xc.y, 1);
+            double e = __shfl_down(xc.x, 1);
+            if (lane == 0) w = edge;
+            if (lane == 63) e = edge;
+
+            // row 2*lane: [N,W,C,E,S] = a0..a4 ; row 2*lane+1: b0..b4 ; order W,C,E,N,S
+            double r0 = a1 * w;
+            r0 = fma(a2, xc.x, r0);
+            r0 = fma(a3, xc.y, r0);
+            r0 = fma(a0, xn.x, r0);
+            r0 = fma(a4, xs.x, r0);
+            double r1 = b1 * xc.x;
+            r1 = fma(b2, xc.y, r1);
+            r1 = fma(b3, e, r1);
+            r1 = fma(b0, xn.y, r1);
+            r1 = fma(b4, xs.y, r1);
+            if (kDot) {
+                dot_acc = fma(xc.x, r0, dot_acc);
+                dot_acc = fma(xc.y, r1, dot_acc);
+            }
+            double* __restrict__ yl = y + l0 + 2 * lane;
+            if (kVecXY) {
+                d2 out = {alpha * r0, alpha * r1};
+                *reinterpret_cast<d2*>(yl) = out;
+            } else {
+                yl[0] = alpha * r0;
+                yl[1] = alpha * r1;
+            }
+        } else {
+            // tile touching a grid-row end, the first/last grid row, or the launch range's edge
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int lr = l0 + 2 * lane + e;
+                if (lr >= first_row && lr < last_row) {
+                    int j = j0 + 2 * lane + e;
+                    int i = i0;
+                    if (j >= n) {
+                        j -= n;
+                        ++i;
+                    }
+                    const double sum = row_reference<true>(m, x, lr, i, j);
+                    if (kDot) dot_acc = fma(x[lr], sum, dot_acc);
+                    y[lr] = alpha * sum;
+                }
+            }
+        }
+    }
+    if (kDot) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) dot_acc += __shfl_down(dot_acc, off);
+        if (lane == 0) dot_partials[blockIdx.x * kWavesPerBlock + wave_in_block] = dot_acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// STENCIL5, row-generic variant: one thread per row, the reference's own shape. Used for
+// small grids, for matrices that are not a complete 5-point stencil (kAnalytic = false:
+// every row takes the CSR loop, as the reference does when grid_size = -1).
+// ---------------------------------------------------------------------------------
+template <bool kAnalytic>
+__global__ __launch_bounds__(kBlock) void stencil5_row_kernel(SlabCsr m, const double* __restrict__ x,
+                                                              double* __restrict__ y, double alpha,
+                                                              int first_row, int last_row,
+                                                              const int* __restrict__ skip_flag) {
+    if (skip_flag != nullptr && *skip_flag != 0) return;
+    const long long row = (long long)first_row + (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (row >= last_row) return;
+    int i = -1, j = 0;
+    if (kAnalytic) {
+        const int g = m.row_offset + (int)row;
+        i = g / m.grid_size;
+        j = g - i * m.grid_size;
+    }
+    y[row] = alpha * row_reference<kAnalytic>(m, x, (int)row, i, j);
+}
+
+// ---------------------------------------------------------------------------------
+// CSR baseline kernels (reference operator "cusparse-csr": arithmetic in closed-source
+// cuSPARSE; semantic model = csr_spmv_kernel, cg_solver_mgpu_partitioned.cu:40-56).
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void csr_row_scalar_kernel(SlabCsr m, const double* __restrict__ x,
+                                                                double* __restrict__ y, double alpha) {
+    const long long row = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (row >= m.n_local) return;
+    y[row] = alpha * row_reference<false>(m, x, (int)row, -1, 0);
+}
+
+// kLanes lanes cooperate on one row (kLanes = 64: one row per wavefront). Lanes stride the
+// row's entries, so consecutive lanes read consecutive col_idx/values: coalesced. The per-lane
+// partial sums are combined by a fixed shuffle tree, so the summation order differs from the
+// sequential loop (results agree to rounding; exact on the integer-valued benchmark inputs).
+template <int kLanes>
+__global__ __launch_bounds__(kBlock) void csr_subwave_kernel(SlabCsr m, const double* __restrict__ x,
+                                                             double* __restrict__ y, double alpha) {
+    const long long gid = (long long)blockIdx.x * kBlock + threadIdx.x;
+    const long long row = gid / kLanes;
+    const int sub = (int)(gid % kLanes);
+    const int lo = -m.halo_before, hi = m.n_local + m.halo_after;
+    double sum = 0.0;
+    if (row < m.n_local) {
+        const int k1 = m.row_ptr[row + 1];
+        for (int k = m.row_ptr[row] + sub; k < k1; k += kLanes)
+            sum = fma(m.values[k], x_at(x, (long long)m.col_idx[k] - m.row_offset, lo, hi), sum);
+    }
+#pragma unroll
+    for (int off = kLanes / 2; off > 0; off >>= 1) sum += __shfl_down(sum, off, kLanes);
+    if (sub == 0 && row < m.n_local) y[row] = alpha * sum;
+}
+
+// ---------------------------------------------------------------------------------
+// ELLPACK. Device layout is slot-major (element (r,k) at [k*rows + r]) so that one thread per
+// row reads every array with unit stride across lanes; padding slots carry index -1.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void ell_transpose_kernel(int rows, int width,
+                                                               const int* __restrict__ idx_rm,
+                                                               const double* __restrict__ val_rm,
+                                                               int* __restrict__ idx_sm,
+                                                               double* __restrict__ val_sm) {
+    const long long r = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (r >= rows) return;
+    for (int k = 0; k < width; ++k) {
+        idx_sm[(long long)k * rows + r] = idx_rm[r * (long long)width + k];
+        val_sm[(long long)k * rows + r] = val_rm[r * (long long)width + k];
+    }
+}
+
+__device__ __forceinline__ double ell_row_walk(int rows, int width, const int* __restrict__ idx,
+                                               const double* __restrict__ val,
+                                               const double* __restrict__ x, long long r) {
+    double sum = 0.0;
+    for (int k = 0; k < width; ++k) {
+        const int c = idx[(long long)k * rows + r];
+        if (c >= 0) sum = fma(val[(long long)k * rows + r], x[c], sum);
+    }
+    return sum;
+}
+
+__device__ __forceinline__ double ell_finish(double alpha, double beta, double sum, double y_old) {
+    return beta == 0.0 ? alpha * sum : fma(alpha, sum, beta * y_old);
+}
+
+__global__ __launch_bounds__(kBlock) void ell_spmv_kernel(int rows, int width, const int* __restrict__ idx,
+                                                          const double* __restrict__ val,
+                                                          const double* __restrict__ x,
+                                                          double* __restrict__ y, double alpha,
+                                                          double beta) {
+    const long long r = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (r >= rows) return;
+    const double sum = ell_row_walk(rows, width, idx, val, x, r);
+    y[r] = ell_finish(alpha, beta, sum, beta == 0.0 ? 0.0 : y[r]);
+}
+
+// Interior rows of a stencil stored as ELL: slots [N,W,C,E,S], columns computed, indices
+// never read (the contract of reference include/spmv_stencil.h:25-42).
+__global__ __launch_bounds__(kBlock) void ell_stencil5_kernel(int rows, int width, int n,
+                                                              const int* __restrict__ idx,
+                                                              const double* __restrict__ val,
+                                                              const double* __restrict__ x,
+                                                              double* __restrict__ y, double alpha,
+                                                              double beta) {
+    const long long r = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (r >= rows) return;
+    const int i = (int)(r / n), j = (int)(r - (long long)i * n);
+    double sum;
+    if (width >= 5 && stencil_is_interior(i, j, n)) {
+        const double* __restrict__ v = val + r;
+        const long long R = rows;
+        sum = v[1 * R] * x[r - 1];
+        sum = fma(v[2 * R], x[r], sum);
+        sum = fma(v[3 * R], x[r + 1], sum);
+        sum = fma(v[0], x[r - n], sum);
+        sum = fma(v[4 * R], x[r + n], sum);
+    } else {
+        sum = ell_row_walk(rows, width, idx, val, x, r);
+    }
+    y[r] = ell_finish(alpha, beta, sum, beta == 0.0 ? 0.0 : y[r]);
+}
+
+// ---------------------------------------------------------------------------------
+// Structure: generator and verifier of the complete 5-point pattern
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void generate_stencil5_kernel(int n, int row_offset, int n_local,
+                                                                   long long nnz_base, double center,
+                                                                   double off, int* __restrict__ row_ptr,
+                                                                   int* __restrict__ col_idx,
+                                                                   double* __restrict__ values) {
+    const long long lr = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (lr > n_local) return;
+    const long long g = (long long)row_offset + lr;
+    if (lr == n_local) {
+        row_ptr[lr] = (int)(stencil_row_start_flat(g, n) - nnz_base);
+        return;
+    }
+    const int i = (int)(g / n), j = (int)(g - (long long)i * n);
+    long long k = stencil_row_start(i, j, n) - nnz_base;
+    row_ptr[lr] = (int)k;
+    if (i > 0) col_idx[k] = (int)(g - n), values[k] = off, ++k;
+    if (j > 0) col_idx[k] = (int)(g - 1), values[k] = off, ++k;
+    col_idx[k] = (int)g, values[k] = center, ++k;
+    if (j < n - 1) col_idx[k] = (int)(g + 1), values[k] = off, ++k;
+    if (i < n - 1) col_idx[k] = (int)(g + n), values[k] = off, ++k;
+}
+
+__global__ __launch_bounds__(kBlock) void verify_stencil5_kernel(SlabCsr m, int* __restrict__ mismatch) {
+    const long long lr = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (lr >= m.n_local) return;
+    const int n = m.grid_size;
+    const long long g = (long long)m.row_offset + lr;
+    const int i = (int)(g / n), j = (int)(g - (long long)i * n);
+    const long long start = stencil_row_start(i, j, n) - m.nnz_base;
+    bool ok = m.row_ptr[lr] == start && m.row_ptr[lr + 1] - m.row_ptr[lr] == stencil_row_nnz(i, j, n);
+    if (ok) {
+        long long k = start;
+        if (i > 0) ok = ok && m.col_idx[k++] == g - n;
+        if (j > 0) ok = ok && m.col_idx[k++] == g - 1;
+        ok = ok && m.col_idx[k++] == g;
+        if (j < n - 1) ok = ok && m.col_idx[k++] == g + 1;
+        if (i < n - 1) ok = ok && m.col_idx[k++] == g + n;
+    }
+    if (!ok) *mismatch = 1;  // benign race: every writer stores the same value
+}
+
+inline unsigned blocks_for(long long items) { return (unsigned)((items + kBlock - 1) / kBlock); }
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+}  // namespace
+
+// ===================================================================================
+// launchers
+// ===================================================================================
+
+void launch_generate_stencil5_csr(int n, int row_offset, int n_local, long long nnz_base,
+                                  double center, double off, int* row_ptr, int* col_idx,
+                                  double* values, hipStream_t stream) {
+    hipLaunchKernelGGL(generate_stencil5_kernel, dim3(blocks_for((long long)n_local + 1)),
+                       dim3(kBlock), 0, stream, n, row_offset, n_local, nnz_base, center, off,
+                       row_ptr, col_idx, values);
+}
+
+void launch_verify_stencil5_csr(const SlabCsr& m, int* d_mismatch, hipStream_t stream) {
+    if (m.n_local == 0) return;
+    hipLaunchKernelGGL(verify_stencil5_kernel, dim3(blocks_for(m.n_local)), dim3(kBlock), 0, stream,
+                       m, d_mismatch);
+}
+
+static int wavetile_blocks(const LaunchShape& shape) {
+    int blocks = shape.compute_units * shape.blocks_per_cu;
+    blocks = (blocks + 7) & ~7;
+    return blocks < 8 ? 8 : blocks;
+}
+
+int launch_stencil5_waves(const LaunchShape& shape) { return wavetile_blocks(shape) * kWavesPerBlock; }
+
+void launch_stencil5_spmv(const SlabCsr& m, const double* x, double* y, double alpha,
+                          int first_row, int last_row, double* d_dot_partials,
+                          const int* d_skip_flag, Stencil5Variant variant,
+                          const LaunchShape& shape, hipStream_t stream) {
+    if (last_row <= first_row) return;
+    const int n = m.grid_size;
+    const bool tile_ok = m.verified_stencil && n >= kTileRows;
+    if (variant == Stencil5Variant::Auto)
+        variant = tile_ok ? Stencil5Variant::WaveTile : Stencil5Variant::RowGeneric;
+    if (variant == Stencil5Variant::WaveTile && !tile_ok) variant = Stencil5Variant::RowGeneric;
+
+    if (variant == Stencil5Variant::RowGeneric) {
+        const dim3 grid(blocks_for((long long)last_row - first_row));
+        if (m.verified_stencil && n >= 2)
+            hipLaunchKernelGGL(stencil5_row_kernel<true>, grid, dim3(kBlock), 0, stream, m, x, y,
+                               alpha, first_row, last_row, d_skip_flag);
+        else
+            hipLaunchKernelGGL(stencil5_row_kernel<false>, grid, dim3(kBlock), 0, stream, m, x, y,
+                               alpha, first_row, last_row, d_skip_flag);
+        return;
+    }
+
+    // Fixed grid (independent of the row range) so that the dot partials keep their shape.
+    const dim3 grid(wavetile_blocks(shape));
+    const bool vec_xy = aligned16(x) && aligned16(y);
+    const bool vec_ns = vec_xy && (n % 2 == 0);
+    const bool dot = d_dot_partials != nullptr;
+#define SPMV_AMD_LAUNCH_TILE(VXY, VNS, DOT)                                                       \
+    hipLaunchKernelGGL((stencil5_wavetile_kernel<VXY, VNS, DOT>), grid, dim3(kBlock), 0, stream, m, \
+                       x, y, alpha, first_row, last_row, d_dot_partials, d_skip_flag)
+    if (vec_ns) {
+        if (dot) SPMV_AMD_LAUNCH_TILE(true, true, true);
+        else SPMV_AMD_LAUNCH_TILE(true, true, false);
+    } else if (vec_xy) {
+        if (dot) SPMV_AMD_LAUNCH_TILE(true, false, true);
+        else SPMV_AMD_LAUNCH_TILE(true, false, false);
+    } else {
+        if (dot) SPMV_AMD_LAUNCH_TILE(false, false, true);
+        else SPMV_AMD_LAUNCH_TILE(false, false, false);
+    }
+#undef SPMV_AMD_LAUNCH_TILE
+}
+
+void launch_csr_spmv(const SlabCsr& m, const double* x, double* y, double alpha,
+                     CsrVariant variant, hipStream_t stream) {
+    if (m.n_local == 0) return;
+    if (variant == CsrVariant::Auto) {
+        const double avg = m.n_local > 0 ? (double)m.nnz_local / m.n_local : 0.0;
+        variant = avg <= 2.0   ? CsrVariant::RowScalar
+                  : avg <= 4.0 ? CsrVariant::SubWave4
+                  : avg <= 8.0 ? CsrVariant::SubWave8
+                  : avg <= 16.0 ? CsrVariant::SubWave16
+                  : avg <= 32.0 ? CsrVariant::SubWave32
+                                : CsrVariant::Wavefront;
+    }
+    const long long rows = m.n_local;
+    switch (variant) {
+        case CsrVariant::RowScalar:
+            hipLaunchKernelGGL(csr_row_scalar_kernel, dim3(blocks_for(rows)), dim3(kBlock), 0, stream,
+                               m, x, y, alpha);
+            break;
+#define SPMV_AMD_SUBWAVE(L)                                                                        \
+    hipLaunchKernelGGL(csr_subwave_kernel<L>, dim3(blocks_for(rows * L)), dim3(kBlock), 0, stream, m, \
+                       x, y, alpha)
+        case CsrVariant::SubWave4: SPMV_AMD_SUBWAVE(4); break;
+        case CsrVariant::SubWave8: SPMV_AMD_SUBWAVE(8); break;
+        case CsrVariant::SubWave16: SPMV_AMD_SUBWAVE(16); break;
+        case CsrVariant::SubWave32: SPMV_AMD_SUBWAVE(32); break;
+        default: SPMV_AMD_SUBWAVE(64); break;
+#undef SPMV_AMD_SUBWAVE
+    }
+}
+
+void launch_ell_transpose(int rows, int width, const int* idx_rowmajor, const double* val_rowmajor,
+                          int* idx_slotmajor, double* val_slotmajor, hipStream_t stream) {
+    if (rows == 0) return;
+    hipLaunchKernelGGL(ell_transpose_kernel, dim3(blocks_for(rows)), dim3(kBlock), 0, stream, rows,
+                       width, idx_rowmajor, val_rowmajor, idx_slotmajor, val_slotmajor);
+}
+
+void launch_ell_spmv(int rows, int width, const int* idx, const double* val, const double* x,
+                     double* y, double alpha, double beta, hipStream_t stream) {
+    if (rows == 0) return;
+    hipLaunchKernelGGL(ell_spmv_kernel, dim3(blocks_for(rows)), dim3(kBlock), 0, stream, rows, width,
+                       idx, val, x, y, alpha, beta);
+}
+
+void launch_ell_stencil5_spmv(int rows, int width, int grid_size, const int* idx,
+                              const double* val, const double* x, double* y, double alpha,
+                              double beta, hipStream_t stream) {
+    if (rows == 0) return;
+    if (grid_size < 3 || (long long)grid_size * grid_size != rows) {
+        launch_ell_spmv(rows, width, idx, val, x, y, alpha, beta, stream);
+        return;
+    }
+    hipLaunchKernelGGL(ell_stencil5_kernel, dim3(blocks_for(rows)), dim3(kBlock), 0, stream, rows,
+                       width, grid_size, idx, val, x, y, alpha, beta);
+}
+
+}  // namespace spmv_amd

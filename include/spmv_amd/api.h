@@ -212,11 +212,13 @@ typedef int (*SpmvAmdHostGatherFn)(void* user, const double* send, int n_send, d
                                    const int* counts, const int* displs);
 typedef int (*SpmvAmdHostBarrierFn)(void* user);
 
-/* 128-byte RCCL unique id, to be produced on rank 0 and handed to every rank. */
-int spmv_amd_comm_unique_id(void* out_id128);
+/* 256-byte blob (two RCCL unique ids: one communicator for the halo send/recv, one for
+ * the all-reduces), to be produced on rank 0 and handed to every rank. */
+#define SPMV_AMD_COMM_ID_BYTES 256
+int spmv_amd_comm_unique_id(void* out_id256);
 /* One process per GPU: RCCL communicator over xGMI; halo rows travel by
  * ncclSend/ncclRecv on a side stream, dot products by ncclAllReduce. */
-SpmvAmdComm* spmv_amd_comm_create_rccl(int rank, int world, const void* id128);
+SpmvAmdComm* spmv_amd_comm_create_rccl(int rank, int world, const void* id256);
 SpmvAmdComm* spmv_amd_comm_create_staged(int rank, int world, SpmvAmdHostHaloFn halo,
                                          SpmvAmdHostAllreduceFn allreduce,
                                          SpmvAmdHostGatherFn gather, SpmvAmdHostBarrierFn barrier,
@@ -251,6 +253,11 @@ void spmv_amd_cg_slab_info(const SpmvAmdCgSlab* s, int* row_offset, int* n_local
  * slab SpMV kernel pair on the current direction vector. */
 int spmv_amd_cg_slab_time_spmv(SpmvAmdCgSlab* s, int reps, float* ms_each);
 void spmv_amd_cg_slab_destroy(SpmvAmdCgSlab* s);
+
+/* write_matrix_market_stencil5 with other value texts (e.g. "-4.0", "-1.0": the convention
+ * of the shipped matrix/example81x81.mtx); used to regenerate test fixtures. */
+int spmv_amd_write_stencil5_values(int n, const char* filename, const char* center_text,
+                                   const char* off_text);
 
 /* Library build string ("libspmv_amd <date> gfx950 ..."). */
 const char* spmv_amd_version(void);

@@ -1,0 +1,173 @@
+"""One rank of a multi-process test; started by tests/test_distributed.py with RANK / WORLD_SIZE /
+MASTER_ADDR / MASTER_PORT set, rendezvous over gloo on 127.0.0.1.
+
+  mode oracle : (CPU) the partitioned CG algorithm with the ORACLE's per-rank kernels and real
+                gloo messages (halo rows by send/recv, dots by all_reduce); rank 0 checks the
+                residual history against the serial oracle.
+  mode gpu    : (GPU) libspmv_amd's slab solver, one rank per process sharing the box's single
+                GPU, over the staged communicator whose host callbacks are these gloo calls;
+                rank 0 checks against the oracle's partitioned CG.
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from oracle import oracle as O  # noqa: E402
+from conftest import load_binding, rel_err  # noqa: E402
+
+
+def exchange_halo(rank, world, first_row, last_row):
+    """Sends this rank's first grid row to rank-1 and last grid row to rank+1; returns (prev, next)."""
+    prev = torch.zeros_like(first_row) if rank > 0 else None
+    nxt = torch.zeros_like(last_row) if rank < world - 1 else None
+    reqs = []
+    if rank > 0:
+        reqs += [dist.isend(first_row, rank - 1), dist.irecv(prev, rank - 1)]
+    if rank < world - 1:
+        reqs += [dist.isend(last_row, rank + 1), dist.irecv(nxt, rank + 1)]
+    for r in reqs:
+        r.wait()
+    return prev, nxt
+
+
+def allreduce(v):
+    t = torch.tensor([v], dtype=torch.float64)
+    dist.all_reduce(t)
+    return float(t[0])
+
+
+def run_oracle(n, rank, world):
+    rp, ci, va = O.stencil5_csr(n)
+    N = n * n
+    off, nl = O.partition_rows(N, world, rank)
+    base = rp[off]
+    lrp = (rp[off:off + nl + 1] - base).astype(np.int32)
+    lci, lva = ci[base:rp[off + nl]], va[base:rp[off + nl]]
+    x, b = np.zeros(nl), np.ones(nl)
+
+    def spmv(v):
+        t = torch.from_numpy(v)
+        hp, hn = exchange_halo(rank, world, t[:n].clone(), t[nl - n:].clone())
+        return O.spmv_halo(lrp, lci, lva, v, None if hp is None else hp.numpy(), None if hn is None else hn.numpy(), off, N, n)
+
+    r = b - spmv(x)
+    p = r.copy()
+    rs_old = allreduce(O.dot_host(r, r))
+    b_norm = np.sqrt(rs_old)
+    hist = [b_norm]
+    for it in range(1000):
+        Ap = spmv(p)
+        alpha = rs_old / allreduce(O.dot_host(p, Ap))
+        x = x + alpha * p
+        r = r - alpha * Ap
+        rs_new = allreduce(O.dot_host(r, r))
+        hist.append(np.sqrt(rs_new))
+        if np.sqrt(rs_new) / b_norm < 1e-6:
+            break
+        p = r + (rs_new / rs_old) * p
+        rs_old = rs_new
+    if rank == 0:
+        xs, hs, rs = O.cg_partitioned(rp, ci, va, n, np.ones(N), np.zeros(N), world=world)
+        assert len(hist) == len(hs) and rel_err(hist, hs) < 1e-12, (len(hist), len(hs))
+        xd, hd, rd = O.cg(rp, ci, va, n, np.ones(N), np.zeros(N))
+        assert rd.iterations == len(hist) - 1 and rel_err(hist, hd) < 1e-12
+    print(f"rank {rank}: oracle distributed CG ok ({len(hist) - 1} iterations)")
+
+
+def run_gpu(n, rank, world, synthetic):
+    B = load_binding()
+    B.lib()
+
+    def halo_cb(user, sp, sn, rp_, rn_, count):
+        first = torch.from_numpy(np.ctypeslib.as_array(sp, shape=(count,)).copy()) if sp else None
+        last = torch.from_numpy(np.ctypeslib.as_array(sn, shape=(count,)).copy()) if sn else None
+        prev, nxt = exchange_halo(rank, world, first, last)
+        if prev is not None:
+            np.ctypeslib.as_array(rp_, shape=(count,))[:] = prev.numpy()
+        if nxt is not None:
+            np.ctypeslib.as_array(rn_, shape=(count,))[:] = nxt.numpy()
+        return 0
+
+    def allreduce_cb(user, buf, count):
+        a = np.ctypeslib.as_array(buf, shape=(count,))
+        t = torch.from_numpy(a.copy())
+        dist.all_reduce(t)
+        a[:] = t.numpy()
+        return 0
+
+    def gather_cb(user, send, n_send, recv, counts, displs):
+        mine = torch.from_numpy(np.ctypeslib.as_array(send, shape=(n_send,)).copy())
+        if rank == 0:
+            out = np.ctypeslib.as_array(recv, shape=(sum(counts[r] for r in range(world)),))
+            out[displs[0]:displs[0] + counts[0]] = mine.numpy()
+            for r in range(1, world):
+                t = torch.zeros(counts[r], dtype=torch.float64)
+                dist.recv(t, r)
+                out[displs[r]:displs[r] + counts[r]] = t.numpy()
+        else:
+            dist.send(mine, 0)
+        return 0
+
+    def barrier_cb(user):
+        dist.barrier()
+        return 0
+
+    comm = B.Comm.staged(rank, world, halo_cb, allreduce_cb, gather_cb, barrier_cb)
+    N = n * n
+    if synthetic:
+        slab = B.CgSlab.stencil5(n, comm)
+    else:
+        m = B.HostMatrix(O.stencil5_coo(n), N, N, n)
+        slab = B.CgSlab.from_matrix(m, comm)
+        slab.set_vectors(np.ones(N), np.zeros(N))
+    assert (slab.row_offset, slab.n_local) == O.partition_rows(N, world, rank)
+    for timers in (0, 1):
+        st = slab.solve(timers=timers)
+        hist = slab.history()
+        x = slab.gather()
+        if rank == 0:
+            rp, ci, va = O.stencil5_csr(n)
+            xo, ho, ro = O.cg_partitioned(rp, ci, va, n, np.ones(N), np.zeros(N), world=world)
+            assert st.iterations == ro.iterations and st.converged == 1, (st.iterations, ro.iterations)
+            assert rel_err(hist, ho) < 1e-10
+            assert np.max(np.abs(x - xo)) <= 1e-10 * np.max(np.abs(xo))
+    # the reference entry point over the world communicator
+    if not synthetic:
+        B.lib().spmv_amd_comm_set_world(comm.handle)
+        b, x = np.ones(N), np.zeros(N)
+        cfg, st = B.CGConfig(1000, 1e-6, 0, 0), B.CGStatsMultiGPU()
+        assert B.lib().spmv_amd_cg_solve_mgpu_partitioned(m.ptr, b.ctypes.data, x.ctypes.data, C.byref(cfg), C.byref(st)) == 0
+        if rank == 0:
+            assert np.max(np.abs(x - xo)) <= 1e-10 * np.max(np.abs(xo)) and st.solution_norm > 0
+        B.lib().spmv_amd_comm_set_world(None)
+    slab.destroy()
+    comm.destroy()
+    print(f"rank {rank}: slab solver over staged/gloo communicator ok")
+
+
+def main():
+    mode, n = sys.argv[1], int(sys.argv[2])
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        if mode == "oracle":
+            run_oracle(n, rank, world)
+        elif mode == "gpu":
+            run_gpu(n, rank, world, synthetic=False)
+        elif mode == "gpu-synthetic":
+            run_gpu(n, rank, world, synthetic=True)
+        else:
+            raise SystemExit(f"unknown mode {mode}")
+    finally:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

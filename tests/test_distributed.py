@@ -1,0 +1,71 @@
+"""World-size > 1 paths. CPU: the partitioned algorithm over real gloo messages (oracle kernels).
+GPU: libspmv_amd's slab solver with 2 and 3 ranks sharing the box's GPU over the staged/gloo
+communicator, and the RCCL communicator with one rank (a 1-GPU box cannot host two RCCL ranks)."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, rel_err
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch(world, mode, n, timeout=600):
+    port = free_port()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), mode, str(n)],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(out)
+    for rank, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {rank} failed:\n{out}"
+    return outs
+
+
+@pytest.mark.parametrize("world,n", [(2, 64), (2, 130), (4, 64)])
+def test_partitioned_cg_over_gloo_cpu(world, n):
+    outs = launch(world, "oracle", n)
+    assert all("oracle distributed CG ok" in o for o in outs)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,n,mode", [(2, 64, "gpu"), (2, 256, "gpu"), (3, 192, "gpu-synthetic"), (2, 512, "gpu-synthetic")])
+def test_slab_solver_multi_rank_one_gpu(world, n, mode):
+    outs = launch(world, mode, n)
+    assert all("slab solver over staged/gloo communicator ok" in o for o in outs)
+
+
+@pytest.mark.gpu
+def test_rccl_communicator_single_rank(B, O, fresh_host_matrices):
+    uid = B.Comm.unique_id()
+    assert len(uid) == B.COMM_ID_BYTES and any(uid)
+    comm = B.Comm.rccl(0, 1, uid)
+    assert B.lib().spmv_amd_comm_rank(comm.handle) == 0 and B.lib().spmv_amd_comm_size(comm.handle) == 1
+    n = 200
+    slab = B.CgSlab.stencil5(n, comm)
+    st = slab.solve()
+    rp, ci, va = O.stencil5_csr(n)
+    xo, ho, ro = O.cg_partitioned(rp, ci, va, n, np.ones(n * n), np.zeros(n * n), world=1)
+    assert st.iterations == ro.iterations and rel_err(slab.history(), ho) < 1e-10
+    slab.destroy()
+    comm.destroy()

@@ -1,0 +1,142 @@
+"""The oracle against every known answer the reference holds for this path:
+reference-test checksums, the shipped 81x81 data file, published iteration counts, and the
+committed golden vectors. CPU only."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, rel_err
+import matrices as M
+
+
+def test_reference_test_checksums(O):
+    # tests/test_wrapper_basic.cpp:115-121 : 3x3, centre -4 / off -1, x = 1 -> sum(y) = -60, nnz 33
+    e = O.stencil5_coo(3, -4.0, -1.0)
+    assert len(e) == 33
+    rp, ci, va = O.build_csr(e, 9)
+    assert O.spmv_csr(rp, ci, va, np.ones(9)).sum() == -60.0
+    # tests/helpers/matrix_fixtures.cpp:38,57,84,108 : 3 / 15 / 2 / 21
+    for make in (M.identity, M.diagonal, M.tridiagonal, M.upper_triangular):
+        ent, rows, cols, expect = make()
+        rp, ci, va = O.build_csr(ent, rows)
+        assert O.spmv_csr(rp, ci, va, np.ones(cols)).sum() == expect
+
+
+def test_stencil_equals_csr_elementwise(O):
+    # tests/test_wrapper_basic.cpp:184-189 : stencil vs CSR element-wise <= 1e-12
+    rng = np.random.default_rng(0)
+    for n in (3, 4, 5, 17, 81):
+        e = O.stencil5_coo(n)
+        e["value"] = rng.uniform(-3, 3, len(e))
+        rp, ci, va = O.build_csr(e, n * n)
+        x = rng.standard_normal(n * n)
+        y_csr = O.spmv_csr(rp, ci, va, x)
+        y_st = O.spmv_stencil5(rp, ci, va, x, n)
+        assert rel_err(y_st, y_csr) <= 1e-12
+        # no stencil announced: every row takes the CSR loop, bit for bit
+        assert np.array_equal(O.spmv_stencil5(rp, ci, va, x, -1), y_csr)
+
+
+def test_shipped_81x81_file(O, golden):
+    path = os.path.join(GOLDEN, "example81x81.mtx")
+    lines = open(path).read().split("\n")
+    assert lines[1] == "% STENCIL_GRID_SIZE 81" and lines[2] == "6561 6561 32481"
+    body = np.loadtxt(path, skiprows=3)
+    e = np.zeros(len(body), dtype=O.ENTRY_DTYPE)
+    e["row"], e["col"], e["value"] = body[:, 0] - 1, body[:, 1] - 1, body[:, 2]
+    assert np.array_equal(e, O.stencil5_coo(81, -4.0, -1.0))
+    rp, ci, va = O.build_csr(e, 6561)
+    y = O.spmv_csr(rp, ci, va, np.ones(6561))
+    s = golden["survey_8c"]["81:-4.0"]
+    assert y.sum() == s["sum_y"] == -52164.0
+    assert abs(np.sqrt((y * y).sum()) - s["norm2_y"]) <= 1e-12 * s["norm2_y"]
+    assert list(rp[:6]) == [0, 3, 7, 11, 15, 19]
+    assert list(ci[rp[82]:rp[83]]) == [1, 81, 82, 83, 163] and rp[82] == 326 == O.interior_csr_offset(82, 81)
+    x, hist, res = O.cg(rp, ci, va, 81, np.ones(6561), np.zeros(6561))
+    assert res.iterations == s["cg_iterations"] == 40 and res.converged == 1
+    assert abs(res.solution_sum - s["solution_sum"]) <= 1e-12 * abs(s["solution_sum"])
+    assert abs(res.solution_norm - s["solution_norm"]) <= 1e-12 * s["solution_norm"]
+
+
+@pytest.mark.parametrize("n", [3, 81, 512, 2000])
+def test_generator_stencil_known_answers(O, golden, n):
+    rp, ci, va = O.stencil5_csr(n)
+    y = O.spmv_stencil5(rp, ci, va, np.ones(n * n), n)
+    assert y.sum() == n * n + 4 * n  # interior 1, edge 2, corner 3
+    if n >= 3:
+        assert (y * y).sum() == (n - 2) ** 2 + 16 * (n - 2) + 36
+    g = golden["cases"][f"{n}:5.0"]
+    assert y.sum() == g["sum_y"] and np.sqrt((y * y).sum()) == g["norm2_y"]
+    x, hist, res = O.cg(rp, ci, va, n, np.ones(n * n), np.zeros(n * n))
+    assert res.iterations == g["cg"]["iterations"] and np.array_equal(hist, np.array(g["cg"]["history"]))
+    survey = golden["survey_8c"].get(f"{n}:5.0")
+    if survey:
+        assert res.iterations == survey["cg_iterations"]
+
+
+def test_published_fourteen_iterations_history(golden):
+    """n = 10^4: the oracle's committed history vs the independent SURVEY values (10 digits)
+    and the published '14 iterations' (README.md:62). The 60 s run itself lives in make_golden.py."""
+    g = golden["cases"].get("10000:5.0")
+    if g is None:
+        pytest.skip("10k golden not generated yet (tests/golden/make_golden.py --with-10k)")
+    s = golden["survey_8c"]["10000:5.0"]
+    assert g["cg"]["iterations"] == s["cg_iterations"] == 14
+    assert rel_err(g["cg"]["history"], s["history"]) < 5e-10
+    assert abs(g["cg"]["solution_sum"] - s["solution_sum"]) < 1e-10 * s["solution_sum"]
+    assert abs(g["cg"]["solution_norm"] - s["solution_norm"]) < 1e-10 * s["solution_norm"]
+
+
+def test_cg_forms_agree(O):
+    """cg_solve (host scalars), cg_solve_device and the partitioned solver differ only in
+    reduction shape / one fused op: histories agree far inside the 1e-10 bar."""
+    for n, worlds in ((81, (1, 3)), (64, (1, 2, 4)), (256, (8,))):
+        rp, ci, va = O.stencil5_csr(n)
+        b, x0 = np.ones(n * n), np.zeros(n * n)
+        xd, hd, rd = O.cg(rp, ci, va, n, b, x0, device_form=True)
+        xh, hh, rh = O.cg(rp, ci, va, n, b, x0, device_form=False)
+        assert rd.iterations == rh.iterations and rel_err(hh, hd) < 1e-12
+        for w in worlds:
+            xp, hp, rpart = O.cg_partitioned(rp, ci, va, n, b, x0, world=w)
+            assert rpart.iterations == rd.iterations and rel_err(hp, hd) < 1e-12
+            assert np.max(np.abs(xp - xd)) < 1e-13
+
+
+def test_partition_outside_reference_domain_is_flagged(O):
+    rp, ci, va = O.stencil5_csr(81)
+    res = O.CGResult()
+    import ctypes as C
+    x = np.zeros(6561)
+    b = np.ones(6561)
+    rc = O.lib().oracle_cg_partitioned(6561, rp.ctypes.data_as(C.POINTER(C.c_int)), ci.ctypes.data_as(C.POINTER(C.c_int)),
+                                       va.ctypes.data_as(C.POINTER(C.c_double)), 81, b.ctypes.data_as(C.POINTER(C.c_double)),
+                                       x.ctypes.data_as(C.POINTER(C.c_double)), 10, C.c_double(1e-6), 2, None, 0, C.byref(res))
+    assert rc == 3  # 6561 / 2 rows is not a whole number of grid rows: reference reads out of bounds
+
+
+def test_ell_equals_csr(O):
+    for n in (3, 10, 81):
+        rp, ci, va = O.stencil5_csr(n)
+        w, idx, val = O.build_ell(rp, ci, va)
+        assert w == 5 and (idx == -1).sum() == 5 * n * n - rp[-1]
+        x = np.random.default_rng(n).standard_normal(n * n)
+        assert np.array_equal(O.spmv_ell(n * n, w, idx, val, x), O.spmv_csr(rp, ci, va, x))
+    ent, rows, cols = M.unbalanced()
+    rp, ci, va = O.build_csr(ent, rows)
+    w, idx, val = O.build_ell(rp, ci, va)
+    x = np.random.default_rng(1).standard_normal(cols)
+    y0 = np.random.default_rng(2).standard_normal(rows)
+    assert np.array_equal(O.spmv_ell(rows, w, idx, val, x), O.spmv_csr(rp, ci, va, x))
+    got = O.spmv_ell(rows, w, idx, val, x, y0=y0, alpha=2.0, beta=-0.5)
+    assert rel_err(got, 2.0 * O.spmv_csr(rp, ci, va, x) - 0.5 * y0) < 1e-12
+
+
+def test_integer_formulas(O):
+    for n in (3, 4, 81, 1000, 20000):
+        for (i, j) in ((1, 1), (1, n - 2), (n - 2, 1), (n - 2, n - 2), (n // 2, n // 3 + 1)):
+            got = O.interior_csr_offset(i * n + j, n)
+            assert got == (4 * n - 2) + (i - 1) * (5 * n - 2) + 5 * j - 1
+    assert O.interior_csr_offset(19998 * 20000 + 19998, 20000) == 1999839993  # SURVEY 8 a1 maximum
+    assert O.partition_rows(400000000, 8, 3) == (150000000, 50000000)
+    assert O.partition_rows(10, 3, 2) == (6, 4)

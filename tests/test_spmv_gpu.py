@@ -1,0 +1,195 @@
+"""Parity of the HIP SpMV operators with the CPU oracle, through the C-ABI (get_operator ->
+init / run_timed / run_device / free). Bit-exact wherever the summation order is defined by the
+reference (stencil5-csr, ELLPACK, CSR row-scalar), <= 1e-12 relative for the sub-wavefront CSR
+kernels whose shuffle tree re-orders the sum (cuSPARSE's own order is unpinned)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, rel_err
+import matrices as M
+
+pytestmark = pytest.mark.gpu
+
+STENCIL_SIZES = [2, 3, 5, 81, 127, 128, 129, 200, 257, 300, 513]
+
+
+def random_stencil(O, n, seed):
+    rng = np.random.default_rng(seed)
+    e = O.stencil5_coo(n)
+    e["value"] = rng.uniform(-3.0, 3.0, len(e))
+    return e, rng.standard_normal(n * n)
+
+
+@pytest.mark.parametrize("n", STENCIL_SIZES)
+def test_stencil5_csr_bit_exact_random_values(B, O, fresh_host_matrices, n):
+    e, x = random_stencil(O, n, n)
+    m = B.HostMatrix(e, n * n, n * n, n)
+    op = B.Operator("stencil5-csr")
+    assert op.init(m) == 0
+    expect_variant = "stencil5/wave-tile" if n >= 128 else "stencil5/row-generic"
+    assert op.variant() == expect_variant
+    rp, ci, va = O.build_csr(e, n * n)
+    want = O.spmv_stencil5(rp, ci, va, x, n)
+    got, ms = op.run_timed(x)
+    assert ms > 0 and np.array_equal(got, want)
+    # device-native entry point, including x/y at odd (8-byte aligned) addresses -> scalar-load variant
+    dx, dy = B.DeviceVector.from_host(np.concatenate([[0.0], x])), B.DeviceVector(n * n + 1, fill=-7.0)
+    class Shift:  # view one double into the allocation
+        def __init__(self, v): self.ptr = v.ptr + 8
+    assert op.run_device(Shift(dx), Shift(dy)) == 0
+    assert np.array_equal(dy.to_host()[1:], want)
+    # the same matrix forced through the thread-per-row variant
+    op.select_variant("row-generic")
+    got2, _ = op.run_timed(x)
+    op.select_variant(None)
+    assert np.array_equal(got2, want)
+    dx.free(), dy.free(), op.free()
+
+
+def test_stencil5_csr_shipped_81_and_generator_checksums(B, O, golden, fresh_host_matrices):
+    m = B.load_matrix_market(os.path.join(GOLDEN, "example81x81.mtx"))
+    op = B.Operator("stencil5-csr")
+    assert op.init(m) == 0
+    y, _ = op.run_timed(np.ones(6561))
+    assert y.sum() == -52164.0 and abs(np.sqrt((y * y).sum()) - golden["survey_8c"]["81:-4.0"]["norm2_y"]) < 1e-9
+    op.free()
+    for n in (3, 81, 512):
+        B.lib().spmv_amd_reset_host_matrices()
+        m = B.HostMatrix(O.stencil5_coo(n), n * n, n * n, n)
+        assert op.init(m) == 0
+        y, _ = op.run_timed(np.ones(n * n))
+        g = golden["cases"][f"{n}:5.0"]
+        assert y.sum() == g["sum_y"] == n * n + 4 * n and np.sqrt((y * y).sum()) == g["norm2_y"]
+        op.free()
+
+
+def test_stencil5_csr_non_stencil_inputs_take_the_csr_loop(B, O, fresh_host_matrices):
+    """grid_size = -1 (no comment in the file), or a grid_size that does not describe the
+    structure: every row goes through the CSR loop, results equal plain CSR SpMV bit for bit."""
+    cases = []
+    for make in (M.identity, M.diagonal, M.tridiagonal, M.upper_triangular):
+        e, r, c, expect = make()
+        cases.append((e, r, c, -1, expect))
+    e, r, c = M.random_sparse(500, 400, 7, seed=21)
+    cases.append((e, r, c, -1, None))
+    e, r, c = M.unbalanced()
+    cases.append((e, r, c, -1, None))
+    e, r, c = M.random_sparse(400, 400, 5, seed=22)
+    cases.append((e, r, c, 20, None))  # claims to be a 20x20 stencil but is not
+    op = B.Operator("stencil5-csr")
+    for e, r, c, grid, expect in cases:
+        B.lib().spmv_amd_reset_host_matrices()
+        m = B.HostMatrix(e, r, c, grid)
+        assert op.init(m) == 0
+        assert "csr-loop" in op.variant()
+        x = np.ones(c) if expect is not None else np.random.default_rng(r).standard_normal(c)
+        rp, ci, va = O.build_csr(e, r)
+        got, _ = op.run_timed(x)
+        assert np.array_equal(got, O.spmv_csr(rp, ci, va, x))
+        if expect is not None:
+            assert got.sum() == expect
+        op.free()
+
+
+@pytest.mark.parametrize("variant", [None, "row-scalar", "subwave4", "subwave8", "subwave16", "subwave32", "wavefront"])
+def test_csr_operator(B, O, fresh_host_matrices, variant):
+    op = B.Operator("cusparse-csr")
+    op.select_variant(variant)
+    mats = []
+    e, x = random_stencil(O, 130, 5)
+    mats.append((e, 130 * 130, 130 * 130, 130, x))
+    e, r, c = M.unbalanced()
+    mats.append((e, r, c, -1, np.random.default_rng(3).standard_normal(c)))
+    e, r, c = M.random_sparse(1000, 777, 33, seed=9)
+    mats.append((e, r, c, -1, np.random.default_rng(4).standard_normal(c)))
+    for e, r, c, grid, x in mats:
+        B.lib().spmv_amd_reset_host_matrices()
+        m = B.HostMatrix(e, r, c, grid)
+        assert op.init(m) == 0
+        rp, ci, va = O.build_csr(e, r)
+        want = O.spmv_csr(rp, ci, va, x)
+        got, ms = op.run_timed(x)
+        if variant == "row-scalar":
+            assert np.array_equal(got, want)
+        else:
+            scale = np.maximum(np.abs(want), O.spmv_csr(rp, ci, np.abs(va), np.abs(x)))
+            assert np.max(np.abs(got - want) / np.maximum(scale, 1e-300)) <= 1e-12
+        # integer-valued data: exact under any summation order
+        xi = np.ones(c)
+        ei = e.copy()
+        ei["value"] = np.round(e["value"])
+        B.lib().spmv_amd_reset_host_matrices()
+        mi = B.HostMatrix(ei, r, c, grid)
+        assert op.init(mi) == 0
+        rpi, cii, vai = O.build_csr(ei, r)
+        goti, _ = op.run_timed(xi)
+        assert np.array_equal(goti, O.spmv_csr(rpi, cii, vai, xi))
+        op.free()
+    op.select_variant(None)
+
+
+@pytest.mark.parametrize("name", ["ellpack", "stencil5-ellpack"])
+def test_ellpack_operators_bit_exact(B, O, fresh_host_matrices, name):
+    op = B.Operator(name)
+    for n in (3, 5, 81, 130, 257):
+        B.lib().spmv_amd_reset_host_matrices()
+        e, x = random_stencil(O, n, 100 + n)
+        m = B.HostMatrix(e, n * n, n * n, n)
+        assert op.init(m) == 0
+        rp, ci, va = O.build_csr(e, n * n)
+        w, idx, val = O.build_ell(rp, ci, va)
+        want_ell = O.spmv_ell(n * n, w, idx, val, x)
+        got, _ = op.run_timed(x)
+        if name == "stencil5-ellpack":
+            assert op.variant() == "ell/stencil5-direct"
+            # interior rows use the stencil order W,C,E,N,S: compare with the stencil oracle
+            assert np.array_equal(got, O.spmv_stencil5(rp, ci, va, x, n))
+        else:
+            assert np.array_equal(got, want_ell) and np.array_equal(want_ell, O.spmv_csr(rp, ci, va, x))
+        op.free()
+    # generic, ragged rows with padding
+    B.lib().spmv_amd_reset_host_matrices()
+    e, r, c = M.unbalanced()
+    m = B.HostMatrix(e, r, c)
+    assert op.init(m) == 0 and op.variant() == "ell/slot-major"
+    x = np.random.default_rng(8).standard_normal(c)
+    rp, ci, va = O.build_csr(e, r)
+    got, _ = op.run_timed(x)
+    assert np.array_equal(got, O.spmv_csr(rp, ci, va, x))
+    op.free()
+
+
+@pytest.mark.parametrize("n", [2, 3, 81, 128, 300])
+def test_synthetic_device_csr_equals_host_built_csr(B, O, fresh_host_matrices, n):
+    """The in-HBM generator must produce the bytes load + build_csr_struct + upload produce."""
+    op = B.Operator("stencil5-csr")
+    assert op.init_synthetic(n) == 0
+    orp, oci, ova = O.build_csr(O.stencil5_coo(n), n * n)
+    rp, ci, va = op.download_csr(n * n, len(oci))
+    assert np.array_equal(rp, orp) and np.array_equal(ci, oci) and np.array_equal(va, ova)
+    x = np.random.default_rng(n).standard_normal(n * n)
+    got, _ = op.run_timed(x)
+    assert np.array_equal(got, O.spmv_stencil5(orp, oci, ova, x, n))
+    cm = B.csr_mat()
+    assert (cm.nb_rows, cm.nb_nonzeros) == (n * n, len(oci))
+    op.free()
+    for other in ("cusparse-csr", "ellpack", "stencil5-ellpack"):
+        o2 = B.Operator(other)
+        assert o2.init_synthetic(n) == 0
+        got, _ = o2.run_timed(np.ones(n * n))
+        assert np.array_equal(got, O.spmv_csr(orp, oci, ova, np.ones(n * n)))
+        o2.free()
+
+
+def test_run_device_leaves_no_sync_and_time_helper(B, O, fresh_host_matrices):
+    n = 512
+    op = B.Operator("stencil5-csr")
+    assert op.init_synthetic(n) == 0
+    dx, dy = B.DeviceVector(n * n, fill=1.0), B.DeviceVector(n * n, fill=0.0)
+    ms = op.time_device(dx, dy, 5)
+    assert len(ms) == 5 and (ms > 0).all()
+    y = dy.to_host()
+    assert y.sum() == n * n + 4 * n
+    dx.free(), dy.free(), op.free()
