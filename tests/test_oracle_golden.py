@@ -84,8 +84,11 @@ def test_published_fourteen_iterations_history(golden):
     s = golden["survey_8c"]["10000:5.0"]
     assert g["cg"]["iterations"] == s["cg_iterations"] == 14
     assert rel_err(g["cg"]["history"], s["history"]) < 5e-10
-    assert abs(g["cg"]["solution_sum"] - s["solution_sum"]) < 1e-10 * s["solution_sum"]
-    assert abs(g["cg"]["solution_norm"] - s["solution_norm"]) < 1e-10 * s["solution_norm"]
+    # The checksums are the reference's plain left-to-right host loops over 10^8 nearly equal terms
+    # (cg_solver.cu:336-342); their rounding error grows linearly (~1e-9 relative here), while the
+    # SURVEY values came from numpy's pairwise sums. Same x, different summation: compare loosely.
+    assert abs(g["cg"]["solution_sum"] - s["solution_sum"]) < 2e-9 * s["solution_sum"]
+    assert abs(g["cg"]["solution_norm"] - s["solution_norm"]) < 2e-9 * s["solution_norm"]
 
 
 def test_cg_forms_agree(O):
