@@ -61,3 +61,12 @@ def rel_err(a, b):
     a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
     den = np.maximum(np.abs(b), 1e-300)
     return float(np.max(np.abs(a - b) / den)) if len(a) else 0.0
+
+
+def hist_err(hist, ref):
+    """Relative error of a residual history. Entries that have fallen to rounding noise (below
+    1e-12 * ||r0||: exact convergence on tiny grids) are measured against that floor instead of
+    against themselves, where 'relative' would compare noise with noise."""
+    hist, ref = np.asarray(hist, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+    den = np.maximum(np.abs(ref), 1e-12 * abs(ref[0]))
+    return float(np.max(np.abs(hist - ref) / den))

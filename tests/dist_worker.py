@@ -20,7 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from oracle import oracle as O  # noqa: E402
-from conftest import load_binding, rel_err  # noqa: E402
+from conftest import load_binding, rel_err, hist_err  # noqa: E402
 
 
 def exchange_halo(rank, world, first_row, last_row):
@@ -136,7 +136,7 @@ def run_gpu(n, rank, world, synthetic):
             rp, ci, va = O.stencil5_csr(n)
             xo, ho, ro = O.cg_partitioned(rp, ci, va, n, np.ones(N), np.zeros(N), world=world)
             assert st.iterations == ro.iterations and st.converged == 1, (st.iterations, ro.iterations)
-            assert rel_err(hist, ho) < 1e-10
+            assert hist_err(hist, ho) < 1e-10
             assert np.max(np.abs(x - xo)) <= 1e-10 * np.max(np.abs(xo))
     # the reference entry point over the world communicator
     if not synthetic:
