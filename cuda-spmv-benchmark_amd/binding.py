@@ -86,7 +86,7 @@ DECLARED_SYMBOLS = [
     "spmv_amd_copy_to_device", "spmv_amd_copy_to_host", "spmv_amd_device_fill_f64", "spmv_amd_device_synchronize",
     "spmv_amd_init_stencil5_synthetic", "spmv_amd_download_device_csr", "spmv_amd_time_run_device", "spmv_amd_operator_variant",
     "spmv_amd_operator_select_variant", "spmv_amd_cg_last_history", "spmv_amd_comm_unique_id", "spmv_amd_comm_create_rccl",
-    "spmv_amd_comm_create_staged", "spmv_amd_comm_destroy", "spmv_amd_comm_set_world", "spmv_amd_comm_rank", "spmv_amd_comm_size",
+    "spmv_amd_comm_create_staged", "spmv_amd_comm_destroy", "spmv_amd_comm_set_world", "spmv_amd_comm_rank", "spmv_amd_comm_size", "spmv_amd_comm_selftest",
     "spmv_amd_cg_slab_create", "spmv_amd_cg_slab_create_stencil5", "spmv_amd_cg_slab_set_vectors", "spmv_amd_cg_slab_solve",
     "spmv_amd_cg_slab_gather", "spmv_amd_cg_slab_history", "spmv_amd_cg_slab_spmv", "spmv_amd_cg_slab_info",
     "spmv_amd_cg_slab_time_spmv", "spmv_amd_cg_slab_destroy", "spmv_amd_version", "spmv_amd_write_stencil5_values",
@@ -148,6 +148,9 @@ def lib():
     L.spmv_amd_comm_create_staged.argtypes = [C.c_int, C.c_int, HALO_FN, ALLREDUCE_FN, GATHER_FN, BARRIER_FN, C.c_void_p]
     L.spmv_amd_comm_destroy.argtypes = [C.c_void_p]
     L.spmv_amd_comm_set_world.argtypes = [C.c_void_p]
+    L.spmv_amd_comm_rank.argtypes = [C.c_void_p]
+    L.spmv_amd_comm_size.argtypes = [C.c_void_p]
+    L.spmv_amd_comm_selftest.argtypes = [C.c_void_p]
     L.spmv_amd_cg_slab_create.restype = C.c_void_p
     L.spmv_amd_cg_slab_create.argtypes = [C.POINTER(MatrixData), C.c_void_p]
     L.spmv_amd_cg_slab_create_stencil5.restype = C.c_void_p

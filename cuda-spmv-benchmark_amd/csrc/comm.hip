@@ -57,7 +57,6 @@ struct RcclComm final : SpmvAmdComm {
         RCCL_CHECK(ncclGroupEnd());
     }
     void allreduce_sum(double* d_buf, int count, hipStream_t stream) override {
-        if (world == 1) return;
         RCCL_CHECK(ncclAllReduce(d_buf, d_buf, (size_t)count, ncclDouble, ncclSum, coll, stream));
     }
     void gather_to_root(const double* d_local, int n_local, double* h_full, const int* counts,
@@ -82,7 +81,6 @@ struct RcclComm final : SpmvAmdComm {
         }
     }
     void barrier() override {
-        if (world == 1) return;
         double* d = device_alloc<double>(1);
         HIP_CHECK(hipMemset(d, 0, sizeof(double)));
         RCCL_CHECK(ncclAllReduce(d, d, 1, ncclDouble, ncclSum, coll, nullptr));
@@ -191,7 +189,7 @@ extern "C" SpmvAmdComm* spmv_amd_comm_create_rccl(int rank, int world, const voi
     RcclComm* c = new RcclComm();
     c->rank = rank;
     c->world = world;
-    if (world > 1) {
+    {
         ncclUniqueId a, b;
         memcpy(&a, id256, NCCL_UNIQUE_ID_BYTES);
         memcpy(&b, (const char*)id256 + NCCL_UNIQUE_ID_BYTES, NCCL_UNIQUE_ID_BYTES);
@@ -226,3 +224,17 @@ extern "C" void spmv_amd_comm_destroy(SpmvAmdComm* comm) {
 extern "C" void spmv_amd_comm_set_world(SpmvAmdComm* comm) { g_world = comm; }
 extern "C" int spmv_amd_comm_rank(const SpmvAmdComm* comm) { return comm ? comm->rank : 0; }
 extern "C" int spmv_amd_comm_size(const SpmvAmdComm* comm) { return comm ? comm->world : 1; }
+
+extern "C" int spmv_amd_comm_selftest(SpmvAmdComm* comm) {
+    if (comm == nullptr) comm = &g_self;
+    double mine = (double)(comm->rank + 1), got = 0.0;
+    double* d = device_alloc<double>(1);
+    HIP_CHECK(hipMemcpy(d, &mine, sizeof mine, hipMemcpyHostToDevice));
+    comm->allreduce_sum(d, 1, nullptr);
+    HIP_CHECK(hipStreamSynchronize(nullptr));
+    HIP_CHECK(hipMemcpy(&got, d, sizeof got, hipMemcpyDeviceToHost));
+    device_release(d);
+    comm->barrier();
+    const double want = 0.5 * comm->world * (comm->world + 1);
+    return got == want ? 0 : 1;
+}

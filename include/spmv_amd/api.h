@@ -228,6 +228,9 @@ void spmv_amd_comm_destroy(SpmvAmdComm* comm);
 void spmv_amd_comm_set_world(SpmvAmdComm* comm);
 int spmv_amd_comm_rank(const SpmvAmdComm* comm);
 int spmv_amd_comm_size(const SpmvAmdComm* comm);
+/* Runs one all-reduce and one barrier through the communicator and checks the sum
+ * (value rank+1 on every rank -> world*(world+1)/2); 0 on success. */
+int spmv_amd_comm_selftest(SpmvAmdComm* comm);
 
 /* ---- resident multi-GPU CG (what cg_solve_mgpu_partitioned is built from) ---- */
 typedef struct SpmvAmdCgSlab SpmvAmdCgSlab;

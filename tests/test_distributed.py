@@ -61,6 +61,7 @@ def test_rccl_communicator_single_rank(B, O, fresh_host_matrices):
     assert len(uid) == B.COMM_ID_BYTES and any(uid)
     comm = B.Comm.rccl(0, 1, uid)
     assert B.lib().spmv_amd_comm_rank(comm.handle) == 0 and B.lib().spmv_amd_comm_size(comm.handle) == 1
+    assert B.lib().spmv_amd_comm_selftest(comm.handle) == 0  # one all-reduce + barrier through RCCL
     n = 200
     slab = B.CgSlab.stencil5(n, comm)
     st = slab.solve()
