@@ -51,7 +51,8 @@ struct SpmvAmdCgSlab {
     hipEvent_t ev_p_ready = nullptr, ev_halo_done = nullptr, ev_poll = nullptr;
     int waves = 0;
     LaunchShape shape;
-    LaunchShape edge_shape;  // grid for the one-grid-row launches next to the halos
+    int partials_cap = 0;
+    const char* variant_name = "";
     bool fused_dot = false;
     std::vector<double> history;
     // event pairs around every in-loop SpMV (recorded without any host sync, resolved after the
@@ -86,20 +87,28 @@ void make_common(SpmvAmdCgSlab* s) {
     HIP_CHECK(hipMemset(s->p_alloc, 0, (lead + nl + (size_t)s->halo + 2) * sizeof(double)));
     s->shape = current_launch_shape();
     s->waves = launch_stencil5_waves(s->shape);
-    {
-        const int edge_tiles = s->halo / 128 + 2;
-        s->edge_shape.compute_units = (edge_tiles + 3) / 4;
-        s->edge_shape.blocks_per_cu = 1;
-        if (launch_stencil5_waves(s->edge_shape) > s->waves) s->edge_shape = s->shape;
-    }
-    s->partials_spmv = device_alloc<double>(3 * (size_t)s->waves);
-    HIP_CHECK(hipMemset(s->partials_spmv, 0, 3 * (size_t)s->waves * sizeof(double)));
     s->partials_blas = device_alloc<double>((size_t)cg_partial_count());
     s->d_s = device_alloc<CgScalars>(1);
     HIP_CHECK(hipMemset(s->d_s, 0, sizeof(CgScalars)));
     HIP_CHECK(hipHostMalloc((void**)&s->h_poll, sizeof(*s->h_poll), hipHostMallocDefault));
     s->A.verify_stencil(s->compute);
-    s->fused_dot = s->A.view.verified_stencil && s->grid >= 128;
+    {
+        // dot partials: one slot per launched wave; the launch geometry is a fixed function of the
+        // slab and the row range, so size for the larger of the two ways a SpMV is issued
+        const SlabCsr& A = s->A.view;
+        const int lo = s->has_prev ? s->halo : 0, hi = s->n_local - (s->has_next ? s->halo : 0);
+        const auto need = [&](int a, int b) {
+            return b > a ? stencil5_partials_needed(A, a, b, Stencil5Variant::Auto, s->shape) : 0;
+        };
+        const int whole = need(0, s->n_local);
+        const int split = need(lo, hi) + need(0, lo) + need(hi, s->n_local);
+        s->partials_cap = whole > split ? whole : split;
+        s->partials_spmv = device_alloc<double>((size_t)s->partials_cap);
+        HIP_CHECK(hipMemset(s->partials_spmv, 0, (size_t)s->partials_cap * sizeof(double)));
+        const char* name = stencil5_variant_name(A, 0, s->n_local, Stencil5Variant::Auto, s->shape);
+        s->variant_name = name;
+        s->fused_dot = A.verified_stencil && s->grid >= 128;  // row-generic slabs use the plain dot kernel
+    }
     launch_fill(s->b, nl, 1.0, s->compute);   // default right-hand side b = 1
     launch_fill(s->x0, nl, 0.0, s->compute);  // default initial guess x0 = 0
     HIP_CHECK(hipDeviceSynchronize());
@@ -123,34 +132,30 @@ bool partition_ok(const SpmvAmdComm* comm, int n, int grid, int n_local) {
 // overlap = the halo exchange was started on the side stream and ev_halo_done marks its end.
 void slab_spmv(SpmvAmdCgSlab* s, bool with_dot, bool overlap, const int* skip) {
     const SlabCsr& A = s->A.view;
-    const int W = s->waves;
     double* part = (with_dot && s->fused_dot) ? s->partials_spmv : nullptr;
     const int lo = s->has_prev ? s->halo : 0;
     const int hi = s->n_local - (s->has_next ? s->halo : 0);
+    int used = 0;
     if (!overlap || hi <= lo || (lo == 0 && hi == s->n_local)) {
         if (overlap) HIP_CHECK(hipStreamWaitEvent(s->compute, s->ev_halo_done, 0));
-        launch_stencil5_spmv(A, s->p, s->Ap, 1.0, 0, s->n_local, part, skip, Stencil5Variant::Auto,
-                             s->shape, s->compute);
-        // the edge segments carry no rows in this configuration; with one rank they are never
-        // written at all and stay zero from creation
-        if (part && s->comm->world > 1)
-            HIP_CHECK(hipMemsetAsync(part + W, 0, 2 * (size_t)W * sizeof(double), s->compute));
+        used = launch_stencil5_spmv(A, s->p, s->Ap, 1.0, 0, s->n_local, part, skip, Stencil5Variant::Auto,
+                                    s->shape, s->compute);
     } else {
-        launch_stencil5_spmv(A, s->p, s->Ap, 1.0, lo, hi, part, skip, Stencil5Variant::Auto, s->shape,
-                             s->compute);
+        // rows whose north and south neighbours are local first; the first / last grid row of the
+        // slab once the halo rows have landed
+        used = launch_stencil5_spmv(A, s->p, s->Ap, 1.0, lo, hi, part, skip, Stencil5Variant::Auto,
+                                    s->shape, s->compute);
         HIP_CHECK(hipStreamWaitEvent(s->compute, s->ev_halo_done, 0));
-        // head / tail grid rows: small fixed grids; a segment without rows on this rank is never
-        // written and stays zero from creation
         if (lo > 0)
-            launch_stencil5_spmv(A, s->p, s->Ap, 1.0, 0, lo, part ? part + W : nullptr, skip,
-                                 Stencil5Variant::Auto, s->edge_shape, s->compute);
+            used += launch_stencil5_spmv(A, s->p, s->Ap, 1.0, 0, lo, part ? part + used : nullptr, skip,
+                                         Stencil5Variant::Auto, s->shape, s->compute);
         if (hi < s->n_local)
-            launch_stencil5_spmv(A, s->p, s->Ap, 1.0, hi, s->n_local, part ? part + 2 * W : nullptr,
-                                 skip, Stencil5Variant::Auto, s->edge_shape, s->compute);
+            used += launch_stencil5_spmv(A, s->p, s->Ap, 1.0, hi, s->n_local, part ? part + used : nullptr,
+                                         skip, Stencil5Variant::Auto, s->shape, s->compute);
     }
     if (with_dot) {
         if (part)
-            launch_reduce_partials(part, 3 * W, &s->d_s->pAp, skip, s->compute);
+            launch_reduce_partials(part, used, &s->d_s->pAp, skip, s->compute);
         else
             launch_dot((size_t)s->n_local, s->p, s->Ap, s->partials_blas, &s->d_s->pAp, s->compute);
     }
@@ -405,9 +410,9 @@ extern "C" int spmv_amd_cg_slab_time_spmv(SpmvAmdCgSlab* s, int reps, float* ms_
     EventTimer t;
     for (int i = 0; i < reps; ++i) {
         t.begin(s->compute);
-        launch_stencil5_spmv(s->A.view, s->p, s->Ap, 1.0, 0, s->n_local,
-                             s->fused_dot ? s->partials_spmv : nullptr, nullptr, Stencil5Variant::Auto,
-                             s->shape, s->compute);
+        (void)launch_stencil5_spmv(s->A.view, s->p, s->Ap, 1.0, 0, s->n_local,
+                                   s->fused_dot ? s->partials_spmv : nullptr, nullptr,
+                                   Stencil5Variant::Auto, s->shape, s->compute);
         t.end(s->compute);
         ms_each[i] = t.elapsed_ms();
     }

@@ -43,12 +43,19 @@ void launch_verify_stencil5_csr(const SlabCsr& m, int* d_mismatch, hipStream_t s
 
 // ---- STENCIL5 SpMV ----
 // y[r] = alpha * (A x)[r]. d_dot_partials, if non-null, receives one partial of
-// sum_r x[r]*y_unscaled[r] per launched wave (fixed shape: waves = launch_stencil5_waves()).
-enum class Stencil5Variant { Auto, WaveTile, RowGeneric };
+// sum_r x[r]*y_unscaled[r] per launched wave (count: stencil5_partials_needed()).
+enum class Stencil5Variant { Auto, ColumnMarch, WaveTile, RowGeneric };
 int launch_stencil5_waves(const LaunchShape& shape);
-// first_row/last_row restrict the launch to local rows [first_row, last_row) (multiples of
-// 128 or the slab end); used to split interior rows from halo-dependent rows.
-void launch_stencil5_spmv(const SlabCsr& m, const double* x, double* y, double alpha,
+// Partial-sum slots a launch over [first_row, last_row) writes (a fixed function of the slab, the
+// range and the launch shape, so reductions keep one shape for the life of a solver).
+int stencil5_partials_needed(const SlabCsr& m, int first_row, int last_row, Stencil5Variant variant,
+                             const LaunchShape& shape);
+const char* stencil5_variant_name(const SlabCsr& m, int first_row, int last_row,
+                                  Stencil5Variant variant, const LaunchShape& shape);
+// first_row/last_row restrict the launch to local rows [first_row, last_row); used to split
+// interior rows from halo-dependent rows. Returns the number of dot partials written (0 when
+// d_dot_partials is null).
+int launch_stencil5_spmv(const SlabCsr& m, const double* x, double* y, double alpha,
                           int first_row, int last_row, double* d_dot_partials,
                           const int* d_skip_flag, Stencil5Variant variant,
                           const LaunchShape& shape, hipStream_t stream);

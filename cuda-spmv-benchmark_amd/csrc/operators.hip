@@ -81,15 +81,12 @@ CsrBackedOperator g_csr{"cusparse-csr"};
 // ---- stencil5-csr ----------------------------------------------------------------
 
 void stencil_pick_variant() {
-    const bool tile = g_stencil.A.view.verified_stencil && g_stencil.A.view.grid_size >= 128 &&
-                      g_stencil.stencil_variant != Stencil5Variant::RowGeneric;
-    g_stencil.variant_name = tile ? "stencil5/wave-tile"
-                             : g_stencil.A.view.verified_stencil ? "stencil5/row-generic"
-                                                                 : "stencil5/row-generic(csr-loop)";
+    g_stencil.variant_name = stencil5_variant_name(g_stencil.A.view, 0, g_stencil.rows,
+                                                   g_stencil.stencil_variant, current_launch_shape());
 }
 
 int stencil_init(MatrixData* mat) {
-    printf("[stencil5-csr] Initializing (computed offsets, wave-tile kernel on gfx950)\n");
+    printf("[stencil5-csr] Initializing (computed offsets, column-march kernel on gfx950)\n");
     if (g_stencil.init_from_host(mat) != 0) return EXIT_FAILURE;
     g_stencil.A.verify_stencil(kDefaultStream);
     stencil_pick_variant();
@@ -103,8 +100,9 @@ int stencil_run_device(const double* d_x, double* d_y) {
         fprintf(stderr, "[stencil5-csr] run before init\n");
         return EXIT_FAILURE;
     }
-    launch_stencil5_spmv(g_stencil.A.view, d_x, d_y, /*alpha=*/1.0, 0, g_stencil.rows, nullptr,
-                         nullptr, g_stencil.stencil_variant, current_launch_shape(), kDefaultStream);
+    (void)launch_stencil5_spmv(g_stencil.A.view, d_x, d_y, /*alpha=*/1.0, 0, g_stencil.rows, nullptr,
+                               nullptr, g_stencil.stencil_variant, current_launch_shape(),
+                               kDefaultStream);
     return 0;
 }
 
@@ -412,6 +410,7 @@ extern "C" int spmv_amd_operator_select_variant(const char* mode, const char* va
     switch (which_operator(mode)) {
         case Which::Stencil:
             if (automatic) g_stencil.stencil_variant = Stencil5Variant::Auto;
+            else if (!strcmp(variant, "column-march")) g_stencil.stencil_variant = Stencil5Variant::ColumnMarch;
             else if (!strcmp(variant, "wave-tile")) g_stencil.stencil_variant = Stencil5Variant::WaveTile;
             else if (!strcmp(variant, "row-generic")) g_stencil.stencil_variant = Stencil5Variant::RowGeneric;
             else return EXIT_FAILURE;

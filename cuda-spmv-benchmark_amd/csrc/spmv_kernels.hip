@@ -15,6 +15,9 @@
 // keeps the +-grid_size neighbour rows L2-resident by giving each XCD a contiguous
 // band of tiles (blockIdx % 8 is only a locality label, never a correctness input).
 #include "kernels.hpp"
+
+#include <stdlib.h>
+
 #include "stencil_geometry.hpp"
 
 namespace spmv_amd {
@@ -195,25 +198,187 @@ __global__ __launch_bounds__(kBlock) void stencil5_wavetile_kernel(
 }
 
 // ---------------------------------------------------------------------------------
+// STENCIL5, column-march variant (the default on slabs made of whole grid rows).
+// A wave owns a strip of 128 grid columns and marches down `rows_per_task` grid rows. The three
+// x rows a stencil row needs (north, centre, south) stay in registers and rotate: every x element
+// is fetched from memory exactly once per task (plus two start-up rows), whatever the caches do.
+// `values` of the next grid row are prefetched into registers while the current row is computed.
+// Four waves of a block take four adjacent strips, blocks are numbered strip-group fastest, so the
+// chip sweeps bands of grid rows left to right and streams each array sequentially.
+// Strips containing column 0 or n-1 (and any grid row that is a global boundary, which the
+// launcher sends to the row kernel instead) evaluate rows the reference's way, row by row.
+// ---------------------------------------------------------------------------------
+struct ValueChunks {
+    d2 c0, c1, c2, c3, c4, c5;
+};
+
+__device__ __forceinline__ void load_value_chunks(ValueChunks& v, const double* __restrict__ values,
+                                                  long long s, int lane) {
+    const int sh = (int)(s & 1);
+    const d2* __restrict__ src = reinterpret_cast<const d2*>(values + (s - sh));
+    v.c0 = src[lane];
+    v.c1 = src[64 + lane];
+    v.c2 = src[128 + lane];
+    v.c3 = src[192 + lane];
+    v.c4 = src[256 + lane];
+    if (sh != 0 && lane == 0) v.c5 = src[320];
+}
+
+template <bool kVec, bool kDot>
+__global__ __launch_bounds__(kBlock) void stencil5_colmarch_kernel(
+    SlabCsr m, const double* __restrict__ x, double* __restrict__ y, double alpha, int gi_lo,
+    int gi_hi, int rows_per_task, int strips, double* __restrict__ dot_partials,
+    const int* __restrict__ skip_flag) {
+    __shared__ __attribute__((aligned(16))) double lds[kWavesPerBlock * kLdsDoublesPerWave];
+    if (skip_flag != nullptr && *skip_flag != 0) return;
+
+    const int lane = threadIdx.x & 63;
+    const int wave_in_block = threadIdx.x >> 6;
+    double* __restrict__ wlds = lds + wave_in_block * kLdsDoublesPerWave;
+    const int n = m.grid_size;
+    const int strip_groups = (strips + kWavesPerBlock - 1) / kWavesPerBlock;
+    const int chunk = (int)blockIdx.x / strip_groups;
+    const int strip = ((int)blockIdx.x - chunk * strip_groups) * kWavesPerBlock + wave_in_block;
+    const int li0 = gi_lo + chunk * rows_per_task;  // local grid rows [li0, li1)
+    const int li1 = min(li0 + rows_per_task, gi_hi);
+    const int gfirst = m.row_offset / n;  // global grid row of the slab's first row
+    const int j0 = strip * kTileRows;
+
+    double dot_acc = 0.0;
+    if (strip < strips && li0 < li1) {
+        const bool pure = j0 >= 1 && j0 + kTileRows - 1 <= n - 2;
+        if (pure) {
+            long long s = stencil_gridrow_base(gfirst + li0, n) + 5LL * j0 - 1 - m.nnz_base;
+            const long long s_step = 5LL * n - 2;
+            const double* __restrict__ xl = x + ((long long)li0 * n + j0 + 2 * lane);
+            double* __restrict__ yl = y + ((long long)li0 * n + j0 + 2 * lane);
+            auto load_pair = [](const double* __restrict__ p) {
+                d2 v;
+                if (kVec) {
+                    v = *reinterpret_cast<const d2*>(p);
+                } else {
+                    v.x = p[0];
+                    v.y = p[1];
+                }
+                return v;
+            };
+            d2 xn = load_pair(xl - n);
+            d2 xc = load_pair(xl);
+            ValueChunks A, B;
+            A.c5 = d2{0.0, 0.0};
+            B.c5 = d2{0.0, 0.0};
+            load_value_chunks(A, m.values, s, lane);
+
+            auto step = [&](ValueChunks& cur, ValueChunks& nxt, bool more) {
+                const d2 xs = load_pair(xl + n);
+                double edge = 0.0;
+                if (lane == 0) edge = xl[-1];
+                if (lane == 63) edge = xl[2];
+                if (more) load_value_chunks(nxt, m.values, s + s_step, lane);
+
+                const int sh = (int)(s & 1);
+                d2* __restrict__ w2 = reinterpret_cast<d2*>(wlds);
+                w2[lane] = cur.c0;
+                w2[64 + lane] = cur.c1;
+                w2[128 + lane] = cur.c2;
+                w2[192 + lane] = cur.c3;
+                w2[256 + lane] = cur.c4;
+                if (sh != 0 && lane == 0) w2[320] = cur.c5;
+                __builtin_amdgcn_wave_barrier();
+                const double* __restrict__ v = wlds + sh + 10 * lane;
+                const double a0 = v[0], a1 = v[1], a2 = v[2], a3 = v[3], a4 = v[4];
+                const double b0 = v[5], b1 = v[6], b2 = v[7], b3 = v[8], b4 = v[9];
+                __builtin_amdgcn_wave_barrier();
+
+                double w = __shfl_up(xc.y, 1);
+                double e = __shfl_down(xc.x, 1);
+                if (lane == 0) w = edge;
+                if (lane == 63) e = edge;
+                double r0 = a1 * w;
+                r0 = fma(a2, xc.x, r0);
+                r0 = fma(a3, xc.y, r0);
+                r0 = fma(a0, xn.x, r0);
+                r0 = fma(a4, xs.x, r0);
+                double r1 = b1 * xc.x;
+                r1 = fma(b2, xc.y, r1);
+                r1 = fma(b3, e, r1);
+                r1 = fma(b0, xn.y, r1);
+                r1 = fma(b4, xs.y, r1);
+                if (kDot) {
+                    dot_acc = fma(xc.x, r0, dot_acc);
+                    dot_acc = fma(xc.y, r1, dot_acc);
+                }
+                if (kVec) {
+                    d2 out = {alpha * r0, alpha * r1};
+                    *reinterpret_cast<d2*>(yl) = out;
+                } else {
+                    yl[0] = alpha * r0;
+                    yl[1] = alpha * r1;
+                }
+                xn = xc;
+                xc = xs;
+                xl += n;
+                yl += n;
+                s += s_step;
+            };
+            int li = li0;
+            for (; li + 1 < li1; li += 2) {
+                step(A, B, true);
+                step(B, A, li + 2 < li1);
+            }
+            if (li < li1) step(A, B, false);
+        } else {
+            for (int li = li0; li < li1; ++li) {
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int j = j0 + 2 * lane + e;
+                    if (j < n) {
+                        const long long lr = (long long)li * n + j;
+                        const double sum = row_reference<true>(m, x, (int)lr, gfirst + li, j);
+                        if (kDot) dot_acc = fma(x[lr], sum, dot_acc);
+                        y[lr] = alpha * sum;
+                    }
+                }
+            }
+        }
+    }
+    if (kDot) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) dot_acc += __shfl_down(dot_acc, off);
+        if (lane == 0) dot_partials[blockIdx.x * kWavesPerBlock + wave_in_block] = dot_acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // STENCIL5, row-generic variant: one thread per row, the reference's own shape. Used for
 // small grids, for matrices that are not a complete 5-point stencil (kAnalytic = false:
 // every row takes the CSR loop, as the reference does when grid_size = -1).
 // ---------------------------------------------------------------------------------
-template <bool kAnalytic>
+template <bool kAnalytic, bool kDot>
 __global__ __launch_bounds__(kBlock) void stencil5_row_kernel(SlabCsr m, const double* __restrict__ x,
                                                               double* __restrict__ y, double alpha,
                                                               int first_row, int last_row,
+                                                              double* __restrict__ dot_partials,
                                                               const int* __restrict__ skip_flag) {
     if (skip_flag != nullptr && *skip_flag != 0) return;
     const long long row = (long long)first_row + (long long)blockIdx.x * kBlock + threadIdx.x;
-    if (row >= last_row) return;
-    int i = -1, j = 0;
-    if (kAnalytic) {
-        const int g = m.row_offset + (int)row;
-        i = g / m.grid_size;
-        j = g - i * m.grid_size;
+    double dot_acc = 0.0;
+    if (row < last_row) {
+        int i = -1, j = 0;
+        if (kAnalytic) {
+            const int g = m.row_offset + (int)row;
+            i = g / m.grid_size;
+            j = g - i * m.grid_size;
+        }
+        const double sum = row_reference<kAnalytic>(m, x, (int)row, i, j);
+        if (kDot) dot_acc = x[row] * sum;
+        y[row] = alpha * sum;
     }
-    y[row] = alpha * row_reference<kAnalytic>(m, x, (int)row, i, j);
+    if (kDot) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) dot_acc += __shfl_down(dot_acc, off);
+        if ((threadIdx.x & 63) == 0) dot_partials[blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)] = dot_acc;
+    }
 }
 
 // ---------------------------------------------------------------------------------
@@ -392,49 +557,158 @@ static int wavetile_blocks(const LaunchShape& shape) {
     return blocks < 8 ? 8 : blocks;
 }
 
-int launch_stencil5_waves(const LaunchShape& shape) { return wavetile_blocks(shape) * kWavesPerBlock; }
+static int env_int(const char* name, int fallback) {
+    const char* v = getenv(name);
+    return (v && *v) ? atoi(v) : fallback;
+}
 
-void launch_stencil5_spmv(const SlabCsr& m, const double* x, double* y, double alpha,
-                          int first_row, int last_row, double* d_dot_partials,
-                          const int* d_skip_flag, Stencil5Variant variant,
-                          const LaunchShape& shape, hipStream_t stream) {
-    if (last_row <= first_row) return;
+namespace {
+struct Stencil5Plan {
+    Stencil5Variant variant;
+    // column-march: the range splits into up to two global-boundary grid rows (row kernel) and
+    // the grid rows [gi_lo, gi_hi) in between
+    bool head_rows = false, tail_rows = false;
+    int gi_lo = 0, gi_hi = 0, rows_per_task = 0, strips = 0, march_blocks = 0;
+    int row_blocks = 0;  // blocks of one boundary-grid-row launch
+    int tile_blocks = 0;
+};
+
+Stencil5Plan plan_stencil5(const SlabCsr& m, int first_row, int last_row, Stencil5Variant variant,
+                           const LaunchShape& shape) {
+    Stencil5Plan p;
     const int n = m.grid_size;
     const bool tile_ok = m.verified_stencil && n >= kTileRows;
+    const bool march_ok = tile_ok && m.row_offset % n == 0 && m.n_local % n == 0 &&
+                          first_row % n == 0 && last_row % n == 0;
     if (variant == Stencil5Variant::Auto)
+        variant = march_ok ? Stencil5Variant::ColumnMarch
+                  : tile_ok ? Stencil5Variant::WaveTile
+                            : Stencil5Variant::RowGeneric;
+    if (variant == Stencil5Variant::ColumnMarch && !march_ok)
         variant = tile_ok ? Stencil5Variant::WaveTile : Stencil5Variant::RowGeneric;
     if (variant == Stencil5Variant::WaveTile && !tile_ok) variant = Stencil5Variant::RowGeneric;
-
+    p.variant = variant;
     if (variant == Stencil5Variant::RowGeneric) {
-        const dim3 grid(blocks_for((long long)last_row - first_row));
-        if (m.verified_stencil && n >= 2)
-            hipLaunchKernelGGL(stencil5_row_kernel<true>, grid, dim3(kBlock), 0, stream, m, x, y,
-                               alpha, first_row, last_row, d_skip_flag);
-        else
-            hipLaunchKernelGGL(stencil5_row_kernel<false>, grid, dim3(kBlock), 0, stream, m, x, y,
-                               alpha, first_row, last_row, d_skip_flag);
-        return;
+        p.row_blocks = (int)blocks_for((long long)last_row - first_row);
+    } else if (variant == Stencil5Variant::WaveTile) {
+        p.tile_blocks = wavetile_blocks(shape);
+    } else {
+        const int gfirst = m.row_offset / n;
+        p.gi_lo = first_row / n;
+        p.gi_hi = last_row / n;
+        if (gfirst + p.gi_lo == 0) p.head_rows = true, ++p.gi_lo;
+        if (gfirst + p.gi_hi == n && p.gi_hi > p.gi_lo) p.tail_rows = true, --p.gi_hi;
+        if (p.gi_hi < p.gi_lo) p.gi_hi = p.gi_lo;
+        p.row_blocks = (int)blocks_for(n);
+        p.strips = (n + kTileRows - 1) / kTileRows;
+        const int strip_groups = (p.strips + kWavesPerBlock - 1) / kWavesPerBlock;
+        const int G = p.gi_hi - p.gi_lo;
+        if (G > 0) {
+            // enough blocks for several rounds over the chip, few enough start-up rows per task
+            const long long target = (long long)shape.compute_units * env_int("SPMV_AMD_MARCH_BLOCKS_PER_CU", 20);
+            long long R = ((long long)G * strip_groups) / (target > 0 ? target : 1);
+            const int r_max = env_int("SPMV_AMD_MARCH_MAX_ROWS", 64), r_min = 4;
+            R = R > r_max ? r_max : (R < r_min ? r_min : R);
+            if (R > G) R = G;
+            p.rows_per_task = env_int("SPMV_AMD_ROWS_PER_TASK", (int)R);
+            if (p.rows_per_task < 1) p.rows_per_task = 1;
+            p.march_blocks = ((G + p.rows_per_task - 1) / p.rows_per_task) * strip_groups;
+        }
     }
+    return p;
+}
+}  // namespace
 
-    // Fixed grid (independent of the row range) so that the dot partials keep their shape.
-    const dim3 grid(wavetile_blocks(shape));
-    const bool vec_xy = aligned16(x) && aligned16(y);
-    const bool vec_ns = vec_xy && (n % 2 == 0);
+int launch_stencil5_waves(const LaunchShape& shape) { return wavetile_blocks(shape) * kWavesPerBlock; }
+
+int stencil5_partials_needed(const SlabCsr& m, int first_row, int last_row, Stencil5Variant variant,
+                             const LaunchShape& shape) {
+    const Stencil5Plan p = plan_stencil5(m, first_row, last_row, variant, shape);
+    if (p.variant == Stencil5Variant::RowGeneric) return p.row_blocks * kWavesPerBlock;
+    if (p.variant == Stencil5Variant::WaveTile) return p.tile_blocks * kWavesPerBlock;
+    return (p.march_blocks + (p.head_rows ? p.row_blocks : 0) + (p.tail_rows ? p.row_blocks : 0)) * kWavesPerBlock;
+}
+
+const char* stencil5_variant_name(const SlabCsr& m, int first_row, int last_row, Stencil5Variant variant,
+                                  const LaunchShape& shape) {
+    switch (plan_stencil5(m, first_row, last_row, variant, shape).variant) {
+        case Stencil5Variant::ColumnMarch: return "stencil5/column-march";
+        case Stencil5Variant::WaveTile: return "stencil5/wave-tile";
+        default: return m.verified_stencil ? "stencil5/row-generic" : "stencil5/row-generic(csr-loop)";
+    }
+}
+
+int launch_stencil5_spmv(const SlabCsr& m, const double* x, double* y, double alpha,
+                         int first_row, int last_row, double* d_dot_partials,
+                         const int* d_skip_flag, Stencil5Variant variant,
+                         const LaunchShape& shape, hipStream_t stream) {
+    if (last_row <= first_row) return 0;
+    const int n = m.grid_size;
+    const Stencil5Plan p = plan_stencil5(m, first_row, last_row, variant, shape);
     const bool dot = d_dot_partials != nullptr;
+    const bool analytic = m.verified_stencil && n >= 2;
+
+    auto launch_rows = [&](int lo, int hi, double* partials) {
+        const dim3 grid(blocks_for((long long)hi - lo));
+#define SPMV_AMD_LAUNCH_ROWS(AN, DOT)                                                                   \
+    hipLaunchKernelGGL((stencil5_row_kernel<AN, DOT>), grid, dim3(kBlock), 0, stream, m, x, y, alpha, lo, \
+                       hi, partials, d_skip_flag)
+        if (analytic) {
+            if (dot) SPMV_AMD_LAUNCH_ROWS(true, true);
+            else SPMV_AMD_LAUNCH_ROWS(true, false);
+        } else {
+            if (dot) SPMV_AMD_LAUNCH_ROWS(false, true);
+            else SPMV_AMD_LAUNCH_ROWS(false, false);
+        }
+#undef SPMV_AMD_LAUNCH_ROWS
+        return (int)grid.x * kWavesPerBlock;
+    };
+
+    if (p.variant == Stencil5Variant::RowGeneric) return launch_rows(first_row, last_row, d_dot_partials);
+
+    const bool vec_xy = aligned16(x) && aligned16(y);
+    if (p.variant == Stencil5Variant::WaveTile) {
+        // Fixed grid (independent of the row range) so that the dot partials keep their shape.
+        const dim3 grid(p.tile_blocks);
+        const bool vec_ns = vec_xy && (n % 2 == 0);
 #define SPMV_AMD_LAUNCH_TILE(VXY, VNS, DOT)                                                       \
     hipLaunchKernelGGL((stencil5_wavetile_kernel<VXY, VNS, DOT>), grid, dim3(kBlock), 0, stream, m, \
                        x, y, alpha, first_row, last_row, d_dot_partials, d_skip_flag)
-    if (vec_ns) {
-        if (dot) SPMV_AMD_LAUNCH_TILE(true, true, true);
-        else SPMV_AMD_LAUNCH_TILE(true, true, false);
-    } else if (vec_xy) {
-        if (dot) SPMV_AMD_LAUNCH_TILE(true, false, true);
-        else SPMV_AMD_LAUNCH_TILE(true, false, false);
-    } else {
-        if (dot) SPMV_AMD_LAUNCH_TILE(false, false, true);
-        else SPMV_AMD_LAUNCH_TILE(false, false, false);
-    }
+        if (vec_ns) {
+            if (dot) SPMV_AMD_LAUNCH_TILE(true, true, true);
+            else SPMV_AMD_LAUNCH_TILE(true, true, false);
+        } else if (vec_xy) {
+            if (dot) SPMV_AMD_LAUNCH_TILE(true, false, true);
+            else SPMV_AMD_LAUNCH_TILE(true, false, false);
+        } else {
+            if (dot) SPMV_AMD_LAUNCH_TILE(false, false, true);
+            else SPMV_AMD_LAUNCH_TILE(false, false, false);
+        }
 #undef SPMV_AMD_LAUNCH_TILE
+        return (int)grid.x * kWavesPerBlock;
+    }
+
+    // column-march: [global first grid row] + marched grid rows + [global last grid row]
+    int used = 0;
+    if (p.march_blocks > 0) {
+        const dim3 grid(p.march_blocks);
+        const bool vec = vec_xy && (n % 2 == 0);
+#define SPMV_AMD_LAUNCH_MARCH(VEC, DOT)                                                               \
+    hipLaunchKernelGGL((stencil5_colmarch_kernel<VEC, DOT>), grid, dim3(kBlock), 0, stream, m, x, y,    \
+                       alpha, p.gi_lo, p.gi_hi, p.rows_per_task, p.strips, d_dot_partials, d_skip_flag)
+        if (vec) {
+            if (dot) SPMV_AMD_LAUNCH_MARCH(true, true);
+            else SPMV_AMD_LAUNCH_MARCH(true, false);
+        } else {
+            if (dot) SPMV_AMD_LAUNCH_MARCH(false, true);
+            else SPMV_AMD_LAUNCH_MARCH(false, false);
+        }
+#undef SPMV_AMD_LAUNCH_MARCH
+        used += p.march_blocks * kWavesPerBlock;
+    }
+    if (p.head_rows) used += launch_rows(first_row, first_row + n, dot ? d_dot_partials + used : nullptr);
+    if (p.tail_rows) used += launch_rows(last_row - n, last_row, dot ? d_dot_partials + used : nullptr);
+    return used;
 }
 
 void launch_csr_spmv(const SlabCsr& m, const double* x, double* y, double alpha,

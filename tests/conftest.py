@@ -64,9 +64,12 @@ def rel_err(a, b):
 
 
 def hist_err(hist, ref):
-    """Relative error of a residual history. Entries that have fallen to rounding noise (below
-    1e-12 * ||r0||: exact convergence on tiny grids) are measured against that floor instead of
-    against themselves, where 'relative' would compare noise with noise."""
+    """Relative error of a residual history against the oracle's. Entries that have fallen to
+    rounding noise (below 1e-13 * ||r0||: exact convergence on tiny grids) cannot be compared
+    relatively (noise vs noise); there both sides just have to be below 1e-12 * ||r0||."""
     hist, ref = np.asarray(hist, dtype=np.float64), np.asarray(ref, dtype=np.float64)
-    den = np.maximum(np.abs(ref), 1e-12 * abs(ref[0]))
-    return float(np.max(np.abs(hist - ref) / den))
+    live = np.abs(ref) > 1e-13 * abs(ref[0])
+    err = float(np.max(np.abs(hist[live] - ref[live]) / np.abs(ref[live])))
+    if (~live).any() and float(np.max(np.abs(hist[~live]))) > 1e-12 * abs(ref[0]):
+        return float("inf")
+    return err

@@ -18,7 +18,7 @@ def check(O, rp, ci, va, n, hist, x, stats, device_form=True):
     assert np.max(np.abs(x - xo)) <= TOL * np.max(np.abs(xo))
     assert abs(stats.solution_sum - ro.solution_sum) <= TOL * abs(ro.solution_sum)
     assert abs(stats.solution_norm - ro.solution_norm) <= TOL * ro.solution_norm
-    assert abs(stats.residual_norm - ro.residual_norm) <= TOL * max(ro.residual_norm, 1e-12 * ho[0])
+    assert hist_err([ho[0], stats.residual_norm], [ho[0], ro.residual_norm]) < TOL
 
 
 @pytest.mark.parametrize("n", [3, 81, 200, 512])

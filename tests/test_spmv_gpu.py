@@ -28,7 +28,7 @@ def test_stencil5_csr_bit_exact_random_values(B, O, fresh_host_matrices, n):
     m = B.HostMatrix(e, n * n, n * n, n)
     op = B.Operator("stencil5-csr")
     assert op.init(m) == 0
-    expect_variant = "stencil5/wave-tile" if n >= 128 else "stencil5/row-generic"
+    expect_variant = "stencil5/column-march" if n >= 128 else "stencil5/row-generic"
     assert op.variant() == expect_variant
     rp, ci, va = O.build_csr(e, n * n)
     want = O.spmv_stencil5(rp, ci, va, x, n)
@@ -40,11 +40,12 @@ def test_stencil5_csr_bit_exact_random_values(B, O, fresh_host_matrices, n):
         def __init__(self, v): self.ptr = v.ptr + 8
     assert op.run_device(Shift(dx), Shift(dy)) == 0
     assert np.array_equal(dy.to_host()[1:], want)
-    # the same matrix forced through the thread-per-row variant
-    op.select_variant("row-generic")
-    got2, _ = op.run_timed(x)
+    # the same matrix forced through the other kernel variants
+    for forced in ("wave-tile", "row-generic"):
+        op.select_variant(forced)
+        got2, _ = op.run_timed(x)
+        assert np.array_equal(got2, want), forced
     op.select_variant(None)
-    assert np.array_equal(got2, want)
     dx.free(), dy.free(), op.free()
 
 
