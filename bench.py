@@ -12,7 +12,7 @@ configuration of reference docs/PROBLEM_SIZE_SCALING_RESULTS.md:40-47, on N row 
   value     CG iterations per second, whole job = K * iterations / (max over ranks of the time
             of K steps, bracketed by barrier + torch.cuda.synchronize() on both sides).
   scaling   strong: the 400 M-unknown problem is fixed, slabs shrink as N grows.
-  roofline  the dominant kernel of the timed region, the STENCIL5 wave-tile SpMV (fused with the
+  roofline  the dominant kernel of the timed region, the STENCIL5 column-march SpMV (fused with the
             p.Ap partials): algorithmic bytes of one launch (8*nnz + 8*cols + 8*rows of the slab,
             SURVEY.md 8d) / its average duration, from HIP events recorded on the solver's stream
             around every in-loop launch of the timed steps. Peak 8 TB/s (MI355X_MICROARCH.md).
@@ -139,7 +139,9 @@ def main():
     if not os.path.exists(B.LIB_PATH):
         if rank == 0:
             B.build()
-    multi = world > 1
+    # SPMV_AMD_BENCH_FORCE_DIST=1 (test hook): take the distributed path with one rank too, i.e.
+    # rendezvous, unique-id broadcast and an RCCL communicator, so a 1-GPU box exercises it.
+    multi = world > 1 or os.environ.get("SPMV_AMD_BENCH_FORCE_DIST") == "1"
     if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -157,7 +159,7 @@ def main():
     rows, nnz = n * n, 5 * n * n - 4 * n
 
     spmv = None
-    if not multi and not args.no_spmv:
+    if world == 1 and not args.no_spmv:
         spmv = spmv_headline(B, n)
 
     comm = None
@@ -205,7 +207,7 @@ def main():
         except (OSError, ValueError):
             pass
     roofline = {
-        "bound": "hbm", "kernel": "stencil5_wavetile_kernel (SpMV + p.Ap partials)", "achieved": achieved, "peak": HBM_PEAK_GBS,
+        "bound": "hbm", "kernel": "stencil5_colmarch_kernel<true,true> (SpMV + p.Ap partials)", "achieved": achieved, "peak": HBM_PEAK_GBS,
         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
         "avg_launch_ms": avg_spmv_ms, "launches_timed": spmv_launches,
     }
@@ -220,7 +222,7 @@ def main():
             "baseline_note": "reference's published CG iters/s on the same problem at the same GPU count, A100-SXM4-80GB (BASELINE.md); no MI355X number is published",
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"CG on the {n}x{n} 5-point stencil ({rows} unknowns, {nnz} nnz), b=1, x0=0, tol 1e-6",
-                       "grid": n, "unknowns": rows, "nnz": nnz, "partition": f"{world} row slab(s)", "transport": "rccl" if multi else "single rank",
+                       "grid": n, "unknowns": rows, "nnz": nnz, "partition": f"{world} row slab(s)", "transport": "rccl" if multi else "single rank (no communicator)",
                        "iterations_per_solve": iterations, "converged": bool(st.converged), "final_residual": st.residual_norm,
                        "residual_history": [float(v) for v in hist]},
             "roofline": roofline,
@@ -231,7 +233,7 @@ def main():
     if comm is not None:
         comm.destroy()
 
-    if rank == 0 and not multi and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.cpu_sample_grid, rows)
     if rank == 0:
         print(json.dumps(out))

@@ -226,7 +226,8 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
     const bool detail = config->enable_detailed_timers != 0;
     const int* skip = &s->d_s->converged;
     SpmvAmdComm* comm = s->comm;
-    const bool multi = comm->world > 1;
+    const bool multi = comm->world > 1;       // halo exchange needed
+    const bool reduce = comm->collective();   // all-reduce of the dot products needed
     memset(stats, 0, sizeof(*stats));
 
     if (s->hist_cap < config->max_iters + 1) {
@@ -269,7 +270,7 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
     timed(&stats->time_dot_rs_initial_ms, nullptr, [&] {
         launch_reduce_partials(s->partials_blas, cg_partial_count(), &s->d_s->rr_new, nullptr, s->compute);
     });
-    if (multi) comm->allreduce_sum(&s->d_s->rr_new, 1, s->compute);
+    if (reduce) comm->allreduce_sum(&s->d_s->rr_new, 1, s->compute);
     launch_cg_scalars_init(s->d_s, s->d_hist, s->compute);
     bool halo_in_flight = false;
     auto start_p_halo = [&] {  // halo rows of the new p: side stream, under the interior SpMV
@@ -303,7 +304,7 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
             slab_spmv(s, true, halo_in_flight, skip);
             HIP_CHECK(hipEventRecord(s->spmv_ev[2 * enqueued + 1], s->compute));
         }
-        if (multi) timed(&stats->time_allreduce_ms, nullptr, [&] { comm->allreduce_sum(&s->d_s->pAp, 1, s->compute); });
+        if (reduce) timed(&stats->time_allreduce_ms, nullptr, [&] { comm->allreduce_sum(&s->d_s->pAp, 1, s->compute); });
         launch_cg_scalars_alpha(s->d_s, s->compute);
         timed(&stats->time_blas1_ms, &stats->time_axpy_update_x_ms, [&] {
             launch_cg_update_xr(nl, s->d_s, s->p, s->Ap, s->x, s->r, s->partials_blas, s->compute);
@@ -311,7 +312,7 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
         timed(&stats->time_reductions_ms, &stats->time_dot_rs_new_ms, [&] {
             launch_reduce_partials(s->partials_blas, cg_partial_count(), &s->d_s->rr_new, skip, s->compute);
         });
-        if (multi) timed(&stats->time_allreduce_ms, nullptr, [&] { comm->allreduce_sum(&s->d_s->rr_new, 1, s->compute); });
+        if (reduce) timed(&stats->time_allreduce_ms, nullptr, [&] { comm->allreduce_sum(&s->d_s->rr_new, 1, s->compute); });
         launch_cg_scalars_step(s->d_s, config->tolerance, s->d_hist, s->compute);
         // 8-byte status record of this iteration, read by the host further down
         HIP_CHECK(hipMemcpyAsync(s->h_poll, &s->d_s->converged, sizeof(*s->h_poll),

@@ -2,6 +2,7 @@
 #include "comm.hpp"
 
 #include <rccl/rccl.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -189,6 +190,8 @@ extern "C" SpmvAmdComm* spmv_amd_comm_create_rccl(int rank, int world, const voi
     RcclComm* c = new RcclComm();
     c->rank = rank;
     c->world = world;
+    const char* force = getenv("SPMV_AMD_FORCE_COLLECTIVES");
+    c->force_collectives = force != nullptr && force[0] == '1';
     {
         ncclUniqueId a, b;
         memcpy(&a, id256, NCCL_UNIQUE_ID_BYTES);

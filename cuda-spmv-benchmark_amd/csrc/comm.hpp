@@ -20,6 +20,10 @@
 struct SpmvAmdComm {
     int rank = 0;
     int world = 1;
+    // Test hook (SPMV_AMD_FORCE_COLLECTIVES=1): issue the all-reduces even with one rank, so that a
+    // 1-GPU box drives the RCCL calls of the CG loop; a 1-rank all-reduce is the identity.
+    bool force_collectives = false;
+    bool collective() const { return world > 1 || force_collectives; }
     virtual ~SpmvAmdComm() {}
     // Exchanges `count` doubles with rank-1 (send_prev/recv_prev) and rank+1 (send_next/recv_next);
     // pointers are device pointers, NULL where there is no neighbour. Ordered on `stream`.

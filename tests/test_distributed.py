@@ -70,3 +70,25 @@ def test_rccl_communicator_single_rank(B, O, fresh_host_matrices):
     assert st.iterations == ro.iterations and hist_err(slab.history(), ho) < 1e-10
     slab.destroy()
     comm.destroy()
+
+
+@pytest.mark.gpu
+def test_bench_distributed_path_with_one_rank():
+    """bench.py through torch.distributed.run with one rank and the two test hooks: rendezvous,
+    unique-id broadcast, RCCL communicator creation and the all-reduces inside the CG loop all run
+    (a 1-rank all-reduce is the identity), and the result must equal the plain single-rank run."""
+    import json
+    env = dict(os.environ, SPMV_AMD_BENCH_FORCE_DIST="1", SPMV_AMD_FORCE_COLLECTIVES="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+           "--grid", "1024", "--no-cpu-baseline", "--no-spmv"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    dist_line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    plain = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--grid", "1024",
+                            "--no-cpu-baseline", "--no-spmv"], capture_output=True, text=True, timeout=600)
+    assert plain.returncode == 0, plain.stdout + plain.stderr
+    plain_line = json.loads([l for l in plain.stdout.splitlines() if l.startswith("{")][-1])
+    assert dist_line["config"]["transport"] == "rccl" and dist_line["n_gpus"] == 1
+    assert dist_line["config"]["residual_history"] == plain_line["config"]["residual_history"]
+    assert dist_line["config"]["iterations_per_solve"] == plain_line["config"]["iterations_per_solve"]
