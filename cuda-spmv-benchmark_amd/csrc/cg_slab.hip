@@ -43,6 +43,7 @@ struct SpmvAmdCgSlab {
     double* p = nullptr;        // local part, 16-byte aligned
     double* partials_spmv = nullptr;  // 3 segments of `waves` doubles: interior, head, tail
     double* partials_blas = nullptr;
+    double* reduce_stage = nullptr;
     CgScalars* d_s = nullptr;
     double* d_hist = nullptr;
     int hist_cap = 0;
@@ -72,7 +73,12 @@ void make_common(SpmvAmdCgSlab* s) {
     s->A.view.halo_before = s->has_prev ? s->halo : 0;
     s->A.view.halo_after = s->has_next ? s->halo : 0;
     HIP_CHECK(hipStreamCreateWithFlags(&s->compute, hipStreamNonBlocking));
-    HIP_CHECK(hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking));
+    {
+        // the halo exchange must get CUs while the interior SpMV saturates the chip: highest priority
+        int least = 0, greatest = 0;
+        HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        HIP_CHECK(hipStreamCreateWithPriority(&s->side, hipStreamNonBlocking, greatest));
+    }
     HIP_CHECK(hipEventCreateWithFlags(&s->ev_p_ready, hipEventDisableTiming));
     HIP_CHECK(hipEventCreateWithFlags(&s->ev_halo_done, hipEventDisableTiming));
     HIP_CHECK(hipEventCreateWithFlags(&s->ev_poll, hipEventDisableTiming));
@@ -87,7 +93,8 @@ void make_common(SpmvAmdCgSlab* s) {
     HIP_CHECK(hipMemset(s->p_alloc, 0, (lead + nl + (size_t)s->halo + 2) * sizeof(double)));
     s->shape = current_launch_shape();
     s->waves = launch_stencil5_waves(s->shape);
-    s->partials_blas = device_alloc<double>((size_t)cg_partial_count());
+    s->partials_blas = device_alloc<double>(dot_scratch_doubles());
+    s->reduce_stage = device_alloc<double>((size_t)reduce_stage_doubles());
     s->d_s = device_alloc<CgScalars>(1);
     HIP_CHECK(hipMemset(s->d_s, 0, sizeof(CgScalars)));
     HIP_CHECK(hipHostMalloc((void**)&s->h_poll, sizeof(*s->h_poll), hipHostMallocDefault));
@@ -130,15 +137,17 @@ bool partition_ok(const SpmvAmdComm* comm, int n, int grid, int n_local) {
 
 // SpMV of the slab on p (halos must be current or in flight on the side stream).
 // overlap = the halo exchange was started on the side stream and ev_halo_done marks its end.
-void slab_spmv(SpmvAmdCgSlab* s, bool with_dot, bool overlap, const int* skip) {
+void slab_spmv(SpmvAmdCgSlab* s, bool with_dot, bool overlap, const int* skip,
+               const double* input = nullptr) {
     const SlabCsr& A = s->A.view;
+    const double* in = input ? input : s->p;
     double* part = (with_dot && s->fused_dot) ? s->partials_spmv : nullptr;
     const int lo = s->has_prev ? s->halo : 0;
     const int hi = s->n_local - (s->has_next ? s->halo : 0);
     int used = 0;
     if (!overlap || hi <= lo || (lo == 0 && hi == s->n_local)) {
         if (overlap) HIP_CHECK(hipStreamWaitEvent(s->compute, s->ev_halo_done, 0));
-        used = launch_stencil5_spmv(A, s->p, s->Ap, 1.0, 0, s->n_local, part, skip, Stencil5Variant::Auto,
+        used = launch_stencil5_spmv(A, in, s->Ap, 1.0, 0, s->n_local, part, skip, Stencil5Variant::Auto,
                                     s->shape, s->compute);
     } else {
         // rows whose north and south neighbours are local first; the first / last grid row of the
@@ -155,7 +164,7 @@ void slab_spmv(SpmvAmdCgSlab* s, bool with_dot, bool overlap, const int* skip) {
     }
     if (with_dot) {
         if (part)
-            launch_reduce_partials(part, used, &s->d_s->pAp, skip, s->compute);
+            launch_reduce_partials(part, used, &s->d_s->pAp, skip, s->compute, s->reduce_stage);
         else
             launch_dot((size_t)s->n_local, s->p, s->Ap, s->partials_blas, &s->d_s->pAp, s->compute);
     }
@@ -261,14 +270,19 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
     total.begin(s->compute);
 
     // ---- r0 = b - A x0 ; p0 = r0 ; rr0 ----
-    HIP_CHECK(hipMemcpyAsync(s->p, s->x, vbytes, hipMemcpyDeviceToDevice, s->compute));
-    timed(&stats->time_allgather_ms, nullptr, [&] { exchange_p_halo(s, s->compute); });
-    slab_spmv(s, /*with_dot=*/false, /*overlap=*/false, nullptr);
+    if (multi) {
+        // x0 needs its halo rows: stage it in the halo-carrying buffer
+        HIP_CHECK(hipMemcpyAsync(s->p, s->x, vbytes, hipMemcpyDeviceToDevice, s->compute));
+        timed(&stats->time_allgather_ms, nullptr, [&] { exchange_p_halo(s, s->compute); });
+        slab_spmv(s, /*with_dot=*/false, /*overlap=*/false, nullptr);
+    } else {
+        slab_spmv(s, /*with_dot=*/false, /*overlap=*/false, nullptr, s->x);
+    }
     timed(&stats->time_initial_r_ms, nullptr, [&] {
         launch_cg_init_residual(nl, s->b, s->Ap, s->r, s->p, s->partials_blas, s->compute);
     });
     timed(&stats->time_dot_rs_initial_ms, nullptr, [&] {
-        launch_reduce_partials(s->partials_blas, cg_partial_count(), &s->d_s->rr_new, nullptr, s->compute);
+        launch_reduce_partials(s->partials_blas, cg_partial_count(), &s->d_s->rr_new, nullptr, s->compute, s->reduce_stage);
     });
     if (reduce) comm->allreduce_sum(&s->d_s->rr_new, 1, s->compute);
     launch_cg_scalars_init(s->d_s, s->d_hist, s->compute);
@@ -310,7 +324,7 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
             launch_cg_update_xr(nl, s->d_s, s->p, s->Ap, s->x, s->r, s->partials_blas, s->compute);
         });
         timed(&stats->time_reductions_ms, &stats->time_dot_rs_new_ms, [&] {
-            launch_reduce_partials(s->partials_blas, cg_partial_count(), &s->d_s->rr_new, skip, s->compute);
+            launch_reduce_partials(s->partials_blas, cg_partial_count(), &s->d_s->rr_new, skip, s->compute, s->reduce_stage);
         });
         if (reduce) timed(&stats->time_allreduce_ms, nullptr, [&] { comm->allreduce_sum(&s->d_s->rr_new, 1, s->compute); });
         launch_cg_scalars_step(s->d_s, config->tolerance, s->d_hist, s->compute);
@@ -434,6 +448,7 @@ extern "C" void spmv_amd_cg_slab_destroy(SpmvAmdCgSlab* s) {
     device_release(s->p_alloc);
     device_release(s->partials_spmv);
     device_release(s->partials_blas);
+    device_release(s->reduce_stage);
     device_release(s->d_s);
     device_release(s->d_hist);
     if (s->h_poll) (void)hipHostFree(s->h_poll);

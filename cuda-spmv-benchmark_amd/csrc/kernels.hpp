@@ -125,9 +125,11 @@ void launch_cg_update_xr(size_t n, const CgScalars* s, const double* p, const do
 void launch_cg_update_p(size_t n, const CgScalars* s, const double* r, double* p,
                         hipStream_t stream);
 int cg_partial_count();  // partial slots written by the two kernels above
-// *d_out = sum of partials[0..count) in a fixed order (single block).
+// *d_out = sum of partials[0..count) in a fixed order. `stage` (reduce_stage_doubles() doubles,
+// may be null) lets large counts be summed by many blocks first.
+int reduce_stage_doubles();
 void launch_reduce_partials(const double* partials, int count, double* d_out,
-                            const int* d_skip_flag, hipStream_t stream);
+                            const int* d_skip_flag, hipStream_t stream, double* stage = nullptr);
 // After the (all-reduced) r.r is known: b_norm (first call), residual, history, convergence
 // flag, beta, rr_old <- rr_new, iteration counter.
 void launch_cg_scalars_init(CgScalars* s, double* history, hipStream_t stream);
