@@ -131,3 +131,26 @@ def test_slab_spmv_matches_halo_oracle(B, O, fresh_host_matrices):
             assert rel_err(got, full[off:off + nl]) < 1e-12 or np.allclose(got, full[off:off + nl], rtol=1e-12, atol=1e-12)
             slab.destroy()
             comm.destroy()
+
+
+def test_reference_harness_binary_runs_on_this_library(golden):
+    """oracle/_ref/ref_cg_solver is the reference's own src/main/cg_solver.cu, unmodified, compiled
+    against this repo's include/ and linked against libspmv_amd.so (oracle/Makefile). Run it on the
+    reference's shipped matrix: its printed results must be the known answers."""
+    import re
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_cg_solver")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/ref_cg_solver not built (reference sources absent at build time)")
+    out = subprocess.run([exe, os.path.join(GOLDEN, "example81x81.mtx"), "--mode=stencil5-csr"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    text = out.stdout
+    s = golden["survey_8c"]["81:-4.0"]
+    m = re.search(r"Converged: YES in (\d+) iterations", text)
+    assert m and int(m.group(1)) == s["cg_iterations"] == 40, text[-2000:]
+    sx = float(re.search(r"Sum\(x\):\s+(\S+)", text).group(1))
+    nx = float(re.search(r"Norm2\(x\):\s+(\S+)", text).group(1))
+    assert abs(sx - s["solution_sum"]) < 1e-10 * abs(s["solution_sum"])
+    assert abs(nx - s["solution_norm"]) < 1e-10 * s["solution_norm"]
+    assert "valid runs" in text  # the reference main went through cg_benchmark_with_stats_device

@@ -1,0 +1,91 @@
+"""BASELINE.json's full-size configurations, checked through size-independent properties (the
+oracle cannot run 400 M rows inside a test): exact checksums of A*1, linearity, agreement of the
+three operators, the published 14 CG iterations, and the committed n = 10^4 golden history."""
+import numpy as np
+import pytest
+
+from conftest import hist_err
+
+pytestmark = pytest.mark.gpu
+
+
+def device_checks(B, op, n):
+    """y = A*1: interior rows 1, edges 2, corners 3 -> sum = n^2 + 4n, sum of squares closed form.
+    Returned through two CG-style reductions on the device would need more API; rows <= 2.25e8 fit
+    a host copy comfortably (1.8 GB), 4e8 too (3.2 GB)."""
+    rows = n * n
+    dx, dy = B.DeviceVector(rows, fill=1.0), B.DeviceVector(rows, fill=-1.0)
+    assert op.run_device(dx, dy) == 0
+    y = dy.to_host()
+    dx.free(), dy.free()
+    return y
+
+
+@pytest.mark.parametrize("mode,n", [("stencil5-csr", 10000), ("cusparse-csr", 10000), ("ellpack", 15000),
+                                    ("stencil5-ellpack", 15000), ("stencil5-csr", 20000)])
+def test_spmv_full_size_checksums(B, mode, n):
+    op = B.Operator(mode)
+    assert op.init_synthetic(n) == 0
+    y = device_checks(B, op, n)
+    # exact: every entry is a small integer
+    assert y.sum() == n * n + 4 * n
+    assert float(np.dot(y, y)) == (n - 2) ** 2 + 16 * (n - 2) + 36
+    counts = np.bincount(y.astype(np.int64), minlength=4)
+    assert list(counts[:4]) == [0, (n - 2) ** 2, 4 * (n - 2), 4]
+    # structure of the answer: corners 3, edges 2
+    assert y[0] == 3 and y[n - 1] == 3 and y[-1] == 3 and y[1] == 2 and y[n] == 2 and y[n + 1] == 1
+    op.free()
+
+
+def test_spmv_full_size_linearity_and_operator_agreement(B):
+    """A(a*u + b*v) == a*A(u) + b*A(v) to rounding, and stencil5-csr == cusparse-csr == ellpack on the
+    same random x at 10k (the reference's own cross-check, tests/test_wrapper_basic.cpp:159-193)."""
+    n = 10000
+    rows = n * n
+    rng = np.random.default_rng(7)
+    u, v = rng.standard_normal(rows), rng.standard_normal(rows)
+    ys = {}
+    for mode in ("stencil5-csr", "cusparse-csr", "ellpack"):
+        op = B.Operator(mode)
+        assert op.init_synthetic(n) == 0
+        yu, _ = op.run_timed(u)
+        if mode == "stencil5-csr":
+            yv, _ = op.run_timed(v)
+            yw, _ = op.run_timed(2.0 * u - 0.5 * v)
+            assert np.max(np.abs(yw - (2.0 * yu - 0.5 * yv))) <= 1e-12 * np.max(np.abs(yw))
+        ys[mode] = yu
+        op.free()
+    scale = np.max(np.abs(ys["stencil5-csr"]))
+    assert np.max(np.abs(ys["stencil5-csr"] - ys["cusparse-csr"])) <= 1e-12 * scale
+    assert np.max(np.abs(ys["stencil5-csr"] - ys["ellpack"])) <= 1e-12 * scale
+    # independent evaluation of the 5-point formula with numpy on a few grid rows
+    U = u.reshape(n, n)
+    for i in (1, n // 2, n - 2):
+        want = 5.0 * U[i, 1:-1] - U[i, :-2] - U[i, 2:] - U[i - 1, 1:-1] - U[i + 1, 1:-1]
+        got = ys["stencil5-csr"].reshape(n, n)[i, 1:-1]
+        assert np.max(np.abs(got - want)) <= 1e-12 * scale
+
+
+def test_cg_10k_matches_committed_golden_history(B, golden):
+    g = golden["cases"].get("10000:5.0")
+    if g is None:
+        pytest.skip("10k golden not generated")
+    slab = B.CgSlab.stencil5(10000)
+    st = slab.solve()
+    assert st.iterations == g["cg"]["iterations"] == 14 and st.converged == 1
+    assert hist_err(slab.history(), g["cg"]["history"]) < 1e-10
+    slab.destroy()
+
+
+def test_cg_20k_published_iteration_count_and_invariants(B):
+    """400 M unknowns: 14 iterations on every GPU count (README.md:62); ||r0|| = sqrt(n^2) exactly;
+    residuals decrease monotonically for this SPD system; the solve is bit-reproducible."""
+    n = 20000
+    slab = B.CgSlab.stencil5(n)
+    st = slab.solve()
+    h = slab.history()
+    assert st.iterations == 14 and st.converged == 1 and len(h) == 15
+    assert h[0] == float(n) and np.all(np.diff(h) < 0) and h[-1] / h[0] < 1e-6 <= h[-2] / h[0]
+    st2 = slab.solve()
+    assert st2.iterations == 14 and np.array_equal(slab.history(), h)
+    slab.destroy()
