@@ -114,7 +114,8 @@ void make_common(SpmvAmdCgSlab* s) {
         HIP_CHECK(hipMemset(s->partials_spmv, 0, (size_t)s->partials_cap * sizeof(double)));
         const char* name = stencil5_variant_name(A, 0, s->n_local, Stencil5Variant::Auto, s->shape);
         s->variant_name = name;
-        s->fused_dot = A.verified_stencil && s->grid >= 128;  // row-generic slabs use the plain dot kernel
+        // unverified / unaligned slabs run the row-generic kernel and use the plain dot kernel
+        s->fused_dot = strstr(name, "row-generic") == nullptr;
     }
     launch_fill(s->b, nl, 1.0, s->compute);   // default right-hand side b = 1
     launch_fill(s->x0, nl, 0.0, s->compute);  // default initial guess x0 = 0

@@ -28,8 +28,7 @@ def test_stencil5_csr_bit_exact_random_values(B, O, fresh_host_matrices, n):
     m = B.HostMatrix(e, n * n, n * n, n)
     op = B.Operator("stencil5-csr")
     assert op.init(m) == 0
-    expect_variant = "stencil5/column-march" if n >= 128 else "stencil5/row-generic"
-    assert op.variant() == expect_variant
+    assert op.variant() == "stencil5/row-direct"
     rp, ci, va = O.build_csr(e, n * n)
     want = O.spmv_stencil5(rp, ci, va, x, n)
     got, ms = op.run_timed(x)
@@ -40,11 +39,15 @@ def test_stencil5_csr_bit_exact_random_values(B, O, fresh_host_matrices, n):
         def __init__(self, v): self.ptr = v.ptr + 8
     assert op.run_device(Shift(dx), Shift(dy)) == 0
     assert np.array_equal(dy.to_host()[1:], want)
-    # the same matrix forced through the other kernel variants
-    for forced in ("wave-tile", "row-generic"):
+    # the same matrix forced through the other kernel variants (aligned and odd-address vectors)
+    for forced in ("column-march", "wave-tile", "row-generic"):
         op.select_variant(forced)
+        if n >= 128:
+            assert op.variant() == "stencil5/" + forced
         got2, _ = op.run_timed(x)
         assert np.array_equal(got2, want), forced
+        assert op.run_device(Shift(dx), Shift(dy)) == 0
+        assert np.array_equal(dy.to_host()[1:], want), forced
     op.select_variant(None)
     dx.free(), dy.free(), op.free()
 

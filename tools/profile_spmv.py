@@ -13,6 +13,8 @@ mode = sys.argv[1] if len(sys.argv) > 1 else "stencil5-csr"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 20000
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 op = B.Operator(mode)
+if len(sys.argv) > 4:
+    op.select_variant(sys.argv[4])
 assert op.init_synthetic(n) == 0
 dx, dy = B.DeviceVector(n * n, fill=1.0), B.DeviceVector(n * n, fill=0.0)
 ms = op.time_device(dx, dy, reps)
