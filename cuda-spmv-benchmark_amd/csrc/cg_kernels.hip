@@ -11,7 +11,10 @@
 // wave -> single-block tree), so a solve is bit-reproducible run to run; the summation order
 // differs from the reference's 256-wide blocks, which SURVEY.md section 8 allows (1e-10).
 //
-// All streaming kernels move 16 bytes per lane and use a capped grid with a grid-stride loop.
+// All streaming kernels move 16 bytes per lane, one pair per thread on a one-shot grid: on MI355X
+// that beat every capped grid-stride shape tried (tools/stream_probe.hip: p-update 1.66 ms vs
+// 1.88-2.05 ms, x/r-update 3.20 ms vs 3.33-3.47 ms at 4e8 rows). Kernels that reduce write one
+// partial per block (wave trees, then the four wave sums in wave order).
 #include "kernels.hpp"
 
 namespace spmv_amd {
@@ -19,8 +22,6 @@ namespace {
 
 constexpr int kBlock = 256;
 constexpr int kWavesPerBlock = 4;
-constexpr int kStreamBlocks = 2048;  // 256 CUs x 8 blocks: memory-bound grid cap
-constexpr int kPartials = kStreamBlocks * kWavesPerBlock;
 constexpr int kReduceStageBlocks = 256;
 
 typedef double d2 __attribute__((ext_vector_type(2)));
@@ -31,11 +32,22 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
-// Runs body(i) for pairs (2i, 2i+1) with 16-byte accesses, and the odd tail element.
+// Runs the body for this thread's pair (2i, 2i+1) with 16-byte accesses; the odd tail element is
+// handled by thread 0 of block 0 in each kernel.
 #define SPMV_AMD_STREAM_LOOP(n)                                                     \
     const size_t pairs = (n) >> 1;                                                  \
-    const size_t stride = (size_t)gridDim.x * kBlock;                               \
-    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < pairs; i += stride)
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;                     \
+    if (i < pairs)
+
+// Block partial of a per-thread value: written by thread 0 to partials[blockIdx.x].
+__device__ __forceinline__ void block_partial(double acc, double* __restrict__ partials) {
+    __shared__ double wave_part[kWavesPerBlock];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) wave_part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        partials[blockIdx.x] = ((wave_part[0] + wave_part[1]) + wave_part[2]) + wave_part[3];
+}
 
 __global__ __launch_bounds__(kBlock) void fill_kernel(double* __restrict__ d, size_t n, double value) {
     SPMV_AMD_STREAM_LOOP(n) {
@@ -111,8 +123,7 @@ __global__ __launch_bounds__(kBlock) void dot_partials_kernel(size_t n, const do
         acc = fma(xv.y, yv.y, acc);
     }
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) acc = fma(x[n - 1], y[n - 1], acc);
-    acc = wave_sum(acc);
-    if ((threadIdx.x & 63) == 0) partials[blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)] = acc;
+    block_partial(acc, partials);
 }
 
 // Single block: thread t sums partials t, t+256, ... then a 256-wide tree in LDS.
@@ -191,8 +202,7 @@ __global__ __launch_bounds__(kBlock) void cg_init_residual_kernel(size_t n, cons
         p[n - 1] = rv;
         acc = fma(rv, rv, acc);
     }
-    acc = wave_sum(acc);
-    if ((threadIdx.x & 63) == 0) partials[blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)] = acc;
+    block_partial(acc, partials);
 }
 
 __global__ __launch_bounds__(kBlock) void cg_update_xr_kernel(size_t n, const CgScalars* __restrict__ s,
@@ -224,8 +234,7 @@ __global__ __launch_bounds__(kBlock) void cg_update_xr_kernel(size_t n, const Cg
         r[n - 1] = rv;
         acc = fma(rv, rv, acc);
     }
-    acc = wave_sum(acc);
-    if ((threadIdx.x & 63) == 0) partials[blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6)] = acc;
+    block_partial(acc, partials);
 }
 
 __global__ __launch_bounds__(kBlock) void cg_update_p_kernel(size_t n, const CgScalars* __restrict__ s,
@@ -281,7 +290,7 @@ __global__ void cg_scalars_step_kernel(CgScalars* s, double tol, double* history
 
 inline unsigned stream_grid(size_t n) {
     const size_t want = ((n >> 1) + kBlock - 1) / kBlock;
-    return (unsigned)(want < 1 ? 1 : (want > (size_t)kStreamBlocks ? (size_t)kStreamBlocks : want));
+    return (unsigned)(want < 1 ? 1 : want);
 }
 
 }  // namespace
@@ -316,15 +325,15 @@ void launch_update_p_dev(size_t n, const double* r, const double* d_b, double* p
     hipLaunchKernelGGL(update_p_dev_kernel, dim3(stream_grid(n)), dim3(kBlock), 0, stream, n, r, d_b, p);
 }
 
-size_t dot_scratch_doubles() { return kPartials + kReduceStageBlocks; }
-int cg_partial_count() { return kPartials; }
+size_t dot_scratch_doubles(size_t n) { return (size_t)stream_grid(n) + kReduceStageBlocks; }
+int cg_partial_count(size_t n) { return (int)stream_grid(n); }
 
 void launch_dot(size_t n, const double* x, const double* y, double* scratch, double* d_result,
                 hipStream_t stream) {
-    // Always the full fixed grid, so that every partial slot is rewritten on every call.
-    hipLaunchKernelGGL(dot_partials_kernel, dim3(kStreamBlocks), dim3(kBlock), 0, stream, n, x, y, scratch);
-    // scratch = [kPartials partials | kReduceStageBlocks stage slots]
-    launch_reduce_partials(scratch, kPartials, d_result, nullptr, stream, scratch + kPartials);
+    // scratch = [one partial per block | kReduceStageBlocks stage slots]
+    const unsigned blocks = stream_grid(n);
+    hipLaunchKernelGGL(dot_partials_kernel, dim3(blocks), dim3(kBlock), 0, stream, n, x, y, scratch);
+    launch_reduce_partials(scratch, (int)blocks, d_result, nullptr, stream, scratch + blocks);
 }
 
 void launch_scalar_divide(const double* d_num, const double* d_den, double* d_out, hipStream_t stream) {
@@ -339,18 +348,18 @@ void launch_check_convergence(const double* d_rr_new, double b_norm, double tol,
 
 void launch_cg_init_residual(size_t n, const double* b, const double* Ap, double* r, double* p,
                              double* partials, hipStream_t stream) {
-    hipLaunchKernelGGL(cg_init_residual_kernel, dim3(kStreamBlocks), dim3(kBlock), 0, stream, n, b, Ap,
+    hipLaunchKernelGGL(cg_init_residual_kernel, dim3(stream_grid(n)), dim3(kBlock), 0, stream, n, b, Ap,
                        r, p, partials);
 }
 
 void launch_cg_update_xr(size_t n, const CgScalars* s, const double* p, const double* Ap, double* x,
                          double* r, double* partials, hipStream_t stream) {
-    hipLaunchKernelGGL(cg_update_xr_kernel, dim3(kStreamBlocks), dim3(kBlock), 0, stream, n, s, p, Ap,
+    hipLaunchKernelGGL(cg_update_xr_kernel, dim3(stream_grid(n)), dim3(kBlock), 0, stream, n, s, p, Ap,
                        x, r, partials);
 }
 
 void launch_cg_update_p(size_t n, const CgScalars* s, const double* r, double* p, hipStream_t stream) {
-    hipLaunchKernelGGL(cg_update_p_kernel, dim3(kStreamBlocks), dim3(kBlock), 0, stream, n, s, r, p);
+    hipLaunchKernelGGL(cg_update_p_kernel, dim3(stream_grid(n)), dim3(kBlock), 0, stream, n, s, r, p);
 }
 
 void launch_reduce_partials(const double* partials, int count, double* d_out, const int* d_skip_flag,

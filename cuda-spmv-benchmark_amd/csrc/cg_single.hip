@@ -37,7 +37,7 @@ struct Vectors {
         r = device_alloc<double>(n);
         p = device_alloc<double>(n);
         Ap = device_alloc<double>(n);
-        scratch = device_alloc<double>(dot_scratch_doubles());
+        scratch = device_alloc<double>(dot_scratch_doubles(n));
     }
     void release() {
         device_release(x);

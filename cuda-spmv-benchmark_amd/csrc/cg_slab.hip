@@ -93,7 +93,7 @@ void make_common(SpmvAmdCgSlab* s) {
     HIP_CHECK(hipMemset(s->p_alloc, 0, (lead + nl + (size_t)s->halo + 2) * sizeof(double)));
     s->shape = current_launch_shape();
     s->waves = launch_stencil5_waves(s->shape);
-    s->partials_blas = device_alloc<double>(dot_scratch_doubles());
+    s->partials_blas = device_alloc<double>(dot_scratch_doubles(nl));
     s->reduce_stage = device_alloc<double>((size_t)reduce_stage_doubles());
     s->d_s = device_alloc<CgScalars>(1);
     HIP_CHECK(hipMemset(s->d_s, 0, sizeof(CgScalars)));
@@ -283,7 +283,7 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
         launch_cg_init_residual(nl, s->b, s->Ap, s->r, s->p, s->partials_blas, s->compute);
     });
     timed(&stats->time_dot_rs_initial_ms, nullptr, [&] {
-        launch_reduce_partials(s->partials_blas, cg_partial_count(), &s->d_s->rr_new, nullptr, s->compute, s->reduce_stage);
+        launch_reduce_partials(s->partials_blas, cg_partial_count(nl), &s->d_s->rr_new, nullptr, s->compute, s->reduce_stage);
     });
     if (reduce) comm->allreduce_sum(&s->d_s->rr_new, 1, s->compute);
     launch_cg_scalars_init(s->d_s, s->d_hist, s->compute);
@@ -325,7 +325,7 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
             launch_cg_update_xr(nl, s->d_s, s->p, s->Ap, s->x, s->r, s->partials_blas, s->compute);
         });
         timed(&stats->time_reductions_ms, &stats->time_dot_rs_new_ms, [&] {
-            launch_reduce_partials(s->partials_blas, cg_partial_count(), &s->d_s->rr_new, skip, s->compute, s->reduce_stage);
+            launch_reduce_partials(s->partials_blas, cg_partial_count(nl), &s->d_s->rr_new, skip, s->compute, s->reduce_stage);
         });
         if (reduce) timed(&stats->time_allreduce_ms, nullptr, [&] { comm->allreduce_sum(&s->d_s->rr_new, 1, s->compute); });
         launch_cg_scalars_step(s->d_s, config->tolerance, s->d_hist, s->compute);

@@ -103,8 +103,8 @@ void launch_axpy_dev(size_t n, const double* d_a, const double* x, double* y, bo
 void launch_update_p_dev(size_t n, const double* r, const double* d_b, double* p,
                          hipStream_t stream);
 // result = sum x[i]*y[i], fixed reduction shape (deterministic run to run). scratch must
-// hold dot_scratch_doubles() doubles.
-size_t dot_scratch_doubles();
+// hold dot_scratch_doubles(n) doubles.
+size_t dot_scratch_doubles(size_t n);
 void launch_dot(size_t n, const double* x, const double* y, double* scratch, double* d_result,
                 hipStream_t stream);
 // *d_out = (*d_num) / (*d_den)   (scalar_divide_kernel, cg_solver.cu:414-419)
@@ -124,7 +124,7 @@ void launch_cg_update_xr(size_t n, const CgScalars* s, const double* p, const do
 // p = 1.0*r + beta*p (axpby form of the multi-GPU reference, cg_solver_mgpu_partitioned.cu:136-140)
 void launch_cg_update_p(size_t n, const CgScalars* s, const double* r, double* p,
                         hipStream_t stream);
-int cg_partial_count();  // partial slots written by the two kernels above
+int cg_partial_count(size_t n);  // partial slots written by the two reducing kernels above
 // *d_out = sum of partials[0..count) in a fixed order. `stage` (reduce_stage_doubles() doubles,
 // may be null) lets large counts be summed by many blocks first.
 int reduce_stage_doubles();

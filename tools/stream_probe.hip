@@ -62,6 +62,30 @@ __global__ __launch_bounds__(256) void mix_kernel(const double* __restrict__ val
     }
 }
 
+// BLAS1 shapes of the CG loop: p = r + b*p (2 reads, 1 write) and the x/r double update (4 reads, 2 writes)
+template <int UNROLL>
+__global__ __launch_bounds__(256) void upd_p(const d2* __restrict__ r, d2* __restrict__ p, size_t n2, double b, int oneshot) {
+    size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * (oneshot ? UNROLL : 1);
+    const size_t stride = oneshot ? n2 : (size_t)gridDim.x * 256;
+    if (oneshot) {
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) if (i + u < n2) { d2 rv = r[i + u], pv = p[i + u]; pv.x = fma(b, pv.x, rv.x); pv.y = fma(b, pv.y, rv.y); p[i + u] = pv; }
+    } else {
+        for (; i < n2; i += stride) { d2 rv = r[i], pv = p[i]; pv.x = fma(b, pv.x, rv.x); pv.y = fma(b, pv.y, rv.y); p[i] = pv; }
+    }
+}
+__global__ __launch_bounds__(256) void upd_xr(const d2* __restrict__ p, const d2* __restrict__ ap, d2* __restrict__ x, d2* __restrict__ r, size_t n2, double a, int oneshot, double* out) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t stride = oneshot ? n2 : (size_t)gridDim.x * 256;
+    double acc = 0;
+    for (; i < n2; i += stride) {
+        d2 pv = p[i], av = ap[i], xv = x[i], rv = r[i];
+        xv.x = fma(a, pv.x, xv.x); xv.y = fma(a, pv.y, xv.y); rv.x = fma(-a, av.x, rv.x); rv.y = fma(-a, av.y, rv.y);
+        x[i] = xv; r[i] = rv; acc = fma(rv.x, rv.x, acc); acc = fma(rv.y, rv.y, acc);
+    }
+    if (acc == 123.456) out[0] = acc;
+}
+
 template <class F> double time_ms(F&& f, int reps = 7) {
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     std::vector<float> ms;
@@ -95,6 +119,27 @@ int main(int argc, char** argv) {
             ms = time_ms([&] { hipLaunchKernelGGL(mix_kernel<1>, dim3(grid), dim3(256), 0, 0, values, x, y, ntiles, banded); });
             printf("mix lds     banded %d blocks/CU %2d : %7.3f ms  %8.1f GB/s\n", banded, bpc, ms, mixbytes / ms / 1e6);
         }
+    }
+    {
+        double *a1, *a2;
+        CK(hipMalloc(&a1, (size_t)rows * 8)); CK(hipMalloc(&a2, (size_t)rows * 8));
+        CK(hipMemset(a1, 0, (size_t)rows * 8)); CK(hipMemset(a2, 0, (size_t)rows * 8));
+        const size_t n2 = (size_t)rows / 2;
+        for (int blocks : {512, 1024, 2048, 4096, 8192}) {
+            double ms = time_ms([&] { hipLaunchKernelGGL(upd_p<1>, dim3(blocks), dim3(256), 0, 0, (const d2*)x, (d2*)y, n2, 0.5, 0); });
+            printf("upd_p  grid-stride blocks %5d : %7.3f ms  %8.1f GB/s\n", blocks, ms, rows * 24.0 / ms / 1e6);
+            ms = time_ms([&] { hipLaunchKernelGGL(upd_xr, dim3(blocks), dim3(256), 0, 0, (const d2*)x, (const d2*)y, (d2*)a1, (d2*)a2, n2, 0.5, 0, values); });
+            printf("upd_xr grid-stride blocks %5d : %7.3f ms  %8.1f GB/s\n", blocks, ms, rows * 48.0 / ms / 1e6);
+        }
+        double ms = time_ms([&] { hipLaunchKernelGGL(upd_p<1>, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, 0, (const d2*)x, (d2*)y, n2, 0.5, 1); });
+        printf("upd_p  one-shot 16 B/thread      : %7.3f ms  %8.1f GB/s\n", ms, rows * 24.0 / ms / 1e6);
+        ms = time_ms([&] { hipLaunchKernelGGL(upd_p<2>, dim3((unsigned)((n2 / 2 + 255) / 256)), dim3(256), 0, 0, (const d2*)x, (d2*)y, n2, 0.5, 1); });
+        printf("upd_p  one-shot 32 B/thread      : %7.3f ms  %8.1f GB/s\n", ms, rows * 24.0 / ms / 1e6);
+        ms = time_ms([&] { hipLaunchKernelGGL(upd_p<4>, dim3((unsigned)((n2 / 4 + 255) / 256)), dim3(256), 0, 0, (const d2*)x, (d2*)y, n2, 0.5, 1); });
+        printf("upd_p  one-shot 64 B/thread      : %7.3f ms  %8.1f GB/s\n", ms, rows * 24.0 / ms / 1e6);
+        ms = time_ms([&] { hipLaunchKernelGGL(upd_xr, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, 0, (const d2*)x, (const d2*)y, (d2*)a1, (d2*)a2, n2, 0.5, 1, values); });
+        printf("upd_xr one-shot 16 B/thread      : %7.3f ms  %8.1f GB/s\n", ms, rows * 48.0 / ms / 1e6);
+        CK(hipFree(a1)); CK(hipFree(a2));
     }
     // one tile per wave, non-persistent
     {
