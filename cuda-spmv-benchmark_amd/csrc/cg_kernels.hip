@@ -205,31 +205,24 @@ __global__ __launch_bounds__(kBlock) void cg_init_residual_kernel(size_t n, cons
     block_partial(acc, partials);
 }
 
-__global__ __launch_bounds__(kBlock) void cg_update_xr_kernel(size_t n, const CgScalars* __restrict__ s,
-                                                              const double* __restrict__ p,
-                                                              const double* __restrict__ Ap,
-                                                              double* __restrict__ x,
-                                                              double* __restrict__ r,
-                                                              double* __restrict__ partials) {
+// r -= alpha*Ap with the r.r partials (axpy_kernel(-alpha, Ap, r) + the dot, mgpu :612,627).
+__global__ __launch_bounds__(kBlock) void cg_update_r_kernel(size_t n, const CgScalars* __restrict__ s,
+                                                             const double* __restrict__ Ap,
+                                                             double* __restrict__ r,
+                                                             double* __restrict__ partials) {
     if (s->converged) return;
     const double alpha = s->alpha;
     double acc = 0.0;
     SPMV_AMD_STREAM_LOOP(n) {
-        const d2 pv = reinterpret_cast<const d2*>(p)[i];
         const d2 av = reinterpret_cast<const d2*>(Ap)[i];
-        d2 xv = reinterpret_cast<d2*>(x)[i];
         d2 rv = reinterpret_cast<d2*>(r)[i];
-        xv.x = fma(alpha, pv.x, xv.x);
-        xv.y = fma(alpha, pv.y, xv.y);
         rv.x = fma(-alpha, av.x, rv.x);
         rv.y = fma(-alpha, av.y, rv.y);
-        reinterpret_cast<d2*>(x)[i] = xv;
         reinterpret_cast<d2*>(r)[i] = rv;
         acc = fma(rv.x, rv.x, acc);
         acc = fma(rv.y, rv.y, acc);
     }
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
-        x[n - 1] = fma(alpha, p[n - 1], x[n - 1]);
         const double rv = fma(-alpha, Ap[n - 1], r[n - 1]);
         r[n - 1] = rv;
         acc = fma(rv, rv, acc);
@@ -237,19 +230,35 @@ __global__ __launch_bounds__(kBlock) void cg_update_xr_kernel(size_t n, const Cg
     block_partial(acc, partials);
 }
 
-__global__ __launch_bounds__(kBlock) void cg_update_p_kernel(size_t n, const CgScalars* __restrict__ s,
-                                                             const double* __restrict__ r,
-                                                             double* __restrict__ p) {
-    if (s->converged) return;
-    const double beta = s->beta;
+// x += alpha*p of iteration `iteration` and, unless that iteration converged, p = 1.0*r + beta*p, in
+// one pass over p (the reference reads p twice: axpy_kernel(alpha, p, x) :598 and axpby_kernel :682).
+// Same per-element arithmetic, so results are unchanged. A launch enqueued for an iteration beyond
+// the converging one finds s->iterations != iteration and does nothing.
+__global__ __launch_bounds__(kBlock) void cg_update_px_kernel(size_t n, const CgScalars* __restrict__ s,
+                                                              const double* __restrict__ r,
+                                                              double* __restrict__ p,
+                                                              double* __restrict__ x, int iteration) {
+    if (s->iterations != iteration) return;
+    const bool advance = s->converged == 0;
+    const double alpha = s->alpha, beta = s->beta;
     SPMV_AMD_STREAM_LOOP(n) {
-        const d2 rv = reinterpret_cast<const d2*>(r)[i];
         d2 pv = reinterpret_cast<d2*>(p)[i];
-        pv.x = fma(1.0, rv.x, beta * pv.x);
-        pv.y = fma(1.0, rv.y, beta * pv.y);
-        reinterpret_cast<d2*>(p)[i] = pv;
+        d2 xv = reinterpret_cast<d2*>(x)[i];
+        xv.x = fma(alpha, pv.x, xv.x);
+        xv.y = fma(alpha, pv.y, xv.y);
+        reinterpret_cast<d2*>(x)[i] = xv;
+        if (advance) {
+            const d2 rv = reinterpret_cast<const d2*>(r)[i];
+            pv.x = fma(1.0, rv.x, beta * pv.x);
+            pv.y = fma(1.0, rv.y, beta * pv.y);
+            reinterpret_cast<d2*>(p)[i] = pv;
+        }
     }
-    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) p[n - 1] = fma(1.0, r[n - 1], beta * p[n - 1]);
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        const double pv = p[n - 1];
+        x[n - 1] = fma(alpha, pv, x[n - 1]);
+        if (advance) p[n - 1] = fma(1.0, r[n - 1], beta * pv);
+    }
 }
 
 // rr_new holds the (all-reduced) initial r.r: b_norm = sqrt, history[0], rr_old.
@@ -352,14 +361,15 @@ void launch_cg_init_residual(size_t n, const double* b, const double* Ap, double
                        r, p, partials);
 }
 
-void launch_cg_update_xr(size_t n, const CgScalars* s, const double* p, const double* Ap, double* x,
-                         double* r, double* partials, hipStream_t stream) {
-    hipLaunchKernelGGL(cg_update_xr_kernel, dim3(stream_grid(n)), dim3(kBlock), 0, stream, n, s, p, Ap,
-                       x, r, partials);
+void launch_cg_update_r(size_t n, const CgScalars* s, const double* Ap, double* r, double* partials,
+                        hipStream_t stream) {
+    hipLaunchKernelGGL(cg_update_r_kernel, dim3(stream_grid(n)), dim3(kBlock), 0, stream, n, s, Ap, r, partials);
 }
 
-void launch_cg_update_p(size_t n, const CgScalars* s, const double* r, double* p, hipStream_t stream) {
-    hipLaunchKernelGGL(cg_update_p_kernel, dim3(stream_grid(n)), dim3(kBlock), 0, stream, n, s, r, p);
+void launch_cg_update_px(size_t n, const CgScalars* s, const double* r, double* p, double* x, int iteration,
+                         hipStream_t stream) {
+    hipLaunchKernelGGL(cg_update_px_kernel, dim3(stream_grid(n)), dim3(kBlock), 0, stream, n, s, r, p, x,
+                       iteration);
 }
 
 void launch_reduce_partials(const double* partials, int count, double* d_out, const int* d_skip_flag,

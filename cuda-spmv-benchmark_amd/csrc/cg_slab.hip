@@ -10,8 +10,9 @@
 //  * the direction vector p lives in ONE allocation [prev halo | local rows | next halo], so the
 //    +-grid_size neighbours of the first/last grid row are ordinary addresses and the slab kernel
 //    is the single-GPU wave-tile kernel with a row offset; RCCL receives straight into the halos;
-//  * SpMV is fused with the p.Ap partial sums; x += a p, r -= a Ap and r.r are one pass;
-//    152 -> 128 bytes per row per iteration, element-wise results unchanged;
+//  * SpMV is fused with the p.Ap partial sums; r -= a Ap carries the r.r partials; x += a p rides
+//    with the direction update p = r + b p (one pass over p instead of two);
+//    152 -> 120 bytes per row per iteration, element-wise results unchanged;
 //  * scalars (alpha, beta, the norms, the convergence flag, the iteration counter) stay in HBM;
 //    kernels of iterations enqueued past convergence see the flag and return, so the host reads
 //    one 8-byte record per iteration while the GPU is already busy with the next SpMV;
@@ -321,8 +322,8 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
         }
         if (reduce) timed(&stats->time_allreduce_ms, nullptr, [&] { comm->allreduce_sum(&s->d_s->pAp, 1, s->compute); });
         launch_cg_scalars_alpha(s->d_s, s->compute);
-        timed(&stats->time_blas1_ms, &stats->time_axpy_update_x_ms, [&] {
-            launch_cg_update_xr(nl, s->d_s, s->p, s->Ap, s->x, s->r, s->partials_blas, s->compute);
+        timed(&stats->time_blas1_ms, &stats->time_axpy_update_r_ms, [&] {
+            launch_cg_update_r(nl, s->d_s, s->Ap, s->r, s->partials_blas, s->compute);
         });
         timed(&stats->time_reductions_ms, &stats->time_dot_rs_new_ms, [&] {
             launch_reduce_partials(s->partials_blas, cg_partial_count(nl), &s->d_s->rr_new, skip, s->compute, s->reduce_stage);
@@ -338,7 +339,7 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
         // p <- r + beta p, its halo exchange, and (when overlapping) nothing else before the host
         // looks at the status: the GPU works on these while the host waits for the record.
         timed(&stats->time_blas1_ms, &stats->time_axpby_update_p_ms, [&] {
-            launch_cg_update_p(nl, s->d_s, s->r, s->p, s->compute);
+            launch_cg_update_px(nl, s->d_s, s->r, s->p, s->x, enqueued, s->compute);
         });
         start_p_halo();
         HIP_CHECK(hipEventSynchronize(s->ev_poll));
@@ -376,7 +377,7 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
     if (!fin.converged && comm->rank == 0) printf("\nMax iterations reached without convergence\n");
     if (detail && stats->iterations > 0) {
         stats->time_dot_rs_new_ms /= stats->iterations;
-        stats->time_axpy_update_x_ms /= stats->iterations;
+        stats->time_axpy_update_r_ms /= stats->iterations;
         stats->time_axpby_update_p_ms /= stats->iterations;
     }
     const int count = fin.iterations + 1 < s->hist_cap ? fin.iterations + 1 : s->hist_cap;

@@ -118,12 +118,13 @@ void launch_check_convergence(const double* d_rr_new, double b_norm, double tol,
 // r = b - Ap ; p = r ; partials of r.r
 void launch_cg_init_residual(size_t n, const double* b, const double* Ap, double* r, double* p,
                              double* partials, hipStream_t stream);
-// alpha = rr_old / pAp ; x += alpha p ; r -= alpha Ap ; partials of r.r
-void launch_cg_update_xr(size_t n, const CgScalars* s, const double* p, const double* Ap,
-                         double* x, double* r, double* partials, hipStream_t stream);
-// p = 1.0*r + beta*p (axpby form of the multi-GPU reference, cg_solver_mgpu_partitioned.cu:136-140)
-void launch_cg_update_p(size_t n, const CgScalars* s, const double* r, double* p,
+// r -= alpha Ap ; partials of r.r
+void launch_cg_update_r(size_t n, const CgScalars* s, const double* Ap, double* r, double* partials,
                         hipStream_t stream);
+// x += alpha p (the update of iteration `iteration`), then p = 1.0*r + beta*p unless that iteration
+// converged; one pass over p (axpy + axpby of cg_solver_mgpu_partitioned.cu:598,682 fused).
+void launch_cg_update_px(size_t n, const CgScalars* s, const double* r, double* p, double* x,
+                         int iteration, hipStream_t stream);
 int cg_partial_count(size_t n);  // partial slots written by the two reducing kernels above
 // *d_out = sum of partials[0..count) in a fixed order. `stage` (reduce_stage_doubles() doubles,
 // may be null) lets large counts be summed by many blocks first.
