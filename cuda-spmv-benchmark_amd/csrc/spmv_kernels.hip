@@ -367,16 +367,25 @@ __global__ __launch_bounds__(kBlock) void stencil5_colmarch_kernel(
 // by the vector L1 (every line of `values` is still fetched from HBM exactly once), dispatch-order
 // blocks keep the +-n rows L2-resident, and 8 waves/SIMD with no staging hide the latency.
 // ---------------------------------------------------------------------------------
+//
+// XCD affinity: workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 names the group
+// that shares an L2; speed only, never correctness). The launch is 1-D and block b is mapped to
+// (column block, grid row) so that a column block keeps its XCD for every grid row: the +-n rows a
+// block needs were fetched by the same XCD one grid row earlier and are L2 hits instead of
+// Infinity-Cache reads (rocprofv3: fabric reads 25.8 GB -> see profiles/ with the 2-D mapping).
 template <bool kDot>
 __global__ __launch_bounds__(kBlock) void stencil5_rowdirect_kernel(
     SlabCsr m, const double* __restrict__ x, double* __restrict__ y, double alpha, int gi_lo,
-    double* __restrict__ dot_partials, const int* __restrict__ skip_flag) {
+    int col_blocks_per_xcd, double* __restrict__ dot_partials, const int* __restrict__ skip_flag) {
     __shared__ double wave_part[kWavesPerBlock];
     if (skip_flag != nullptr && *skip_flag != 0) return;
     const int n = m.grid_size;
-    const int li = gi_lo + (int)blockIdx.y;                    // local grid row
+    const int slot = (int)(blockIdx.x >> 3);
+    const int row_in_launch = slot / col_blocks_per_xcd;
+    const int col_block = (slot - row_in_launch * col_blocks_per_xcd) * 8 + (int)(blockIdx.x & 7);
+    const int li = gi_lo + row_in_launch;                      // local grid row
     const int gi = m.row_offset / n + li;                      // global grid row
-    const int j = (int)blockIdx.x * kBlock + (int)threadIdx.x; // grid column
+    const int j = col_block * kBlock + (int)threadIdx.x;       // grid column
     double dot_acc = 0.0;
     if (j < n) {
         const long long lr = (long long)li * n + j;
@@ -402,8 +411,7 @@ __global__ __launch_bounds__(kBlock) void stencil5_rowdirect_kernel(
         if ((threadIdx.x & 63) == 0) wave_part[threadIdx.x >> 6] = dot_acc;
         __syncthreads();
         if (threadIdx.x == 0)
-            dot_partials[(size_t)blockIdx.y * gridDim.x + blockIdx.x] =
-                ((wave_part[0] + wave_part[1]) + wave_part[2]) + wave_part[3];
+            dot_partials[blockIdx.x] = ((wave_part[0] + wave_part[1]) + wave_part[2]) + wave_part[3];
     }
 }
 
@@ -654,7 +662,7 @@ Stencil5Plan plan_stencil5(const SlabCsr& m, int first_row, int last_row, Stenci
     } else if (variant == Stencil5Variant::RowDirect) {
         p.gi_lo = first_row / n;
         p.gi_hi = last_row / n;
-        p.row_blocks = (int)blocks_for(n);  // blocks per grid row
+        p.row_blocks = (((int)blocks_for(n) + 7) / 8) * 8;  // blocks per grid row, a multiple of 8 XCDs
     } else if (variant == Stencil5Variant::WaveTile) {
         p.tile_blocks = wavetile_blocks(shape);
     } else {
@@ -735,15 +743,16 @@ int launch_stencil5_spmv(const SlabCsr& m, const double* x, double* y, double al
     if (p.variant == Stencil5Variant::RowGeneric) return launch_rows(first_row, last_row, d_dot_partials);
 
     if (p.variant == Stencil5Variant::RowDirect) {
-        // blockIdx.y is limited to 65535 grid rows per launch: far above any grid that fits int32 CSR
-        const dim3 grid(p.row_blocks, p.gi_hi - p.gi_lo);
+        const long long blocks = (long long)p.row_blocks * (p.gi_hi - p.gi_lo);  // < 2^31 for any int32 CSR
+        const dim3 grid((unsigned)blocks);
+        const int per_xcd = p.row_blocks / 8;
         if (dot)
             hipLaunchKernelGGL(stencil5_rowdirect_kernel<true>, grid, dim3(kBlock), 0, stream, m, x, y, alpha,
-                               p.gi_lo, d_dot_partials, d_skip_flag);
+                               p.gi_lo, per_xcd, d_dot_partials, d_skip_flag);
         else
             hipLaunchKernelGGL(stencil5_rowdirect_kernel<false>, grid, dim3(kBlock), 0, stream, m, x, y, alpha,
-                               p.gi_lo, d_dot_partials, d_skip_flag);
-        return (int)(grid.x * grid.y);
+                               p.gi_lo, per_xcd, d_dot_partials, d_skip_flag);
+        return (int)blocks;
     }
 
     const bool vec_xy = aligned16(x) && aligned16(y);
