@@ -368,41 +368,70 @@ __global__ __launch_bounds__(kBlock) void stencil5_colmarch_kernel(
 // blocks keep the +-n rows L2-resident, and 8 waves/SIMD with no staging hide the latency.
 // ---------------------------------------------------------------------------------
 //
-// XCD affinity: workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 names the group
-// that shares an L2; speed only, never correctness). The launch is 1-D and block b is mapped to
-// (column block, grid row) so that a column block keeps its XCD for every grid row: the +-n rows a
-// block needs were fetched by the same XCD one grid row earlier and are L2 hits instead of
-// Infinity-Cache reads (rocprofv3: fabric reads 25.8 GB -> see profiles/ with the 2-D mapping).
-template <bool kDot>
+// kRows consecutive grid rows per thread (same column): the centre row of one step is the north
+// row of the next, so x costs (kRows + 2) / kRows cache-served row loads per row instead of 3.
+//
+// Block order: a 1-D launch walked in dispatch order, column block fastest. Two XCD-affine
+// mappings (column blocks pinned to an XCD, interleaved or as contiguous bands) were measured and
+// rejected: they cut the fabric reads from 25.8 GB to 19.3 GB per launch at 20 000^2 (the +-n rows
+// become L2 hits instead of Infinity-Cache hits) but ran 4.49-4.58 ms against 4.08 ms in the CG
+// loop; the plain order keeps all eight XCDs on one moving front of the arrays.
+template <int kRows, bool kDot>
 __global__ __launch_bounds__(kBlock) void stencil5_rowdirect_kernel(
     SlabCsr m, const double* __restrict__ x, double* __restrict__ y, double alpha, int gi_lo,
-    int col_blocks_per_xcd, double* __restrict__ dot_partials, const int* __restrict__ skip_flag) {
+    int gi_hi, int col_blocks, double* __restrict__ dot_partials, const int* __restrict__ skip_flag) {
     __shared__ double wave_part[kWavesPerBlock];
     if (skip_flag != nullptr && *skip_flag != 0) return;
     const int n = m.grid_size;
-    const int slot = (int)(blockIdx.x >> 3);
-    const int row_in_launch = slot / col_blocks_per_xcd;
-    const int col_block = (slot - row_in_launch * col_blocks_per_xcd) * 8 + (int)(blockIdx.x & 7);
-    const int li = gi_lo + row_in_launch;                      // local grid row
-    const int gi = m.row_offset / n + li;                      // global grid row
+    const int row_group = (int)blockIdx.x / col_blocks;
+    const int col_block = (int)blockIdx.x - row_group * col_blocks;
+    const int li0 = gi_lo + row_group * kRows;                 // first local grid row of this block
+    const int gfirst = m.row_offset / n;
     const int j = col_block * kBlock + (int)threadIdx.x;       // grid column
     double dot_acc = 0.0;
     if (j < n) {
-        const long long lr = (long long)li * n + j;
-        double sum;
-        if (gi > 0 && gi < n - 1 && j > 0 && j < n - 1) {
-            const double* __restrict__ v = m.values + (stencil_gridrow_base(gi, n) + 5LL * j - 1 - m.nnz_base);
-            const double* __restrict__ xl = x + lr;
-            sum = v[1] * xl[-1];
-            sum = fma(v[2], xl[0], sum);
-            sum = fma(v[3], xl[1], sum);
-            sum = fma(v[0], xl[-n], sum);
-            sum = fma(v[4], xl[n], sum);
-        } else {
-            sum = row_reference<false>(m, x, (int)lr, gi, j);
+        const bool col_interior = j > 0 && j < n - 1;
+        double xn = 0.0, xc = 0.0;
+        if (kRows > 1) {
+            const double* __restrict__ x0 = x + ((long long)li0 * n + j);
+            xc = x0[0];
+            if (gfirst + li0 > 0) xn = x0[-n];
         }
-        if (kDot) dot_acc = x[lr] * sum;
-        y[lr] = alpha * sum;
+#pragma unroll
+        for (int k = 0; k < kRows; ++k) {
+            const int li = li0 + k;
+            if (li < gi_hi) {
+                const int gi = gfirst + li;
+                const long long lr = (long long)li * n + j;
+                const double* __restrict__ xl = x + lr;
+                double sum, centre;
+                if (col_interior && gi > 0 && gi < n - 1) {
+                    const double* __restrict__ v =
+                        m.values + (stencil_gridrow_base(gi, n) + 5LL * j - 1 - m.nnz_base);
+                    const double xs = xl[n];
+                    centre = kRows > 1 ? xc : xl[0];
+                    const double north = kRows > 1 ? xn : xl[-n];
+                    sum = v[1] * xl[-1];
+                    sum = fma(v[2], centre, sum);
+                    sum = fma(v[3], xl[1], sum);
+                    sum = fma(v[0], north, sum);
+                    sum = fma(v[4], xs, sum);
+                    if (kRows > 1) {
+                        xn = xc;
+                        xc = xs;
+                    }
+                } else {
+                    sum = row_reference<false>(m, x, (int)lr, gi, j);
+                    centre = xl[0];
+                    if (kRows > 1) {
+                        xn = centre;
+                        if (k + 1 < kRows && li + 1 < gi_hi) xc = xl[n];
+                    }
+                }
+                if (kDot) dot_acc = fma(centre, sum, dot_acc);
+                y[lr] = alpha * sum;
+            }
+        }
     }
     if (kDot) {
         // one partial per block: wave tree, then the four wave sums in wave order
@@ -662,7 +691,9 @@ Stencil5Plan plan_stencil5(const SlabCsr& m, int first_row, int last_row, Stenci
     } else if (variant == Stencil5Variant::RowDirect) {
         p.gi_lo = first_row / n;
         p.gi_hi = last_row / n;
-        p.row_blocks = (((int)blocks_for(n) + 7) / 8) * 8;  // blocks per grid row, a multiple of 8 XCDs
+        p.row_blocks = (int)blocks_for(n);  // column blocks per grid row
+        p.rows_per_task = env_int("SPMV_AMD_DIRECT_ROWS", 1);
+        if (p.rows_per_task != 2 && p.rows_per_task != 4) p.rows_per_task = 1;
     } else if (variant == Stencil5Variant::WaveTile) {
         p.tile_blocks = wavetile_blocks(shape);
     } else {
@@ -699,7 +730,8 @@ int stencil5_partials_needed(const SlabCsr& m, int first_row, int last_row, Sten
                              const LaunchShape& shape) {
     const Stencil5Plan p = plan_stencil5(m, first_row, last_row, variant, shape);
     if (p.variant == Stencil5Variant::RowGeneric) return p.row_blocks * kWavesPerBlock;
-    if (p.variant == Stencil5Variant::RowDirect) return p.row_blocks * (p.gi_hi - p.gi_lo);
+    if (p.variant == Stencil5Variant::RowDirect)
+        return p.row_blocks * ((p.gi_hi - p.gi_lo + p.rows_per_task - 1) / p.rows_per_task);
     if (p.variant == Stencil5Variant::WaveTile) return p.tile_blocks * kWavesPerBlock;
     return (p.march_blocks + (p.head_rows ? p.row_blocks : 0) + (p.tail_rows ? p.row_blocks : 0)) * kWavesPerBlock;
 }
@@ -743,15 +775,23 @@ int launch_stencil5_spmv(const SlabCsr& m, const double* x, double* y, double al
     if (p.variant == Stencil5Variant::RowGeneric) return launch_rows(first_row, last_row, d_dot_partials);
 
     if (p.variant == Stencil5Variant::RowDirect) {
-        const long long blocks = (long long)p.row_blocks * (p.gi_hi - p.gi_lo);  // < 2^31 for any int32 CSR
+        const int groups = (p.gi_hi - p.gi_lo + p.rows_per_task - 1) / p.rows_per_task;
+        const long long blocks = (long long)p.row_blocks * groups;  // < 2^31 for any int32 CSR
         const dim3 grid((unsigned)blocks);
-        const int per_xcd = p.row_blocks / 8;
-        if (dot)
-            hipLaunchKernelGGL(stencil5_rowdirect_kernel<true>, grid, dim3(kBlock), 0, stream, m, x, y, alpha,
-                               p.gi_lo, per_xcd, d_dot_partials, d_skip_flag);
-        else
-            hipLaunchKernelGGL(stencil5_rowdirect_kernel<false>, grid, dim3(kBlock), 0, stream, m, x, y, alpha,
-                               p.gi_lo, per_xcd, d_dot_partials, d_skip_flag);
+#define SPMV_AMD_LAUNCH_DIRECT(R, DOT)                                                                  \
+    hipLaunchKernelGGL((stencil5_rowdirect_kernel<R, DOT>), grid, dim3(kBlock), 0, stream, m, x, y, alpha, \
+                       p.gi_lo, p.gi_hi, p.row_blocks, d_dot_partials, d_skip_flag)
+        if (p.rows_per_task == 4) {
+            if (dot) SPMV_AMD_LAUNCH_DIRECT(4, true);
+            else SPMV_AMD_LAUNCH_DIRECT(4, false);
+        } else if (p.rows_per_task == 2) {
+            if (dot) SPMV_AMD_LAUNCH_DIRECT(2, true);
+            else SPMV_AMD_LAUNCH_DIRECT(2, false);
+        } else {
+            if (dot) SPMV_AMD_LAUNCH_DIRECT(1, true);
+            else SPMV_AMD_LAUNCH_DIRECT(1, false);
+        }
+#undef SPMV_AMD_LAUNCH_DIRECT
         return (int)blocks;
     }
 
