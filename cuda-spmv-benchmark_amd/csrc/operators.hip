@@ -131,15 +131,7 @@ void stencil_free() {
 // ---- cusparse-csr ----------------------------------------------------------------
 
 const char* csr_variant_name(CsrVariant v, const SlabCsr& m) {
-    if (v == CsrVariant::Auto) {
-        const double avg = m.n_local > 0 ? (double)m.nnz_local / m.n_local : 0.0;
-        v = avg <= 2.0    ? CsrVariant::RowScalar
-            : avg <= 4.0  ? CsrVariant::SubWave4
-            : avg <= 8.0  ? CsrVariant::SubWave8
-            : avg <= 16.0 ? CsrVariant::SubWave16
-            : avg <= 32.0 ? CsrVariant::SubWave32
-                          : CsrVariant::Wavefront;
-    }
+    if (v == CsrVariant::Auto) v = csr_auto_variant(m);
     switch (v) {
         case CsrVariant::RowScalar: return "csr/row-scalar";
         case CsrVariant::SubWave4: return "csr/subwave4";
