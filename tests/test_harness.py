@@ -1,0 +1,67 @@
+"""The harness binaries (cuda-spmv-benchmark_amd/apps): same command lines, checksums and JSON keys
+as the reference's spmv_bench / cg_solver / cg_solver_mgpu_stencil."""
+import json
+import os
+import re
+import subprocess
+
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+BIN = os.path.join(ROOT, "cuda-spmv-benchmark_amd", "bin")
+
+
+def run(args, **kw):
+    return subprocess.run(args, capture_output=True, text=True, timeout=600, **kw)
+
+
+def test_binaries_exist_and_print_usage(B):
+    for exe in ("spmv_bench", "cg_solver", "cg_solver_mgpu_stencil"):
+        path = os.path.join(BIN, exe)
+        assert os.path.exists(path), f"{exe} not built (make -C cuda-spmv-benchmark_amd)"
+        out = run([path])
+        assert out.returncode != 0 and "Usage" in (out.stdout + out.stderr)
+    out = run([os.path.join(BIN, "spmv_bench"), os.path.join(GOLDEN, "example81x81.mtx"), "--mode=nonsense"])
+    assert out.returncode != 0 and "Unknown mode" in out.stderr  # modes are validated before the matrix is read
+
+
+@pytest.mark.gpu
+def test_spmv_bench_on_shipped_matrix(tmp_path):
+    js = tmp_path / "res.json"
+    out = run([os.path.join(BIN, "spmv_bench"), os.path.join(GOLDEN, "example81x81.mtx"),
+               "--mode=cusparse-csr,stencil5-csr,ellpack", f"--json={js}", f"--csv={tmp_path / 'res.csv'}"])
+    assert out.returncode == 0, out.stdout + out.stderr
+    sums = re.findall(r"Sum\(y\):\s+(\S+)", out.stdout)
+    assert len(sums) == 3 and all(float(s) == -52164.0 for s in sums)
+    for mode in ("cusparse-csr", "stencil5-csr", "ellpack"):
+        d = json.load(open(tmp_path / f"res_{mode}.json"))
+        assert d["benchmark"]["operator"] == mode and d["benchmark"]["matrix"]["nnz"] == 32481
+        assert d["benchmark"]["performance"]["execution_time_ms"] > 0  # key scraped by scripts/run_all.sh
+        assert d["benchmark"]["validation"]["sum_y"] == -52164.0
+        assert os.path.exists(tmp_path / f"res_{mode}.csv")
+
+
+@pytest.mark.gpu
+def test_cg_solver_binary(tmp_path):
+    out = run([os.path.join(BIN, "cg_solver"), "--stencil=81", "--mode=stencil5-csr,cusparse-csr", f"--json={tmp_path / 'cg.json'}"])
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert re.findall(r"Converged: YES in (\d+) iterations", out.stdout) == ["18", "18"]
+    d = json.load(open(tmp_path / "cg_stencil5-csr.json"))
+    assert d["convergence"]["iterations"] == 18 and d["timing"]["median_ms"] > 0 and d["statistics"]["valid_runs"] >= 3
+    host = run([os.path.join(BIN, "cg_solver"), os.path.join(GOLDEN, "example81x81.mtx"), "--host"])
+    assert host.returncode == 0 and "Converged: YES in 40 iterations" in host.stdout
+
+
+@pytest.mark.gpu
+def test_cg_solver_mgpu_binary_single_rank(tmp_path):
+    js = tmp_path / "m.json"
+    out = run([os.path.join(BIN, "cg_solver_mgpu_stencil"), "--stencil=300", "--runs=5", f"--json={js}"])
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "Converged: YES in 17 iterations" in out.stdout
+    d = json.load(open(js))
+    assert d["num_gpus"] == 1 and d["convergence"]["iterations"] == 17 and d["timing"]["median_ms"] > 0
+    mtx = run([os.path.join(BIN, "cg_solver_mgpu_stencil"), os.path.join(GOLDEN, "example81x81.mtx"), "--runs=3"])
+    assert mtx.returncode == 0 and "Converged: YES in 40 iterations" in mtx.stdout
+    s = float(re.search(r"Sum\(x\):\s+(\S+)", mtx.stdout).group(1))
+    assert abs(s - (-8.2608388842537738e+02)) < 1e-8
