@@ -20,7 +20,7 @@ configuration of reference docs/PROBLEM_SIZE_SCALING_RESULTS.md:40-47, on N row 
             + 10 timed launches, >2 sigma outliers dropped, median -> "effective" GB/s by both of
             the reference's byte formulas (spmv_metrics.cu:85-101 and the published 12*nnz+16*rows).
   cpu_baseline  (N = 1, rank 0) the serial C oracle's CG (oracle/spmv_oracle.c, 1 core) on a
-            bounded sample, scaled by rows to the 400 M-unknown problem.
+            bounded sample (10 000 x 10 000 = 1/4 of the rows, ~10 s), scaled by rows to the 400 M-unknown problem.
 
 Multi-GPU: launched by torch.distributed.run with one rank per GPU. torch.distributed (gloo) is
 used only for rendezvous, the unique-id broadcast, barriers and the max-over-ranks; the data path
@@ -119,7 +119,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--grid", type=int, default=20000, help="n of the n x n stencil (default: the 400M-unknown headline)")
-    ap.add_argument("--cpu-sample-grid", type=int, default=5000)
+    ap.add_argument("--cpu-sample-grid", type=int, default=10000, help="grid of the CPU-baseline sample (10000: ~10 s on one core)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-spmv", action="store_true", help="skip the N=1 SpMV headline leg")
     args = ap.parse_args()

@@ -42,7 +42,7 @@ struct SpmvAmdCgSlab {
     double *x = nullptr, *x0 = nullptr, *r = nullptr, *Ap = nullptr, *b = nullptr;
     double* p_alloc = nullptr;  // [pad | prev halo | local | next halo]
     double* p = nullptr;        // local part, 16-byte aligned
-    double* partials_spmv = nullptr;  // 3 segments of `waves` doubles: interior, head, tail
+    double* partials_spmv = nullptr;  // dot partials of the SpMV launches (interior, head, tail back to back)
     double* partials_blas = nullptr;
     double* reduce_stage = nullptr;
     CgScalars* d_s = nullptr;
@@ -51,7 +51,6 @@ struct SpmvAmdCgSlab {
     struct Poll { int converged; int iterations; }* h_poll = nullptr;  // pinned
     hipStream_t compute = nullptr, side = nullptr;
     hipEvent_t ev_p_ready = nullptr, ev_halo_done = nullptr, ev_poll = nullptr;
-    int waves = 0;
     LaunchShape shape;
     int partials_cap = 0;
     const char* variant_name = "";
@@ -93,7 +92,6 @@ void make_common(SpmvAmdCgSlab* s) {
     s->p = s->p_alloc + lead;
     HIP_CHECK(hipMemset(s->p_alloc, 0, (lead + nl + (size_t)s->halo + 2) * sizeof(double)));
     s->shape = current_launch_shape();
-    s->waves = launch_stencil5_waves(s->shape);
     s->partials_blas = device_alloc<double>(dot_scratch_doubles(nl));
     s->reduce_stage = device_alloc<double>((size_t)reduce_stage_doubles());
     s->d_s = device_alloc<CgScalars>(1);

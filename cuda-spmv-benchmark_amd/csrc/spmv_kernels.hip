@@ -724,8 +724,6 @@ Stencil5Plan plan_stencil5(const SlabCsr& m, int first_row, int last_row, Stenci
 }
 }  // namespace
 
-int launch_stencil5_waves(const LaunchShape& shape) { return wavetile_blocks(shape) * kWavesPerBlock; }
-
 int stencil5_partials_needed(const SlabCsr& m, int first_row, int last_row, Stencil5Variant variant,
                              const LaunchShape& shape) {
     const Stencil5Plan p = plan_stencil5(m, first_row, last_row, variant, shape);
