@@ -162,11 +162,27 @@ def main():
     if world == 1 and not args.no_spmv:
         spmv = spmv_headline(B, n)
 
-    comm = None
+    comm, transport = None, "single rank (no communicator)"
     if multi:
         box = [B.Comm.unique_id() if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
         comm = B.Comm.rccl(rank, world, box[0])
+        # every rank must have its RCCL communicators and pass the collective self-test (all-reduce,
+        # neighbour send/recv, barrier); otherwise all ranks switch together to the staged transport
+        ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok[0]) == 1:
+            ok = torch.tensor([1 if comm.selftest() == 0 else 0], dtype=torch.int32)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok[0]) == 1:
+            transport = "rccl"
+        else:
+            if comm is not None:
+                comm.destroy()
+            comm = B.Comm.staged_over_torch(rank, world, dist)
+            transport = "staged over torch.distributed/gloo (RCCL unavailable on this node)"
+            if rank == 0:
+                print("bench.py: RCCL communicator unusable, using the host-staged transport", file=sys.stderr)
     slab = B.CgSlab.stencil5(n, comm)
 
     iterations = None
@@ -223,7 +239,7 @@ def main():
             "baseline_note": "reference's published CG iters/s on the same problem at the same GPU count, A100-SXM4-80GB (BASELINE.md); no MI355X number is published",
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"CG on the {n}x{n} 5-point stencil ({rows} unknowns, {nnz} nnz), b=1, x0=0, tol 1e-6",
-                       "grid": n, "unknowns": rows, "nnz": nnz, "partition": f"{world} row slab(s)", "transport": "rccl" if multi else "single rank (no communicator)",
+                       "grid": n, "unknowns": rows, "nnz": nnz, "partition": f"{world} row slab(s)", "transport": transport,
                        "iterations_per_solve": iterations, "converged": bool(st.converged), "final_residual": st.residual_norm,
                        "residual_history": [float(v) for v in hist]},
             "roofline": roofline,

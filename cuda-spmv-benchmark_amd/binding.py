@@ -346,9 +346,65 @@ class Comm:
 
     @classmethod
     def rccl(cls, rank, world, id_bytes):
+        """RCCL communicator, or None if RCCL could not create it."""
         buf = C.create_string_buffer(bytes(id_bytes), COMM_ID_BYTES)
         h = lib().spmv_amd_comm_create_rccl(rank, world, buf)
-        return cls(h)
+        return cls(h) if h else None
+
+    @classmethod
+    def staged_over_torch(cls, rank, world, dist):
+        """Staged communicator whose host exchange is torch.distributed (CPU tensors, e.g. gloo):
+        the transport of the multi-rank tests on a 1-GPU box, and bench.py's way out if RCCL
+        cannot be initialised."""
+        import torch
+
+        def as_np(ptr, count):
+            return np.ctypeslib.as_array(ptr, shape=(count,))
+
+        def halo_cb(user, sp, sn, rp_, rn_, count):
+            reqs, prev, nxt = [], None, None
+            if rank > 0:
+                prev = torch.zeros(count, dtype=torch.float64)
+                reqs += [dist.isend(torch.from_numpy(as_np(sp, count).copy()), rank - 1), dist.irecv(prev, rank - 1)]
+            if rank < world - 1:
+                nxt = torch.zeros(count, dtype=torch.float64)
+                reqs += [dist.isend(torch.from_numpy(as_np(sn, count).copy()), rank + 1), dist.irecv(nxt, rank + 1)]
+            for r in reqs:
+                r.wait()
+            if prev is not None:
+                as_np(rp_, count)[:] = prev.numpy()
+            if nxt is not None:
+                as_np(rn_, count)[:] = nxt.numpy()
+            return 0
+
+        def allreduce_cb(user, buf, count):
+            a = as_np(buf, count)
+            t = torch.from_numpy(a.copy())
+            dist.all_reduce(t)
+            a[:] = t.numpy()
+            return 0
+
+        def gather_cb(user, send, n_send, recv, counts, displs):
+            mine = torch.from_numpy(as_np(send, n_send).copy())
+            if rank == 0:
+                out = as_np(recv, sum(counts[r] for r in range(world)))
+                out[displs[0]:displs[0] + counts[0]] = mine.numpy()
+                for r in range(1, world):
+                    t = torch.zeros(counts[r], dtype=torch.float64)
+                    dist.recv(t, r)
+                    out[displs[r]:displs[r] + counts[r]] = t.numpy()
+            else:
+                dist.send(mine, 0)
+            return 0
+
+        def barrier_cb(user):
+            dist.barrier()
+            return 0
+
+        return cls.staged(rank, world, halo_cb, allreduce_cb, gather_cb, barrier_cb)
+
+    def selftest(self):
+        return lib().spmv_amd_comm_selftest(self.handle)
 
     @classmethod
     def staged(cls, rank, world, halo, allreduce, gather=None, barrier=None):

@@ -193,11 +193,18 @@ extern "C" SpmvAmdComm* spmv_amd_comm_create_rccl(int rank, int world, const voi
     const char* force = getenv("SPMV_AMD_FORCE_COLLECTIVES");
     c->force_collectives = force != nullptr && force[0] == '1';
     {
+        // Creation failures are reported to the caller (NULL), who may choose another transport;
+        // failures later, inside a solve, end the process like every HIP error does.
         ncclUniqueId a, b;
         memcpy(&a, id256, NCCL_UNIQUE_ID_BYTES);
         memcpy(&b, (const char*)id256 + NCCL_UNIQUE_ID_BYTES, NCCL_UNIQUE_ID_BYTES);
-        RCCL_CHECK(ncclCommInitRank(&c->p2p, world, a, rank));
-        RCCL_CHECK(ncclCommInitRank(&c->coll, world, b, rank));
+        ncclResult_t rc = ncclCommInitRank(&c->p2p, world, a, rank);
+        if (rc == ncclSuccess) rc = ncclCommInitRank(&c->coll, world, b, rank);
+        if (rc != ncclSuccess) {
+            fprintf(stderr, "[comm/rccl] rank %d: communicator creation failed: %s\n", rank, ncclGetErrorString(rc));
+            delete c;
+            return nullptr;
+        }
     }
     return c;
 }
@@ -230,6 +237,7 @@ extern "C" int spmv_amd_comm_size(const SpmvAmdComm* comm) { return comm ? comm-
 
 extern "C" int spmv_amd_comm_selftest(SpmvAmdComm* comm) {
     if (comm == nullptr) comm = &g_self;
+    // all-reduce: value rank+1 on every rank
     double mine = (double)(comm->rank + 1), got = 0.0;
     double* d = device_alloc<double>(1);
     HIP_CHECK(hipMemcpy(d, &mine, sizeof mine, hipMemcpyHostToDevice));
@@ -237,7 +245,23 @@ extern "C" int spmv_amd_comm_selftest(SpmvAmdComm* comm) {
     HIP_CHECK(hipStreamSynchronize(nullptr));
     HIP_CHECK(hipMemcpy(&got, d, sizeof got, hipMemcpyDeviceToHost));
     device_release(d);
+    int bad = got != 0.5 * comm->world * (comm->world + 1);
+    // neighbour exchange: every rank sends 64 doubles carrying its rank both ways
+    if (comm->world > 1) {
+        const int count = 64;
+        std::vector<double> h(4 * count, -1.0);
+        for (int i = 0; i < 2 * count; ++i) h[i] = (double)comm->rank;
+        double* buf = device_alloc<double>(4 * count);  // [send_prev | send_next | recv_prev | recv_next]
+        HIP_CHECK(hipMemcpy(buf, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice));
+        comm->halo_exchange(buf, buf + count, buf + 2 * count, buf + 3 * count, count, nullptr);
+        HIP_CHECK(hipStreamSynchronize(nullptr));
+        HIP_CHECK(hipMemcpy(h.data(), buf, h.size() * sizeof(double), hipMemcpyDeviceToHost));
+        device_release(buf);
+        for (int i = 0; i < count; ++i) {
+            if (comm->rank > 0 && h[2 * count + i] != (double)(comm->rank - 1)) bad = 1;
+            if (comm->rank < comm->world - 1 && h[3 * count + i] != (double)(comm->rank + 1)) bad = 1;
+        }
+    }
     comm->barrier();
-    const double want = 0.5 * comm->world * (comm->world + 1);
-    return got == want ? 0 : 1;
+    return bad;
 }

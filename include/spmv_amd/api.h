@@ -218,6 +218,7 @@ typedef int (*SpmvAmdHostBarrierFn)(void* user);
 int spmv_amd_comm_unique_id(void* out_id256);
 /* One process per GPU: RCCL communicator over xGMI; halo rows travel by
  * ncclSend/ncclRecv on a side stream, dot products by ncclAllReduce. */
+/* Returns NULL if RCCL cannot create the communicators. */
 SpmvAmdComm* spmv_amd_comm_create_rccl(int rank, int world, const void* id256);
 SpmvAmdComm* spmv_amd_comm_create_staged(int rank, int world, SpmvAmdHostHaloFn halo,
                                          SpmvAmdHostAllreduceFn allreduce,
@@ -228,8 +229,9 @@ void spmv_amd_comm_destroy(SpmvAmdComm* comm);
 void spmv_amd_comm_set_world(SpmvAmdComm* comm);
 int spmv_amd_comm_rank(const SpmvAmdComm* comm);
 int spmv_amd_comm_size(const SpmvAmdComm* comm);
-/* Runs one all-reduce and one barrier through the communicator and checks the sum
- * (value rank+1 on every rank -> world*(world+1)/2); 0 on success. */
+/* Runs one all-reduce (value rank+1 on every rank -> world*(world+1)/2), one neighbour exchange
+ * (64 doubles carrying the sender's rank, both ways) and one barrier through the communicator and
+ * checks what arrived; 0 on success. Collective: every rank must call it. */
 int spmv_amd_comm_selftest(SpmvAmdComm* comm);
 
 /* ---- resident multi-GPU CG (what cg_solve_mgpu_partitioned is built from) ---- */

@@ -85,41 +85,8 @@ def run_gpu(n, rank, world, synthetic):
     B = load_binding()
     B.lib()
 
-    def halo_cb(user, sp, sn, rp_, rn_, count):
-        first = torch.from_numpy(np.ctypeslib.as_array(sp, shape=(count,)).copy()) if sp else None
-        last = torch.from_numpy(np.ctypeslib.as_array(sn, shape=(count,)).copy()) if sn else None
-        prev, nxt = exchange_halo(rank, world, first, last)
-        if prev is not None:
-            np.ctypeslib.as_array(rp_, shape=(count,))[:] = prev.numpy()
-        if nxt is not None:
-            np.ctypeslib.as_array(rn_, shape=(count,))[:] = nxt.numpy()
-        return 0
-
-    def allreduce_cb(user, buf, count):
-        a = np.ctypeslib.as_array(buf, shape=(count,))
-        t = torch.from_numpy(a.copy())
-        dist.all_reduce(t)
-        a[:] = t.numpy()
-        return 0
-
-    def gather_cb(user, send, n_send, recv, counts, displs):
-        mine = torch.from_numpy(np.ctypeslib.as_array(send, shape=(n_send,)).copy())
-        if rank == 0:
-            out = np.ctypeslib.as_array(recv, shape=(sum(counts[r] for r in range(world)),))
-            out[displs[0]:displs[0] + counts[0]] = mine.numpy()
-            for r in range(1, world):
-                t = torch.zeros(counts[r], dtype=torch.float64)
-                dist.recv(t, r)
-                out[displs[r]:displs[r] + counts[r]] = t.numpy()
-        else:
-            dist.send(mine, 0)
-        return 0
-
-    def barrier_cb(user):
-        dist.barrier()
-        return 0
-
-    comm = B.Comm.staged(rank, world, halo_cb, allreduce_cb, gather_cb, barrier_cb)
+    comm = B.Comm.staged_over_torch(rank, world, dist)
+    assert comm.selftest() == 0  # all-reduce + neighbour exchange + barrier through the communicator
     N = n * n
     if synthetic:
         slab = B.CgSlab.stencil5(n, comm)
