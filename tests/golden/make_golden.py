@@ -11,7 +11,7 @@
                          the values recorded in SURVEY.md section 8c (computed there by an
                          independent numpy/scipy restatement), which the oracle must reproduce.
 
-Run from the repo root:  python tests/golden/make_golden.py [--with-10k]
+Run from the repo root:  python tests/golden/make_golden.py [--with-10k] [--with-20k] [--out=<json>]
 """
 import hashlib
 import json
@@ -71,11 +71,16 @@ def main():
         info["matches_reference_file"] = True
     path = os.path.join(HERE, "known_answers.json")
     old = json.load(open(path)) if os.path.exists(path) else {}
+    for a in sys.argv:
+        if a.startswith("--out="):
+            path = a[len("--out="):]
     cases = dict(old.get("cases", {}))
     for n, c in ((3, -4.0), (3, 5.0), (81, -4.0), (81, 5.0), (512, 5.0), (2000, 5.0)):
         cases[f"{n}:{c}"] = case(n, c, -1.0)
     if "--with-10k" in sys.argv:
         cases["10000:5.0"] = case(10000, 5.0, -1.0)
+    if "--with-20k" in sys.argv:  # needs ~45 GB of host memory and about a minute: run on the GPU box's host
+        cases["20000:5.0"] = case(20000, 5.0, -1.0)
     info["cases"] = cases
     # values quoted in SURVEY.md section 8c from an independent restatement
     info["survey_8c"] = {

@@ -160,3 +160,44 @@ def test_reference_harness_binary_runs_on_this_library(O):
     assert abs(sx - r2.solution_sum) <= 1e-10 * abs(r2.solution_sum)
     assert abs(nx - r2.solution_norm) <= 1e-10 * r2.solution_norm
     assert "valid runs" in text  # the reference main went through cg_benchmark_with_stats_device
+
+
+def test_slab_solver_on_a_general_spd_matrix(B, O, fresh_host_matrices):
+    """No stencil announced (grid_size = -1): the slab solver runs the CSR loop for every row and the
+    plain dot kernel; results still match the oracle's CG on the same matrix."""
+    n = 400
+    rng = np.random.default_rng(12)
+    rows, cols, vals = [], [], []
+    for i in range(n):  # symmetric, strictly diagonally dominant => SPD
+        for j in rng.choice(n, size=4, replace=False):
+            if j != i:
+                v = float(rng.uniform(-1.0, 1.0))
+                rows += [i, int(j)]
+                cols += [int(j), i]
+                vals += [v, v]
+    import collections
+    acc = collections.defaultdict(float)
+    for r, c, v in zip(rows, cols, vals):
+        acc[(r, c)] += v
+    rowsum = np.zeros(n)
+    for (r, c), v in acc.items():
+        rowsum[r] += abs(v)
+    for i in range(n):
+        acc[(i, i)] = rowsum[i] + 1.0
+    import matrices as M
+    e = M.entries([(r, c, v) for (r, c), v in sorted(acc.items(), key=lambda kv: rng.random())])
+    m = B.HostMatrix(e, n, n, -1)
+    rp, ci, va = O.build_csr(e, n)
+    b = rng.standard_normal(n)
+    xo, ho, ro = O.cg(rp, ci, va, -1, b, np.zeros(n), tol=1e-9)
+    slab = B.CgSlab.from_matrix(m)
+    slab.set_vectors(b, np.zeros(n))
+    st = slab.solve(tol=1e-9)
+    assert st.iterations == ro.iterations and st.converged == 1
+    assert hist_err(slab.history(), ho) < TOL and np.max(np.abs(slab.gather() - xo)) <= 1e-9 * np.max(np.abs(xo))
+    slab.destroy()
+    op = B.Operator("cusparse-csr")
+    assert op.init(m) == 0
+    x, hist, st2 = B.cg_solve(op, m, b, np.zeros(n), tol=1e-9, device=True)
+    assert st2.iterations == ro.iterations and hist_err(hist, ho) < TOL
+    op.free()

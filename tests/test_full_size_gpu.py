@@ -89,3 +89,16 @@ def test_cg_20k_published_iteration_count_and_invariants(B):
     st2 = slab.solve()
     assert st2.iterations == 14 and np.array_equal(slab.history(), h)
     slab.destroy()
+
+
+def test_cg_20k_matches_committed_golden_history(B, golden):
+    """BASELINE config 3: 20 000 x 20 000 CG, 14-iteration residual match vs the CPU oracle
+    (history generated once on the GPU box's host by tests/golden/make_golden.py --with-20k)."""
+    g = golden["cases"].get("20000:5.0")
+    if g is None:
+        pytest.skip("20k golden not generated")
+    slab = B.CgSlab.stencil5(20000)
+    st = slab.solve()
+    assert st.iterations == g["cg"]["iterations"] == 14 and st.converged == 1
+    assert hist_err(slab.history(), g["cg"]["history"]) < 1e-10
+    slab.destroy()
