@@ -12,7 +12,8 @@ import subprocess
 import numpy as np
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG_DIR, "lib", "libspmv_amd.so")
+# SPMV_AMD_LIB: measurement aid, lets an A/B build of the library be loaded instead
+LIB_PATH = os.environ.get("SPMV_AMD_LIB") or os.path.join(PKG_DIR, "lib", "libspmv_amd.so")
 
 ENTRY_DTYPE = np.dtype([("row", np.int32), ("col", np.int32), ("value", np.float64)], align=True)
 assert ENTRY_DTYPE.itemsize == 16
