@@ -483,11 +483,33 @@ __global__ __launch_bounds__(kBlock) void stencil5_row_kernel(SlabCsr m, const d
 // CSR baseline kernels (reference operator "cusparse-csr": arithmetic in closed-source
 // cuSPARSE; semantic model = csr_spmv_kernel, cg_solver_mgpu_partitioned.cu:40-56).
 // ---------------------------------------------------------------------------------
+// One thread per row. The row is walked in chunks of eight entries: all column indices and values
+// of a chunk are requested first, then the eight x gathers, then the fused multiply-adds in
+// ascending order -- the same sequential sum as csr_spmv_kernel, with eight independent loads in
+// flight per lane instead of a col -> x -> fma chain per entry.
 __global__ __launch_bounds__(kBlock) void csr_row_scalar_kernel(SlabCsr m, const double* __restrict__ x,
                                                                 double* __restrict__ y, double alpha) {
     const long long row = (long long)blockIdx.x * kBlock + threadIdx.x;
     if (row >= m.n_local) return;
-    y[row] = alpha * row_reference<false>(m, x, (int)row, -1, 0);
+    const int lo = -m.halo_before, hi = m.n_local + m.halo_after;
+    const int k0 = m.row_ptr[row], k1 = m.row_ptr[row + 1];
+    double sum = 0.0;
+    for (int base = k0; base < k1; base += 8) {
+        int c[8];
+        double v[8], xv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const bool live = base + u < k1;
+            c[u] = live ? m.col_idx[base + u] : m.row_offset;
+            v[u] = live ? m.values[base + u] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) xv[u] = x_at(x, (long long)c[u] - m.row_offset, lo, hi);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (base + u < k1) sum = fma(v[u], xv[u], sum);
+    }
+    y[row] = alpha * sum;
 }
 
 // kLanes lanes cooperate on one row (kLanes = 64: one row per wavefront). Lanes stride the
@@ -532,10 +554,22 @@ __global__ __launch_bounds__(kBlock) void ell_transpose_kernel(int rows, int wid
 __device__ __forceinline__ double ell_row_walk(int rows, int width, const int* __restrict__ idx,
                                                const double* __restrict__ val,
                                                const double* __restrict__ x, long long r) {
+    // slots in chunks of eight: indices and values first, then the gathers, then the sum in slot order
     double sum = 0.0;
-    for (int k = 0; k < width; ++k) {
-        const int c = idx[(long long)k * rows + r];
-        if (c >= 0) sum = fma(val[(long long)k * rows + r], x[c], sum);
+    for (int base = 0; base < width; base += 8) {
+        int c[8];
+        double v[8], xv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const bool live = base + u < width;
+            c[u] = live ? idx[(long long)(base + u) * rows + r] : -1;
+            v[u] = live ? val[(long long)(base + u) * rows + r] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) xv[u] = c[u] >= 0 ? x[c[u]] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (c[u] >= 0) sum = fma(v[u], xv[u], sum);
     }
     return sum;
 }
