@@ -63,8 +63,11 @@ __device__ __forceinline__ double row_reference(const SlabCsr& m, const double* 
 }
 
 // ---------------------------------------------------------------------------------
-// STENCIL5, wave-tile variant. One wave owns 128 consecutive rows at a time; waves are
-// persistent and walk the tiles of their XCD's band round-robin.
+// STENCIL5, wave-tile variant. One wave owns 128 consecutive rows (two per lane): `values` are
+// fetched as five fully coalesced 16-byte loads per lane and transposed through a wave-private
+// LDS strip, x/y move as 16-byte pairs. Either one tile per wave in dispatch order (default) or
+// persistent waves walking the tiles of their XCD's band. Works on any row range, so it serves
+// slabs that are not made of whole grid rows.
 // ---------------------------------------------------------------------------------
 template <bool kVecXY, bool kVecNS, bool kDot>
 __global__ __launch_bounds__(kBlock) void stencil5_wavetile_kernel(
@@ -703,6 +706,7 @@ struct Stencil5Plan {
     int gi_lo = 0, gi_hi = 0, rows_per_task = 0, strips = 0, march_blocks = 0;
     int row_blocks = 0;  // blocks of one boundary-grid-row launch
     int tile_blocks = 0;
+    bool oneshot = true;
 };
 
 Stencil5Plan plan_stencil5(const SlabCsr& m, int first_row, int last_row, Stencil5Variant variant,
@@ -732,7 +736,11 @@ Stencil5Plan plan_stencil5(const SlabCsr& m, int first_row, int last_row, Stenci
         p.rows_per_task = env_int("SPMV_AMD_DIRECT_ROWS", 1);
         if (p.rows_per_task != 2 && p.rows_per_task != 4) p.rows_per_task = 1;
     } else if (variant == Stencil5Variant::WaveTile) {
-        p.tile_blocks = wavetile_blocks(shape);
+        // one tile per wave in dispatch order by default (4.65 ms at 20 000^2); SPMV_AMD_WAVETILE_ONESHOT=0
+        // selects the persistent, XCD-banded walk (5.87 ms), kept for the record
+        p.oneshot = env_int("SPMV_AMD_WAVETILE_ONESHOT", 1) != 0;
+        const int tiles = (last_row + kTileRows - 1) / kTileRows - first_row / kTileRows;
+        p.tile_blocks = p.oneshot ? (tiles + kWavesPerBlock - 1) / kWavesPerBlock : wavetile_blocks(shape);
     } else {
         const int gfirst = m.row_offset / n;
         p.gi_lo = first_row / n;
@@ -833,9 +841,8 @@ int launch_stencil5_spmv(const SlabCsr& m, const double* x, double* y, double al
     const bool vec_xy = aligned16(x) && aligned16(y);
     if (p.variant == Stencil5Variant::WaveTile) {
         // Fixed grid (independent of the row range) so that the dot partials keep their shape.
-        const int oneshot = env_int("SPMV_AMD_WAVETILE_ONESHOT", 0);
-        const int tiles = (last_row + kTileRows - 1) / kTileRows - first_row / kTileRows;
-        const dim3 grid(oneshot ? (tiles + kWavesPerBlock - 1) / kWavesPerBlock : p.tile_blocks);
+        const int oneshot = p.oneshot ? 1 : 0;
+        const dim3 grid(p.tile_blocks);
         const bool vec_ns = vec_xy && (n % 2 == 0);
 #define SPMV_AMD_LAUNCH_TILE(VXY, VNS, DOT)                                                       \
     hipLaunchKernelGGL((stencil5_wavetile_kernel<VXY, VNS, DOT>), grid, dim3(kBlock), 0, stream, m, \
