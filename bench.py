@@ -148,8 +148,11 @@ def main():
         dist.barrier()
     L = B.lib()
     B.require_gpu()
-    torch.cuda.set_device(local_rank)
-    L.spmv_amd_set_device(local_rank)
+    # SPMV_AMD_BENCH_DEVICE (test hook): put every rank on one device, so a 1-GPU box can walk the
+    # N > 1 control flow (RCCL refuses two ranks on one device -> the staged transport takes over)
+    device = int(os.environ.get("SPMV_AMD_BENCH_DEVICE", local_rank))
+    torch.cuda.set_device(device)
+    L.spmv_amd_set_device(device)
 
     def barrier():
         if multi:

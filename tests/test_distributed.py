@@ -93,3 +93,26 @@ def test_bench_distributed_path_with_one_rank():
     assert dist_line["config"]["transport"] == "rccl" and dist_line["n_gpus"] == 1
     assert dist_line["config"]["residual_history"] == plain_line["config"]["residual_history"]
     assert dist_line["config"]["iterations_per_solve"] == plain_line["config"]["iterations_per_solve"]
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_control_flow_on_one_gpu():
+    """bench.py --gpus 2 under torch.distributed.run with both ranks pinned to the box's only GPU:
+    RCCL refuses two ranks on one device, every rank agrees (over gloo) to switch to the staged
+    transport, and the run completes with the same residual history as one rank."""
+    import json
+    env = dict(os.environ, SPMV_AMD_BENCH_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--grid", "1024"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    two = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert two["n_gpus"] == 2 and two["scaling"] == "strong" and "staged" in two["config"]["transport"]
+    assert "cpu_baseline" not in two and "spmv" not in two  # N = 1 only legs
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--grid", "1024",
+                          "--no-cpu-baseline", "--no-spmv"], capture_output=True, text=True, timeout=600)
+    one = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    assert two["config"]["iterations_per_solve"] == one["config"]["iterations_per_solve"]
+    h2, h1 = np.array(two["config"]["residual_history"]), np.array(one["config"]["residual_history"])
+    assert hist_err(h2, h1) < 1e-10
