@@ -185,11 +185,16 @@ int spmv_amd_download_device_csr(const char* mode, int* row_ptr, int* col_idx, d
 int spmv_amd_time_run_device(const char* mode, const double* d_x, double* d_y, int reps,
                              float* ms_each);
 
-/* Which kernel variant the last init selected: a static string such as
- * "stencil5/wave-tile", "stencil5/row-generic", "csr/stream", "csr/wavefront". */
+/* Which kernel variant the last init selected: a static string, one of
+ * "stencil5/row-direct" (default on verified stencils), "stencil5/column-march",
+ * "stencil5/wave-tile", "stencil5/row-generic", "stencil5/row-generic(csr-loop)";
+ * "csr/row-scalar", "csr/subwave4|8|16|32", "csr/wavefront"; "ell/slot-major",
+ * "ell/stencil5-direct". */
 const char* spmv_amd_operator_variant(const char* mode);
 
-/* Forces a kernel variant at the next init of `mode` (NULL = automatic). */
+/* Forces a kernel variant of `mode` ("row-direct", "column-march", "wave-tile", "row-generic" /
+ * "row-scalar", "subwave4".."subwave32", "wavefront"; NULL or "auto" = automatic). A variant
+ * whose preconditions the matrix does not meet falls back to the next applicable one. */
 int spmv_amd_operator_select_variant(const char* mode, const char* variant);
 
 /* ---- residual history of the most recent CG solve in this process ---- */
