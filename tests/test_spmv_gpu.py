@@ -197,3 +197,32 @@ def test_run_device_leaves_no_sync_and_time_helper(B, O, fresh_host_matrices):
     y = dy.to_host()
     assert y.sum() == n * n + 4 * n
     dx.free(), dy.free(), op.free()
+
+
+def test_degenerate_inputs(B, O, fresh_host_matrices):
+    """1x1, an all-zero matrix (every row empty), a single dense row, and the 1x1 'grid'."""
+    cases = [
+        (M.entries([(0, 0, 2.5)]), 1, 1, -1, np.array([4.0])),
+        (M.entries([]), 3, 3, -1, np.array([1.0, 2.0, 3.0])),
+        (M.entries([(1, j, float(j + 1)) for j in range(300)]), 3, 300, -1, np.arange(300, dtype=np.float64)),
+        (M.entries([(0, 0, 5.0)]), 1, 1, 1, np.array([-2.0])),
+    ]
+    for e, r, c, grid, x in cases:
+        rp, ci, va = O.build_csr(e, r)
+        want = O.spmv_csr(rp, ci, va, x)
+        for mode in ("stencil5-csr", "cusparse-csr", "ellpack", "stencil5-ellpack"):
+            B.lib().spmv_amd_reset_host_matrices()
+            op = B.Operator(mode)
+            m = B.HostMatrix(e, r, c, grid)
+            assert op.init(m) == 0, mode
+            got, _ = op.run_timed(x)
+            if mode == "cusparse-csr" and len(e) == 300:
+                assert np.max(np.abs(got - want)) <= 1e-12 * np.max(np.abs(want))  # long row: sub-wavefront tree
+            else:
+                assert np.array_equal(got, want), (mode, r, c)
+            op.free()
+    op = B.Operator("stencil5-csr")
+    assert op.init_synthetic(1) == 0
+    got, _ = op.run_timed(np.array([3.0]))
+    assert got[0] == 15.0
+    op.free()
