@@ -177,7 +177,7 @@ int cg_solve_device(SpmvOperator* spmv_op, MatrixData* mat, const double* b, dou
     double *d_rr_old = d_s, *d_rr_new = d_s + 1, *d_pAp = d_s + 2, *d_alpha = d_s + 3,
            *d_beta = d_s + 4, *d_residual = d_s + 5;
     int* d_converged = device_alloc<int>(1);
-    const int hist_cap = config.max_iters + 1;
+    const int hist_cap = config.max_iters < (1 << 20) ? config.max_iters + 1 : (1 << 20);
     double* d_hist = device_alloc<double>((size_t)hist_cap);
     upload(v.x, x, (size_t)n);
     upload(v.b, b, (size_t)n);
@@ -214,8 +214,9 @@ int cg_solve_device(SpmvOperator* spmv_op, MatrixData* mat, const double* b, dou
         region(t_blas, false, [&] { launch_axpy_dev((size_t)n, d_alpha, v.Ap, v.r, true, kStream); });
         region(t_red, false, [&] { launch_dot((size_t)n, v.r, v.r, v.scratch, d_rr_new, kStream); });
         launch_check_convergence(d_rr_new, b_norm, config.tolerance, d_converged, d_residual, kStream);
-        HIP_CHECK(hipMemcpyAsync(d_hist + iter + 1, d_residual, sizeof(double),
-                                 hipMemcpyDeviceToDevice, kStream));
+        if (iter + 1 < hist_cap)
+            HIP_CHECK(hipMemcpyAsync(d_hist + iter + 1, d_residual, sizeof(double),
+                                     hipMemcpyDeviceToDevice, kStream));
 
         int h_converged = 0;
         download(&h_converged, d_converged, 1);
@@ -240,7 +241,7 @@ int cg_solve_device(SpmvOperator* spmv_op, MatrixData* mat, const double* b, dou
     download(x, v.x, (size_t)n);
 
     std::vector<double>& hist = last_cg_history();
-    hist.assign((size_t)iter + 1, 0.0);
+    hist.assign((size_t)(iter + 1 < hist_cap ? iter + 1 : hist_cap), 0.0);
     download(hist.data(), d_hist, hist.size());
 
     stats->iterations = iter;

@@ -239,9 +239,11 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
     const bool reduce = comm->collective();   // all-reduce of the dot products needed
     memset(stats, 0, sizeof(*stats));
 
-    if (s->hist_cap < config->max_iters + 1) {
+    // residual history: one slot per iteration, capped at 2^20 entries (later iterations go unrecorded)
+    const int want_hist = config->max_iters < (1 << 20) ? config->max_iters + 1 : (1 << 20);
+    if (s->hist_cap < want_hist) {
         device_release(s->d_hist);
-        s->hist_cap = config->max_iters + 1;
+        s->hist_cap = want_hist;
         s->d_hist = device_alloc<double>((size_t)s->hist_cap);
     }
     CgScalars init;
