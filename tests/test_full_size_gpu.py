@@ -102,3 +102,14 @@ def test_cg_20k_matches_committed_golden_history(B, golden):
     assert st.iterations == g["cg"]["iterations"] == 14 and st.converged == 1
     assert hist_err(slab.history(), g["cg"]["history"]) < 1e-10
     slab.destroy()
+
+
+def test_sizes_beyond_int32_csr_are_refused(B):
+    """nnz = 5n^2 - 4n must fit the reference's signed 32-bit CSR indices (hard parts):
+    n = 20 724 is the last grid that does."""
+    last_ok = max(n for n in range(20700, 20760) if 5 * n * n - 4 * n <= 2**31 - 1)
+    assert last_ok == 20724
+    op = B.Operator("stencil5-csr")
+    assert op.init_synthetic(last_ok + 1) != 0  # refused, nothing allocated
+    with pytest.raises(RuntimeError):
+        B.CgSlab.stencil5(last_ok + 1)
