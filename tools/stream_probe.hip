@@ -20,6 +20,36 @@ __global__ __launch_bounds__(256) void read_only(const d2* __restrict__ a, size_
     }
     if (acc.x + acc.y == 123.456) out[0] = acc.x;
 }
+// shape A': the same bytes, one 16-byte load per thread x 4 arrays-worth per block, one-shot grid
+__global__ __launch_bounds__(256) void read_only_oneshot(const d2* __restrict__ a, size_t n2, double* out) {
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    d2 acc = {0, 0};
+    if (i + 3 < n2) acc = a[i] + a[i + 1] + a[i + 2] + a[i + 3];
+    if (acc.x + acc.y == 123.456) out[0] = acc.x;
+}
+// shape D: the stencil's traffic mix with every stream fully coalesced at 8 B/lane, one row per thread,
+// one-shot: 5 value planes (SoA) + x + y = 48 B read : 8 B written, no neighbours, no indices
+__global__ __launch_bounds__(256) void mix_soa_oneshot(const double* __restrict__ v, const double* __restrict__ x,
+                                                       double* __restrict__ y, size_t rows) {
+    const size_t r = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (r < rows) y[r] = v[r] * x[r] + v[rows + r] + v[2 * rows + r] + v[3 * rows + r] + v[4 * rows + r];
+}
+// shape D2: the same mix with two adjacent rows per thread, every access 16 B/lane
+__global__ __launch_bounds__(256) void mix_soa_oneshot2(const d2* __restrict__ v, const d2* __restrict__ x,
+                                                        d2* __restrict__ y, size_t pairs) {
+    const size_t r = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (r < pairs) y[r] = v[r] * x[r] + v[pairs + r] + v[2 * pairs + r] + v[3 * pairs + r] + v[4 * pairs + r];
+}
+// shape D4: four adjacent rows per thread (two 16-byte accesses per stream)
+__global__ __launch_bounds__(256) void mix_soa_oneshot4(const d2* __restrict__ v, const d2* __restrict__ x,
+                                                        d2* __restrict__ y, size_t pairs) {
+    const size_t r = ((size_t)blockIdx.x * 256 + threadIdx.x) * 2;
+    if (r + 1 < pairs) {
+        d2 a = v[r] * x[r] + v[pairs + r] + v[2 * pairs + r] + v[3 * pairs + r] + v[4 * pairs + r];
+        d2 b = v[r + 1] * x[r + 1] + v[pairs + r + 1] + v[2 * pairs + r + 1] + v[3 * pairs + r + 1] + v[4 * pairs + r + 1];
+        y[r] = a; y[r + 1] = b;
+    }
+}
 // shape B: copy 16 B/lane
 __global__ __launch_bounds__(256) void copy16(const d2* __restrict__ a, d2* __restrict__ b, size_t n2) {
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, stride = (size_t)gridDim.x * 256;
@@ -109,6 +139,16 @@ int main(int argc, char** argv) {
         printf("read_only   blocks/CU %2d : %7.3f ms  %8.1f GB/s\n", bpc, ms, vb / ms / 1e6);
         ms = time_ms([&] { hipLaunchKernelGGL(copy16, dim3(grid), dim3(256), 0, 0, (const d2*)values, (d2*)x, (size_t)rows * 8 / 16); });
         printf("copy16      blocks/CU %2d : %7.3f ms  %8.1f GB/s (read+write)\n", bpc, ms, 2.0 * rows * 8 / ms / 1e6);
+    }
+    {
+        double ms = time_ms([&] { hipLaunchKernelGGL(read_only_oneshot, dim3((unsigned)((vb / 16 / 4 + 255) / 256)), dim3(256), 0, 0, (const d2*)values, vb / 16, y); });
+        printf("read_only   one-shot 64 B/thread   : %7.3f ms  %8.1f GB/s\n", ms, vb / ms / 1e6);
+        ms = time_ms([&] { hipLaunchKernelGGL(mix_soa_oneshot, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, 0, values, x, y, (size_t)rows); });
+        printf("mix SoA     one-shot 1 row/thread  : %7.3f ms  %8.1f GB/s (48 B read : 8 B write per row)\n", ms, rows * 56.0 / ms / 1e6);
+        ms = time_ms([&] { hipLaunchKernelGGL(mix_soa_oneshot2, dim3((unsigned)((rows / 2 + 255) / 256)), dim3(256), 0, 0, (const d2*)values, (const d2*)x, (d2*)y, (size_t)rows / 2); });
+        printf("mix SoA     one-shot 2 rows/thread : %7.3f ms  %8.1f GB/s (16 B/lane)\n", ms, rows * 56.0 / ms / 1e6);
+        ms = time_ms([&] { hipLaunchKernelGGL(mix_soa_oneshot4, dim3((unsigned)((rows / 4 + 255) / 256)), dim3(256), 0, 0, (const d2*)values, (const d2*)x, (d2*)y, (size_t)rows / 2); });
+        printf("mix SoA     one-shot 4 rows/thread : %7.3f ms  %8.1f GB/s (2 x 16 B/lane)\n", ms, rows * 56.0 / ms / 1e6);
     }
     const double mixbytes = (double)rows * 56;
     for (int banded : {0, 1}) for (int bpc : {4, 7, 8, 12, 16}) {
