@@ -34,6 +34,12 @@ __global__ __launch_bounds__(256) void mix_soa_oneshot(const double* __restrict_
     const size_t r = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (r < rows) y[r] = v[r] * x[r] + v[rows + r] + v[2 * rows + r] + v[3 * rows + r] + v[4 * rows + r];
 }
+// shape D-nt: shape D with a nontemporal store of y
+__global__ __launch_bounds__(256) void mix_soa_oneshot_nt(const double* __restrict__ v, const double* __restrict__ x,
+                                                          double* __restrict__ y, size_t rows) {
+    const size_t r = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (r < rows) __builtin_nontemporal_store(v[r] * x[r] + v[rows + r] + v[2 * rows + r] + v[3 * rows + r] + v[4 * rows + r], &y[r]);
+}
 // shape D2: the same mix with two adjacent rows per thread, every access 16 B/lane
 __global__ __launch_bounds__(256) void mix_soa_oneshot2(const d2* __restrict__ v, const d2* __restrict__ x,
                                                         d2* __restrict__ y, size_t pairs) {
@@ -145,6 +151,8 @@ int main(int argc, char** argv) {
         printf("read_only   one-shot 64 B/thread   : %7.3f ms  %8.1f GB/s\n", ms, vb / ms / 1e6);
         ms = time_ms([&] { hipLaunchKernelGGL(mix_soa_oneshot, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, 0, values, x, y, (size_t)rows); });
         printf("mix SoA     one-shot 1 row/thread  : %7.3f ms  %8.1f GB/s (48 B read : 8 B write per row)\n", ms, rows * 56.0 / ms / 1e6);
+        ms = time_ms([&] { hipLaunchKernelGGL(mix_soa_oneshot_nt, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, 0, values, x, y, (size_t)rows); });
+        printf("mix SoA     one-shot 1 row/thread, nontemporal store : %7.3f ms  %8.1f GB/s\n", ms, rows * 56.0 / ms / 1e6);
         ms = time_ms([&] { hipLaunchKernelGGL(mix_soa_oneshot2, dim3((unsigned)((rows / 2 + 255) / 256)), dim3(256), 0, 0, (const d2*)values, (const d2*)x, (d2*)y, (size_t)rows / 2); });
         printf("mix SoA     one-shot 2 rows/thread : %7.3f ms  %8.1f GB/s (16 B/lane)\n", ms, rows * 56.0 / ms / 1e6);
         ms = time_ms([&] { hipLaunchKernelGGL(mix_soa_oneshot4, dim3((unsigned)((rows / 4 + 255) / 256)), dim3(256), 0, 0, (const d2*)values, (const d2*)x, (d2*)y, (size_t)rows / 2); });
