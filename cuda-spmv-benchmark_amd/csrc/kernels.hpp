@@ -60,7 +60,7 @@ int launch_stencil5_spmv(const SlabCsr& m, const double* x, double* y, double al
                           const LaunchShape& shape, hipStream_t stream);
 
 // ---- CSR SpMV ----
-enum class CsrVariant { Auto, RowScalar, Wavefront, SubWave4, SubWave8, SubWave16, SubWave32 };
+enum class CsrVariant { Auto, Stream, RowScalar, Wavefront, SubWave4, SubWave8, SubWave16, SubWave32 };
 CsrVariant csr_auto_variant(const SlabCsr& m);
 void launch_csr_spmv(const SlabCsr& m, const double* x, double* y, double alpha,
                      CsrVariant variant, hipStream_t stream);

@@ -133,6 +133,7 @@ void stencil_free() {
 const char* csr_variant_name(CsrVariant v, const SlabCsr& m) {
     if (v == CsrVariant::Auto) v = csr_auto_variant(m);
     switch (v) {
+        case CsrVariant::Stream: return "csr/stream";
         case CsrVariant::RowScalar: return "csr/row-scalar";
         case CsrVariant::SubWave4: return "csr/subwave4";
         case CsrVariant::SubWave8: return "csr/subwave8";
@@ -412,6 +413,7 @@ extern "C" int spmv_amd_operator_select_variant(const char* mode, const char* va
         case Which::Csr: {
             CsrVariant v;
             if (automatic) v = CsrVariant::Auto;
+            else if (!strcmp(variant, "stream")) v = CsrVariant::Stream;
             else if (!strcmp(variant, "row-scalar")) v = CsrVariant::RowScalar;
             else if (!strcmp(variant, "wavefront")) v = CsrVariant::Wavefront;
             else if (!strcmp(variant, "subwave4")) v = CsrVariant::SubWave4;

@@ -518,6 +518,65 @@ __global__ __launch_bounds__(kBlock) void csr_row_scalar_kernel(SlabCsr m, const
     y[row] = alpha * sum;
 }
 
+// CSR-stream: a block owns `rows_per_block` consecutive rows whose entries form one contiguous span
+// of col_idx / values. Phase 1 walks the span with all 256 threads, consecutive lanes on
+// consecutive entries (fully coalesced 4- and 8-byte loads, no dependence on the per-row row_ptr),
+// gathers x and parks (value, x) in LDS; phase 2 gives each row to one thread, which folds its
+// entries from LDS with fma in ascending order -- the sequential sum of csr_spmv_kernel, bit for
+// bit. A span that does not fit the LDS strip (very long rows) is walked by the chunked
+// thread-per-row loop instead. This is the shape of the "stream" half of CSR-adaptive
+// (Greathouse & Daga, SC'14), without a preprocessing pass: the row count per block is fixed per
+// matrix from its mean row length.
+constexpr int kCsrStreamCap = 1536;  // entries per block
+
+__global__ __launch_bounds__(kBlock) void csr_stream_kernel(SlabCsr m, const double* __restrict__ x,
+                                                            double* __restrict__ y, double alpha,
+                                                            int rows_per_block) {
+    __shared__ double sv[kCsrStreamCap];
+    __shared__ double sx[kCsrStreamCap];
+    const int lo = -m.halo_before, hi = m.n_local + m.halo_after;
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    const long long r1 = min(r0 + rows_per_block, (long long)m.n_local);
+    const int kb = m.row_ptr[r0], ke = m.row_ptr[r1];
+    const long long row = r0 + threadIdx.x;
+    const bool has_row = (int)threadIdx.x < rows_per_block && row < r1;
+    int k0 = 0, k1 = 0;
+    if (has_row) {
+        k0 = m.row_ptr[row];
+        k1 = m.row_ptr[row + 1];
+    }
+    if (ke - kb <= kCsrStreamCap) {
+        for (int e = kb + (int)threadIdx.x; e < ke; e += kBlock) {
+            sv[e - kb] = m.values[e];
+            sx[e - kb] = x_at(x, (long long)m.col_idx[e] - m.row_offset, lo, hi);
+        }
+        __syncthreads();
+        if (has_row) {
+            double sum = 0.0;
+            for (int k = k0 - kb; k < k1 - kb; ++k) sum = fma(sv[k], sx[k], sum);
+            y[row] = alpha * sum;
+        }
+    } else if (has_row) {
+        double sum = 0.0;
+        for (int base = k0; base < k1; base += 8) {
+            int c[8];
+            double v[8], xv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const bool live = base + u < k1;
+                c[u] = live ? m.col_idx[base + u] : m.row_offset;
+                v[u] = live ? m.values[base + u] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) xv[u] = x_at(x, (long long)c[u] - m.row_offset, lo, hi);
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (base + u < k1) sum = fma(v[u], xv[u], sum);
+        }
+        y[row] = alpha * sum;
+    }
+}
+
 // kLanes lanes cooperate on one row (kLanes = 64: one row per wavefront). Lanes stride the
 // row's entries, so consecutive lanes read consecutive col_idx/values: coalesced. The per-lane
 // partial sums are combined by a fixed shuffle tree, so the summation order differs from the
@@ -887,9 +946,12 @@ int launch_stencil5_spmv(const SlabCsr& m, const double* x, double* y, double al
     return used;
 }
 
-// Measured on MI355X, 10 000^2 stencil as CSR (5 nnz/row): row-scalar 2.18 ms, subwave4 2.52,
-// subwave8 3.44, subwave16 6.42, one row per wavefront 8.34. Short rows: one thread per row (the
-// vector L1 absorbs the lane stride); longer rows: about four entries per lane.
+// Measured on MI355X, 10 000^2 stencil as CSR (5 nnz/row): row-scalar 1.75 ms (chunked), stream
+// 2.02 ms (LDS-staged, 6 blocks/CU; 1.75 ms with products only in LDS, i.e. no gain for a
+// non-sequential sum), subwave4 2.52, subwave8 3.44, subwave16 6.42, one row per wavefront 8.34.
+// For scale: rocsparse_spmv (csr_adaptive) does the same matrix in 1.33 ms (tools/rocsparse_compare.hip).
+// Short rows: one thread per row (the vector L1 absorbs the lane stride); longer rows: about four
+// entries per lane.
 CsrVariant csr_auto_variant(const SlabCsr& m) {
     const double avg = m.n_local > 0 ? (double)m.nnz_local / m.n_local : 0.0;
     return avg <= 8.0     ? CsrVariant::RowScalar
@@ -906,6 +968,16 @@ void launch_csr_spmv(const SlabCsr& m, const double* x, double* y, double alpha,
     if (variant == CsrVariant::Auto) variant = csr_auto_variant(m);
     const long long rows = m.n_local;
     switch (variant) {
+        case CsrVariant::Stream: {
+            // rows per block: the mean span should fill about 80 % of the LDS strip, at most one row per thread
+            const double avg = rows > 0 ? (double)m.nnz_local / rows : 1.0;
+            int per_block = (int)(0.8 * kCsrStreamCap / (avg > 1.0 ? avg : 1.0));
+            per_block = per_block > kBlock ? kBlock : (per_block < 32 ? 32 : per_block & ~31);
+            per_block = env_int("SPMV_AMD_CSR_STREAM_ROWS", per_block);
+            hipLaunchKernelGGL(csr_stream_kernel, dim3((unsigned)((rows + per_block - 1) / per_block)), dim3(kBlock),
+                               0, stream, m, x, y, alpha, per_block);
+            break;
+        }
         case CsrVariant::RowScalar:
             hipLaunchKernelGGL(csr_row_scalar_kernel, dim3(blocks_for(rows)), dim3(kBlock), 0, stream,
                                m, x, y, alpha);

@@ -97,7 +97,7 @@ def test_stencil5_csr_non_stencil_inputs_take_the_csr_loop(B, O, fresh_host_matr
         op.free()
 
 
-@pytest.mark.parametrize("variant", [None, "row-scalar", "subwave4", "subwave8", "subwave16", "subwave32", "wavefront"])
+@pytest.mark.parametrize("variant", [None, "stream", "row-scalar", "subwave4", "subwave8", "subwave16", "subwave32", "wavefront"])
 def test_csr_operator(B, O, fresh_host_matrices, variant):
     op = B.Operator("cusparse-csr")
     op.select_variant(variant)
@@ -115,7 +115,7 @@ def test_csr_operator(B, O, fresh_host_matrices, variant):
         rp, ci, va = O.build_csr(e, r)
         want = O.spmv_csr(rp, ci, va, x)
         got, ms = op.run_timed(x)
-        if variant == "row-scalar":
+        if variant in ("row-scalar", "stream"):  # sequential fma order: bit-exact
             assert np.array_equal(got, want)
         else:
             scale = np.maximum(np.abs(want), O.spmv_csr(rp, ci, np.abs(va), np.abs(x)))
