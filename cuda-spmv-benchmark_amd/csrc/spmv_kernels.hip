@@ -527,7 +527,8 @@ __global__ __launch_bounds__(kBlock) void csr_row_scalar_kernel(SlabCsr m, const
 // thread-per-row loop instead. This is the shape of the "stream" half of CSR-adaptive
 // (Greathouse & Daga, SC'14), without a preprocessing pass: the row count per block is fixed per
 // matrix from its mean row length.
-constexpr int kCsrStreamCap = 1536;  // entries per block
+constexpr int kCsrStreamPerThread = 4;                         // entries each thread fetches in phase 1
+constexpr int kCsrStreamCap = kBlock * kCsrStreamPerThread;    // 1024 entries: 16 KiB of LDS, 8 blocks per CU
 
 __global__ __launch_bounds__(kBlock) void csr_stream_kernel(SlabCsr m, const double* __restrict__ x,
                                                             double* __restrict__ y, double alpha,
@@ -546,9 +547,22 @@ __global__ __launch_bounds__(kBlock) void csr_stream_kernel(SlabCsr m, const dou
         k1 = m.row_ptr[row + 1];
     }
     if (ke - kb <= kCsrStreamCap) {
-        for (int e = kb + (int)threadIdx.x; e < ke; e += kBlock) {
-            sv[e - kb] = m.values[e];
-            sx[e - kb] = x_at(x, (long long)m.col_idx[e] - m.row_offset, lo, hi);
+        // phase 1, unrolled: all index and value loads first, then the gathers, then LDS
+        int c[kCsrStreamPerThread];
+        double v[kCsrStreamPerThread], xv[kCsrStreamPerThread];
+#pragma unroll
+        for (int u = 0; u < kCsrStreamPerThread; ++u) {
+            const int e = kb + (int)threadIdx.x + u * kBlock;
+            const bool live = e < ke;
+            c[u] = live ? m.col_idx[e] : m.row_offset;
+            v[u] = live ? m.values[e] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < kCsrStreamPerThread; ++u) xv[u] = x_at(x, (long long)c[u] - m.row_offset, lo, hi);
+#pragma unroll
+        for (int u = 0; u < kCsrStreamPerThread; ++u) {
+            sv[threadIdx.x + u * kBlock] = v[u];
+            sx[threadIdx.x + u * kBlock] = xv[u];
         }
         __syncthreads();
         if (has_row) {
@@ -559,19 +573,19 @@ __global__ __launch_bounds__(kBlock) void csr_stream_kernel(SlabCsr m, const dou
     } else if (has_row) {
         double sum = 0.0;
         for (int base = k0; base < k1; base += 8) {
-            int c[8];
-            double v[8], xv[8];
+            int cc[8];
+            double vv[8], xx[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const bool live = base + u < k1;
-                c[u] = live ? m.col_idx[base + u] : m.row_offset;
-                v[u] = live ? m.values[base + u] : 0.0;
+                cc[u] = live ? m.col_idx[base + u] : m.row_offset;
+                vv[u] = live ? m.values[base + u] : 0.0;
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) xv[u] = x_at(x, (long long)c[u] - m.row_offset, lo, hi);
+            for (int u = 0; u < 8; ++u) xx[u] = x_at(x, (long long)cc[u] - m.row_offset, lo, hi);
 #pragma unroll
             for (int u = 0; u < 8; ++u)
-                if (base + u < k1) sum = fma(v[u], xv[u], sum);
+                if (base + u < k1) sum = fma(vv[u], xx[u], sum);
         }
         y[row] = alpha * sum;
     }
@@ -946,15 +960,17 @@ int launch_stencil5_spmv(const SlabCsr& m, const double* x, double* y, double al
     return used;
 }
 
-// Measured on MI355X, 10 000^2 stencil as CSR (5 nnz/row): row-scalar 1.75 ms (chunked), stream
-// 2.02 ms (LDS-staged, 6 blocks/CU; 1.75 ms with products only in LDS, i.e. no gain for a
-// non-sequential sum), subwave4 2.52, subwave8 3.44, subwave16 6.42, one row per wavefront 8.34.
-// For scale: rocsparse_spmv (csr_adaptive) does the same matrix in 1.33 ms (tools/rocsparse_compare.hip).
-// Short rows: one thread per row (the vector L1 absorbs the lane stride); longer rows: about four
-// entries per lane.
+// Measured on MI355X, 10 000^2 stencil as CSR (5 nnz/row): stream 1.37 ms (4 entries per thread,
+// 176 rows per block; 1.50 ms at 3 per thread, 1.40-1.45 at 5-6, 2.02-2.53 ms with one big LDS strip
+// per 256 rows), row-scalar 1.75 ms (chunked), subwave4 2.52, subwave8 3.44, subwave16 6.42, one row
+// per wavefront 8.34. For scale: rocsparse_spmv (csr_adaptive) takes 1.33 ms (tools/rocsparse_compare.hip).
+// The texture addresser is ~80 % busy in the thread-per-row kernels (rocprofv3 TA_BUSY_avr): the
+// 20/40-byte lane strides of col_idx/values are what the coalesced phase 1 of the stream kernel removes.
+// Short rows: stream; longer rows: about four entries per lane.
 CsrVariant csr_auto_variant(const SlabCsr& m) {
     const double avg = m.n_local > 0 ? (double)m.nnz_local / m.n_local : 0.0;
-    return avg <= 8.0     ? CsrVariant::RowScalar
+    return avg <= 10.0    ? CsrVariant::Stream
+           : avg <= 8.0   ? CsrVariant::RowScalar
            : avg <= 16.0  ? CsrVariant::SubWave4
            : avg <= 32.0  ? CsrVariant::SubWave8
            : avg <= 64.0  ? CsrVariant::SubWave16
@@ -971,8 +987,8 @@ void launch_csr_spmv(const SlabCsr& m, const double* x, double* y, double alpha,
         case CsrVariant::Stream: {
             // rows per block: the mean span should fill about 80 % of the LDS strip, at most one row per thread
             const double avg = rows > 0 ? (double)m.nnz_local / rows : 1.0;
-            int per_block = (int)(0.8 * kCsrStreamCap / (avg > 1.0 ? avg : 1.0));
-            per_block = per_block > kBlock ? kBlock : (per_block < 32 ? 32 : per_block & ~31);
+            int per_block = (int)(0.9 * kCsrStreamCap / (avg > 1.0 ? avg : 1.0));
+            per_block = per_block > kBlock ? kBlock : (per_block < 16 ? 16 : per_block & ~15);
             per_block = env_int("SPMV_AMD_CSR_STREAM_ROWS", per_block);
             hipLaunchKernelGGL(csr_stream_kernel, dim3((unsigned)((rows + per_block - 1) / per_block)), dim3(kBlock),
                                0, stream, m, x, y, alpha, per_block);
