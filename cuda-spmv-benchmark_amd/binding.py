@@ -85,7 +85,7 @@ DECLARED_SYMBOLS = [
     "spmv_amd_cg_solve_mgpu_partitioned", "spmv_amd_reset_host_matrices", "spmv_amd_interior_csr_offset",
     "spmv_amd_partition_rows", "spmv_amd_device_count", "spmv_amd_set_device", "spmv_amd_device_alloc", "spmv_amd_device_free",
     "spmv_amd_copy_to_device", "spmv_amd_copy_to_host", "spmv_amd_device_fill_f64", "spmv_amd_device_synchronize",
-    "spmv_amd_init_stencil5_synthetic", "spmv_amd_download_device_csr", "spmv_amd_time_run_device", "spmv_amd_operator_variant",
+    "spmv_amd_init_stencil5_synthetic", "spmv_amd_ellpack_run_device_scaled", "spmv_amd_download_device_csr", "spmv_amd_time_run_device", "spmv_amd_operator_variant",
     "spmv_amd_operator_select_variant", "spmv_amd_cg_last_history", "spmv_amd_comm_unique_id", "spmv_amd_comm_create_rccl",
     "spmv_amd_comm_create_staged", "spmv_amd_comm_destroy", "spmv_amd_comm_set_world", "spmv_amd_comm_rank", "spmv_amd_comm_size", "spmv_amd_comm_selftest",
     "spmv_amd_cg_slab_create", "spmv_amd_cg_slab_create_stencil5", "spmv_amd_cg_slab_set_vectors", "spmv_amd_cg_slab_solve",
@@ -137,6 +137,7 @@ def lib():
     L.spmv_amd_device_fill_f64.argtypes = [C.c_void_p, C.c_size_t, C.c_double]
     L.spmv_amd_init_stencil5_synthetic.argtypes = [C.c_char_p, C.c_int]
     L.spmv_amd_download_device_csr.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.spmv_amd_ellpack_run_device_scaled.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double]
     L.spmv_amd_time_run_device.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_float)]
     L.spmv_amd_cg_solve.argtypes = [C.POINTER(SpmvOperator), C.POINTER(MatrixData), C.c_void_p, C.c_void_p, C.POINTER(CGConfig), C.POINTER(CGStats)]
     L.spmv_amd_cg_solve_device.argtypes = L.spmv_amd_cg_solve.argtypes

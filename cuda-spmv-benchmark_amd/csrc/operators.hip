@@ -265,16 +265,16 @@ int ell_init_synthetic(EllOperator& op, int n) {
     return 0;
 }
 
-int ell_run(EllOperator& op, const double* d_x, double* d_y) {
+int ell_run(EllOperator& op, const double* d_x, double* d_y, double alpha = 1.0, double beta = 0.0) {
     if (!op.ready) {
         fprintf(stderr, "[%s] run before init\n", op.tag);
         return EXIT_FAILURE;
     }
     if (op.stencil_fast_path && op.verified)
-        launch_ell_stencil5_spmv(op.rows, op.width, op.grid_size, op.idx, op.val, d_x, d_y, 1.0, 0.0,
+        launch_ell_stencil5_spmv(op.rows, op.width, op.grid_size, op.idx, op.val, d_x, d_y, alpha, beta,
                                  kDefaultStream);
     else
-        launch_ell_spmv(op.rows, op.width, op.idx, op.val, d_x, d_y, 1.0, 0.0, kDefaultStream);
+        launch_ell_spmv(op.rows, op.width, op.idx, op.val, d_x, d_y, alpha, beta, kDefaultStream);
     return 0;
 }
 
@@ -356,6 +356,15 @@ extern "C" int spmv_amd_init_stencil5_synthetic(const char* mode, int n) {
             return 0;
         case Which::Ell: return ell_init_synthetic(g_ell, n);
         case Which::EllStencil: return ell_init_synthetic(g_ell_stencil, n);
+        default: return EXIT_FAILURE;
+    }
+}
+
+extern "C" int spmv_amd_ellpack_run_device_scaled(const char* mode, const double* d_x, double* d_y,
+                                                  double alpha, double beta) {
+    switch (which_operator(mode)) {
+        case Which::Ell: return ell_run(g_ell, d_x, d_y, alpha, beta);
+        case Which::EllStencil: return ell_run(g_ell_stencil, d_x, d_y, alpha, beta);
         default: return EXIT_FAILURE;
     }
 }

@@ -176,6 +176,12 @@ int spmv_amd_device_synchronize(void);
  * n = 20000). csr_mat gets the dimensions, its host arrays stay NULL. */
 int spmv_amd_init_stencil5_synthetic(const char* mode, int n);
 
+/* y = alpha*A*x + beta*y on an initialised "ellpack" / "stencil5-ellpack" operator: the full
+ * contract of the kernel prototyped in reference include/spmv_stencil.h:25-42 (the operator table
+ * itself always runs alpha = 1, beta = 0). Device pointers, default stream, no synchronisation. */
+int spmv_amd_ellpack_run_device_scaled(const char* mode, const double* d_x, double* d_y, double alpha,
+                                       double beta);
+
 /* Downloads the device CSR of an initialised CSR-based operator (tests compare
  * it with build_csr_struct's host result). Any pointer may be NULL. */
 int spmv_amd_download_device_csr(const char* mode, int* row_ptr, int* col_idx, double* values);

@@ -226,3 +226,27 @@ def test_degenerate_inputs(B, O, fresh_host_matrices):
     got, _ = op.run_timed(np.array([3.0]))
     assert got[0] == 15.0
     op.free()
+
+
+@pytest.mark.parametrize("name", ["ellpack", "stencil5-ellpack"])
+def test_ellpack_alpha_beta_contract(B, O, fresh_host_matrices, name):
+    """y = alpha*A*x + beta*y (reference include/spmv_stencil.h:25-42), bit for bit against the oracle."""
+    n = 130
+    e, x = random_stencil(O, n, 77)
+    m = B.HostMatrix(e, n * n, n * n, n)
+    op = B.Operator(name)
+    assert op.init(m) == 0
+    rp, ci, va = O.build_csr(e, n * n)
+    y0 = np.random.default_rng(5).standard_normal(n * n)
+    base = O.spmv_stencil5(rp, ci, va, x, n) if name == "stencil5-ellpack" else O.spmv_csr(rp, ci, va, x)
+    for alpha, beta in ((1.0, 0.0), (2.5, 0.0), (1.0, 1.0), (-0.75, 3.0)):
+        dx, dy = B.DeviceVector.from_host(x), B.DeviceVector.from_host(y0)
+        assert B.lib().spmv_amd_ellpack_run_device_scaled(name.encode(), dx.ptr, dy.ptr, alpha, beta) == 0
+        got = dy.to_host()
+        want = alpha * base if beta == 0.0 else np.array([np.float64(alpha) * s + np.float64(beta) * y for s, y in zip(base, y0)])
+        if beta == 0.0:
+            assert np.array_equal(got, want)
+        else:  # fma(alpha, sum, beta*y): one rounding fewer than the numpy expression
+            assert np.max(np.abs(got - want)) <= 4e-16 * np.max(np.abs(want)) * 4
+        dx.free(), dy.free()
+    op.free()
