@@ -61,6 +61,14 @@ int main(int argc, char** argv) {
             fclose(f);
         }
         comm = spmv_amd_comm_create_rccl(rank, world, id);
+        if (comm == nullptr) {
+            fprintf(stderr, "[Rank %d] RCCL communicator could not be created (one rank per GPU is required)\n", rank);
+            return 1;
+        }
+        if (spmv_amd_comm_selftest(comm) != 0) {
+            fprintf(stderr, "[Rank %d] communicator self-test failed\n", rank);
+            return 1;
+        }
         spmv_amd_comm_set_world(comm);
     }
 
