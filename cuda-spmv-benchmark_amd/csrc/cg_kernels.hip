@@ -211,7 +211,9 @@ __global__ __launch_bounds__(kBlock) void cg_update_r_kernel(size_t n, const CgS
                                                              double* __restrict__ r,
                                                              double* __restrict__ partials) {
     if (s->converged) return;
-    const double alpha = s->alpha;
+    // alpha = rr_old / pAp from the (all-reduced) dot product: one IEEE division of two wave-uniform
+    // scalars per thread, the same value the scalar step stores for the x update further down
+    const double alpha = s->rr_old / s->pAp;
     double acc = 0.0;
     SPMV_AMD_STREAM_LOOP(n) {
         const d2 av = reinterpret_cast<const d2*>(Ap)[i];
@@ -272,19 +274,12 @@ __global__ void cg_scalars_init_kernel(CgScalars* s, double* history) {
     if (history != nullptr && s->max_history > 0) history[0] = s->b_norm;
 }
 
-// pAp holds the (all-reduced) p.Ap: alpha = rr_old / pAp (host division in the reference,
-// cg_solver_mgpu_partitioned.cu:589; scalar_divide_kernel in cg_solver.cu:564).
-__global__ void cg_scalars_alpha_kernel(CgScalars* s) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    if (s->converged) return;
-    s->alpha = s->rr_old / s->pAp;
-}
-
 // rr_new holds the (all-reduced) new r.r: stopping test (strict <, on ||r||/||r0||), iteration
 // count including the converging iteration, beta, rr_old <- rr_new (mgpu :652-676,716).
 __global__ void cg_scalars_step_kernel(CgScalars* s, double tol, double* history) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     if (s->converged) return;
+    s->alpha = s->rr_old / s->pAp;  // the alpha update_r used (same division), kept for the x update
     const double res = sqrt(s->rr_new);
     s->residual = res;
     s->iterations += 1;
@@ -393,10 +388,6 @@ int reduce_stage_doubles() { return kReduceStageBlocks; }
 
 void launch_cg_scalars_init(CgScalars* s, double* history, hipStream_t stream) {
     hipLaunchKernelGGL(cg_scalars_init_kernel, dim3(1), dim3(1), 0, stream, s, history);
-}
-
-void launch_cg_scalars_alpha(CgScalars* s, hipStream_t stream) {
-    hipLaunchKernelGGL(cg_scalars_alpha_kernel, dim3(1), dim3(1), 0, stream, s);
 }
 
 void launch_cg_scalars_step(CgScalars* s, double tol, double* history, hipStream_t stream) {

@@ -321,7 +321,6 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
             HIP_CHECK(hipEventRecord(s->spmv_ev[2 * enqueued + 1], s->compute));
         }
         if (reduce) timed(&stats->time_allreduce_ms, nullptr, [&] { comm->allreduce_sum(&s->d_s->pAp, 1, s->compute); });
-        launch_cg_scalars_alpha(s->d_s, s->compute);
         timed(&stats->time_blas1_ms, &stats->time_axpy_update_r_ms, [&] {
             launch_cg_update_r(nl, s->d_s, s->Ap, s->r, s->partials_blas, s->compute);
         });

@@ -118,7 +118,7 @@ void launch_check_convergence(const double* d_rr_new, double b_norm, double tol,
 // r = b - Ap ; p = r ; partials of r.r
 void launch_cg_init_residual(size_t n, const double* b, const double* Ap, double* r, double* p,
                              double* partials, hipStream_t stream);
-// r -= alpha Ap ; partials of r.r
+// alpha = rr_old / pAp (per thread, from the scalars) ; r -= alpha Ap ; partials of r.r
 void launch_cg_update_r(size_t n, const CgScalars* s, const double* Ap, double* r, double* partials,
                         hipStream_t stream);
 // x += alpha p (the update of iteration `iteration`), then p = 1.0*r + beta*p unless that iteration
@@ -134,7 +134,6 @@ void launch_reduce_partials(const double* partials, int count, double* d_out,
 // After the (all-reduced) r.r is known: b_norm (first call), residual, history, convergence
 // flag, beta, rr_old <- rr_new, iteration counter.
 void launch_cg_scalars_init(CgScalars* s, double* history, hipStream_t stream);
-void launch_cg_scalars_alpha(CgScalars* s, hipStream_t stream);
 void launch_cg_scalars_step(CgScalars* s, double tol, double* history, hipStream_t stream);
 
 }  // namespace spmv_amd
