@@ -276,20 +276,29 @@ __global__ void cg_scalars_init_kernel(CgScalars* s, double* history) {
 
 // rr_new holds the (all-reduced) new r.r: stopping test (strict <, on ||r||/||r0||), iteration
 // count including the converging iteration, beta, rr_old <- rr_new (mgpu :652-676,716).
-__global__ void cg_scalars_step_kernel(CgScalars* s, double tol, double* history) {
+__global__ void cg_scalars_step_kernel(CgScalars* s, double tol, double* history, int* host_record,
+                                       int sequence) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    if (s->converged) return;
-    s->alpha = s->rr_old / s->pAp;  // the alpha update_r used (same division), kept for the x update
-    const double res = sqrt(s->rr_new);
-    s->residual = res;
-    s->iterations += 1;
-    if (history != nullptr && s->iterations < s->max_history) history[s->iterations] = res;
-    if (res / s->b_norm < tol) {
-        s->converged = 1;
-        return;
+    if (!s->converged) {
+        s->alpha = s->rr_old / s->pAp;  // the alpha update_r used (same division), kept for the x update
+        const double res = sqrt(s->rr_new);
+        s->residual = res;
+        s->iterations += 1;
+        if (history != nullptr && s->iterations < s->max_history) history[s->iterations] = res;
+        if (res / s->b_norm < tol) {
+            s->converged = 1;
+        } else {
+            s->beta = s->rr_new / s->rr_old;
+            s->rr_old = s->rr_new;
+        }
     }
-    s->beta = s->rr_new / s->rr_old;
-    s->rr_old = s->rr_new;
+    if (host_record != nullptr) {
+        // status record in host-coherent pinned memory: payload first, then the sequence number with
+        // system-scope release, so a host that sees `sequence` sees this iteration's payload
+        host_record[1] = s->converged;
+        host_record[2] = s->iterations;
+        __hip_atomic_store(&host_record[0], sequence, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 inline unsigned stream_grid(size_t n) {
@@ -390,8 +399,10 @@ void launch_cg_scalars_init(CgScalars* s, double* history, hipStream_t stream) {
     hipLaunchKernelGGL(cg_scalars_init_kernel, dim3(1), dim3(1), 0, stream, s, history);
 }
 
-void launch_cg_scalars_step(CgScalars* s, double tol, double* history, hipStream_t stream) {
-    hipLaunchKernelGGL(cg_scalars_step_kernel, dim3(1), dim3(1), 0, stream, s, tol, history);
+void launch_cg_scalars_step(CgScalars* s, double tol, double* history, int* host_record, int sequence,
+                            hipStream_t stream) {
+    hipLaunchKernelGGL(cg_scalars_step_kernel, dim3(1), dim3(1), 0, stream, s, tol, history, host_record,
+                       sequence);
 }
 
 }  // namespace spmv_amd

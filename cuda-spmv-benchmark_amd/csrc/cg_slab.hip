@@ -48,9 +48,9 @@ struct SpmvAmdCgSlab {
     CgScalars* d_s = nullptr;
     double* d_hist = nullptr;
     int hist_cap = 0;
-    struct Poll { int converged; int iterations; }* h_poll = nullptr;  // pinned
+    struct Poll { int sequence; int converged; int iterations; int pad; }* h_poll = nullptr;  // pinned, host-coherent
     hipStream_t compute = nullptr, side = nullptr;
-    hipEvent_t ev_p_ready = nullptr, ev_halo_done = nullptr, ev_poll = nullptr;
+    hipEvent_t ev_p_ready = nullptr, ev_halo_done = nullptr;
     LaunchShape shape;
     int partials_cap = 0;
     const char* variant_name = "";
@@ -59,6 +59,7 @@ struct SpmvAmdCgSlab {
     // event pairs around every in-loop SpMV (recorded without any host sync, resolved after the
     // loop) so that time_spmv_ms is the live sum over the timed region even with timers off
     std::vector<hipEvent_t> spmv_ev;
+    int poll_sequence = 0;
     double last_spmv_ms = 0.0;
     int last_spmv_launches = 0;
 };
@@ -81,7 +82,6 @@ void make_common(SpmvAmdCgSlab* s) {
     }
     HIP_CHECK(hipEventCreateWithFlags(&s->ev_p_ready, hipEventDisableTiming));
     HIP_CHECK(hipEventCreateWithFlags(&s->ev_halo_done, hipEventDisableTiming));
-    HIP_CHECK(hipEventCreateWithFlags(&s->ev_poll, hipEventDisableTiming));
     s->x = device_alloc<double>(nl);
     s->x0 = device_alloc<double>(nl);
     s->r = device_alloc<double>(nl);
@@ -96,7 +96,8 @@ void make_common(SpmvAmdCgSlab* s) {
     s->reduce_stage = device_alloc<double>((size_t)reduce_stage_doubles());
     s->d_s = device_alloc<CgScalars>(1);
     HIP_CHECK(hipMemset(s->d_s, 0, sizeof(CgScalars)));
-    HIP_CHECK(hipHostMalloc((void**)&s->h_poll, sizeof(*s->h_poll), hipHostMallocDefault));
+    HIP_CHECK(hipHostMalloc((void**)&s->h_poll, sizeof(*s->h_poll), hipHostMallocCoherent | hipHostMallocMapped));
+    memset(s->h_poll, 0, sizeof(*s->h_poll));
     s->A.verify_stencil(s->compute);
     {
         // dot partials: one slot per launched wave; the launch geometry is a fixed function of the
@@ -167,6 +168,23 @@ void slab_spmv(SpmvAmdCgSlab* s, bool with_dot, bool overlap, const int* skip,
             launch_reduce_partials(part, used, &s->d_s->pAp, skip, s->compute, s->reduce_stage);
         else
             launch_dot((size_t)s->n_local, s->p, s->Ap, s->partials_blas, &s->d_s->pAp, s->compute);
+    }
+}
+
+// Blocks the host until the scalar step of the iteration just enqueued has published its record.
+void wait_for_status(SpmvAmdCgSlab* s) {
+    volatile int* seq = &s->h_poll->sequence;
+    long spins = 0;
+    while (__atomic_load_n(seq, __ATOMIC_ACQUIRE) != s->poll_sequence) {
+        if (++spins % (1L << 22) == 0) {
+            // nothing should take this long: surface a faulted or wedged stream instead of spinning for ever
+            const hipError_t e = hipStreamQuery(s->compute);
+            if (e != hipSuccess && e != hipErrorNotReady) HIP_CHECK(e);
+            if (e == hipSuccess && __atomic_load_n(seq, __ATOMIC_ACQUIRE) != s->poll_sequence) {
+                fprintf(stderr, "[cg-slab] status record missing after the stream drained\n");
+                exit(EXIT_FAILURE);
+            }
+        }
     }
 }
 
@@ -328,11 +346,11 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
             launch_reduce_partials(s->partials_blas, cg_partial_count(nl), &s->d_s->rr_new, skip, s->compute, s->reduce_stage);
         });
         if (reduce) timed(&stats->time_allreduce_ms, nullptr, [&] { comm->allreduce_sum(&s->d_s->rr_new, 1, s->compute); });
-        launch_cg_scalars_step(s->d_s, config->tolerance, s->d_hist, s->compute);
-        // 8-byte status record of this iteration, read by the host further down
-        HIP_CHECK(hipMemcpyAsync(s->h_poll, &s->d_s->converged, sizeof(*s->h_poll),
-                                 hipMemcpyDeviceToHost, s->compute));
-        HIP_CHECK(hipEventRecord(s->ev_poll, s->compute));
+        // the scalar step publishes {sequence, converged, iterations} straight into host-coherent pinned
+        // memory: no copy command sits between it and the p update on the stream
+        ++s->poll_sequence;
+        launch_cg_scalars_step(s->d_s, config->tolerance, s->d_hist, &s->h_poll->sequence, s->poll_sequence,
+                               s->compute);
         ++enqueued;
 
         // p <- r + beta p, its halo exchange, and (when overlapping) nothing else before the host
@@ -341,7 +359,7 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
             launch_cg_update_px(nl, s->d_s, s->r, s->p, s->x, enqueued, s->compute);
         });
         start_p_halo();
-        HIP_CHECK(hipEventSynchronize(s->ev_poll));
+        wait_for_status(s);
         if (s->h_poll->converged) done = true;
         if (config->verbose >= 2 && comm->rank == 0) {
             CgScalars now;
@@ -456,7 +474,6 @@ extern "C" void spmv_amd_cg_slab_destroy(SpmvAmdCgSlab* s) {
     for (hipEvent_t e : s->spmv_ev) (void)hipEventDestroy(e);
     (void)hipEventDestroy(s->ev_p_ready);
     (void)hipEventDestroy(s->ev_halo_done);
-    (void)hipEventDestroy(s->ev_poll);
     (void)hipStreamDestroy(s->compute);
     (void)hipStreamDestroy(s->side);
     delete s;

@@ -134,6 +134,9 @@ void launch_reduce_partials(const double* partials, int count, double* d_out,
 // After the (all-reduced) r.r is known: b_norm (first call), residual, history, convergence
 // flag, beta, rr_old <- rr_new, iteration counter.
 void launch_cg_scalars_init(CgScalars* s, double* history, hipStream_t stream);
-void launch_cg_scalars_step(CgScalars* s, double tol, double* history, hipStream_t stream);
+// host_record (may be null): three ints in host-coherent pinned memory, {sequence, converged, iterations};
+// the kernel publishes the iteration's status there so the host needs no copy command on the stream.
+void launch_cg_scalars_step(CgScalars* s, double tol, double* history, int* host_record, int sequence,
+                            hipStream_t stream);
 
 }  // namespace spmv_amd
