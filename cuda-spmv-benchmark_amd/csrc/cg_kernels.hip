@@ -236,16 +236,18 @@ __global__ __launch_bounds__(kBlock) void cg_update_r_kernel(size_t n, const CgS
 // one pass over p (the reference reads p twice: axpy_kernel(alpha, p, x) :598 and axpby_kernel :682).
 // Same per-element arithmetic, so results are unchanged. A launch enqueued for an iteration beyond
 // the converging one finds s->iterations != iteration and does nothing.
+// x_in is x itself except in the first iteration of a solve, where it is the stored initial guess:
+// the solve never has to copy x0 into x first.
 __global__ __launch_bounds__(kBlock) void cg_update_px_kernel(size_t n, const CgScalars* __restrict__ s,
                                                               const double* __restrict__ r,
                                                               double* __restrict__ p,
-                                                              double* __restrict__ x, int iteration) {
+                                                              const double* x_in, double* x, int iteration) {
     if (s->iterations != iteration) return;
     const bool advance = s->converged == 0;
     const double alpha = s->alpha, beta = s->beta;
     SPMV_AMD_STREAM_LOOP(n) {
         d2 pv = reinterpret_cast<d2*>(p)[i];
-        d2 xv = reinterpret_cast<d2*>(x)[i];
+        d2 xv = reinterpret_cast<const d2*>(x_in)[i];
         xv.x = fma(alpha, pv.x, xv.x);
         xv.y = fma(alpha, pv.y, xv.y);
         reinterpret_cast<d2*>(x)[i] = xv;
@@ -258,7 +260,7 @@ __global__ __launch_bounds__(kBlock) void cg_update_px_kernel(size_t n, const Cg
     }
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
         const double pv = p[n - 1];
-        x[n - 1] = fma(alpha, pv, x[n - 1]);
+        x[n - 1] = fma(alpha, pv, x_in[n - 1]);
         if (advance) p[n - 1] = fma(1.0, r[n - 1], beta * pv);
     }
 }
@@ -370,9 +372,9 @@ void launch_cg_update_r(size_t n, const CgScalars* s, const double* Ap, double* 
     hipLaunchKernelGGL(cg_update_r_kernel, dim3(stream_grid(n)), dim3(kBlock), 0, stream, n, s, Ap, r, partials);
 }
 
-void launch_cg_update_px(size_t n, const CgScalars* s, const double* r, double* p, double* x, int iteration,
-                         hipStream_t stream) {
-    hipLaunchKernelGGL(cg_update_px_kernel, dim3(stream_grid(n)), dim3(kBlock), 0, stream, n, s, r, p, x,
+void launch_cg_update_px(size_t n, const CgScalars* s, const double* r, double* p, const double* x_in,
+                         double* x, int iteration, hipStream_t stream) {
+    hipLaunchKernelGGL(cg_update_px_kernel, dim3(stream_grid(n)), dim3(kBlock), 0, stream, n, s, r, p, x_in, x,
                        iteration);
 }
 

@@ -123,8 +123,9 @@ void launch_cg_update_r(size_t n, const CgScalars* s, const double* Ap, double* 
                         hipStream_t stream);
 // x += alpha p (the update of iteration `iteration`), then p = 1.0*r + beta*p unless that iteration
 // converged; one pass over p (axpy + axpby of cg_solver_mgpu_partitioned.cu:598,682 fused).
-void launch_cg_update_px(size_t n, const CgScalars* s, const double* r, double* p, double* x,
-                         int iteration, hipStream_t stream);
+// x = x_in + alpha p: x_in is x, or the stored initial guess in the first iteration of a solve.
+void launch_cg_update_px(size_t n, const CgScalars* s, const double* r, double* p, const double* x_in,
+                         double* x, int iteration, hipStream_t stream);
 int cg_partial_count(size_t n);  // partial slots written by the two reducing kernels above
 // *d_out = sum of partials[0..count) in a fixed order. `stage` (reduce_stage_doubles() doubles,
 // may be null) lets large counts be summed by many blocks first.

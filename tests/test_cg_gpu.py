@@ -201,3 +201,22 @@ def test_slab_solver_on_a_general_spd_matrix(B, O, fresh_host_matrices):
     x, hist, st2 = B.cg_solve(op, m, b, np.zeros(n), tol=1e-9, device=True)
     assert st2.iterations == ro.iterations and hist_err(hist, ho) < TOL
     op.free()
+
+
+def test_slab_solver_nonzero_initial_guess_and_zero_iterations(B, O, fresh_host_matrices):
+    """x0 != 0 (the first x update reads the stored x0, x is never pre-copied) and max_iters = 0."""
+    n = 130
+    rng = np.random.default_rng(3)
+    b, x0 = rng.standard_normal(n * n), rng.standard_normal(n * n)
+    m = B.HostMatrix(O.stencil5_coo(n), n * n, n * n, n)
+    slab = B.CgSlab.from_matrix(m)
+    slab.set_vectors(b, x0)
+    rp, ci, va = O.stencil5_csr(n)
+    xo, ho, ro = O.cg_partitioned(rp, ci, va, n, b, x0, world=1)
+    for _ in range(2):  # the second solve must start from x0 again, not from the first solution
+        st = slab.solve()
+        assert st.iterations == ro.iterations and hist_err(slab.history(), ho) < TOL
+        assert np.max(np.abs(slab.gather() - xo)) <= TOL * np.max(np.abs(xo))
+    st0 = slab.solve(max_iters=0)
+    assert st0.iterations == 0 and st0.converged == 0 and np.array_equal(slab.gather(), x0)
+    slab.destroy()
