@@ -14,7 +14,9 @@
 // indexes an unsorted list there, benchmark_stats.cu:169-170).
 // JSON/CSV key names are the reference's, so scripts that scrape "execution_time_ms" or
 // "median_ms" keep working.
+#include <dlfcn.h>
 #include <math.h>
+#include <stdint.h>
 #include <string.h>
 #include <time.h>
 
@@ -175,6 +177,33 @@ extern "C" void calculate_spmv_metrics(double execution_time_ms, const MatrixDat
     metrics->bandwidth_gb_s = (t.total_bytes / secs) / 1e9;
 }
 
+namespace {
+// Temperature / power through ROCm SMI when the library is present (the reference shells out to
+// nvidia-smi for the same fields, gpu_detection.cu:41-74). Loaded lazily with dlopen so that the
+// product has no link-time dependency on it; every field stays 0 when it is unavailable.
+void fill_smi_fields(int device, BenchmarkMetrics* metrics) {
+    void* smi = dlopen("librocm_smi64.so", RTLD_NOW | RTLD_LOCAL);
+    if (!smi) smi = dlopen("/opt/rocm/lib/librocm_smi64.so", RTLD_NOW | RTLD_LOCAL);
+    if (!smi) return;
+    typedef int (*init_fn)(uint64_t);
+    typedef int (*temp_fn)(uint32_t, uint32_t, int, int64_t*);
+    typedef int (*power_fn)(uint32_t, uint64_t*);
+    typedef int (*cap_fn)(uint32_t, uint32_t, uint64_t*);
+    init_fn init = (init_fn)dlsym(smi, "rsmi_init");
+    temp_fn temp = (temp_fn)dlsym(smi, "rsmi_dev_temp_metric_get");
+    power_fn power = (power_fn)dlsym(smi, "rsmi_dev_current_socket_power_get");
+    cap_fn cap = (cap_fn)dlsym(smi, "rsmi_dev_power_cap_get");
+    if (init && init(0) == 0) {
+        int64_t milli_c = 0;
+        uint64_t micro_w = 0;
+        if (temp && temp((uint32_t)device, /*RSMI_TEMP_TYPE_EDGE*/ 0, /*RSMI_TEMP_CURRENT*/ 0, &milli_c) == 0)
+            metrics->gpu_info.current_temp_c = (int)(milli_c / 1000);
+        if (power && power((uint32_t)device, &micro_w) == 0) metrics->gpu_info.power_draw_w = (int)(micro_w / 1000000);
+        if (cap && cap((uint32_t)device, 0, &micro_w) == 0) metrics->gpu_info.power_limit_w = (int)(micro_w / 1000000);
+    }
+}
+}  // namespace
+
 extern "C" int get_gpu_properties(BenchmarkMetrics* metrics) {
     memset(&metrics->gpu_info, 0, sizeof(metrics->gpu_info));
     int dev = 0;
@@ -212,6 +241,7 @@ extern "C" int get_gpu_properties(BenchmarkMetrics* metrics) {
         }
         fclose(f);
     }
+    fill_smi_fields(dev, metrics);
     if (FILE* f = fopen("/proc/meminfo", "r")) {
         long kb = 0;
         if (fscanf(f, "MemTotal: %ld kB", &kb) == 1) metrics->gpu_info.system_ram_gb = (int)(kb / (1024 * 1024));

@@ -39,6 +39,7 @@ def test_spmv_bench_on_shipped_matrix(tmp_path):
         assert d["benchmark"]["operator"] == mode and d["benchmark"]["matrix"]["nnz"] == 32481
         assert d["benchmark"]["performance"]["execution_time_ms"] > 0  # key scraped by scripts/run_all.sh
         assert d["benchmark"]["validation"]["sum_y"] == -52164.0
+        assert d["gpu"]["name"] and d["gpu"]["multiprocessor_count"] > 0 and d["system"]["cpu_model"]
         assert os.path.exists(tmp_path / f"res_{mode}.csv")
 
 
