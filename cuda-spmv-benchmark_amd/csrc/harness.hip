@@ -196,8 +196,10 @@ void fill_smi_fields(int device, BenchmarkMetrics* metrics) {
     if (init && init(0) == 0) {
         int64_t milli_c = 0;
         uint64_t micro_w = 0;
-        if (temp && temp((uint32_t)device, /*RSMI_TEMP_TYPE_EDGE*/ 0, /*RSMI_TEMP_CURRENT*/ 0, &milli_c) == 0)
-            metrics->gpu_info.current_temp_c = (int)(milli_c / 1000);
+        // edge, junction (hotspot), memory: the first sensor the board exposes
+        for (uint32_t sensor = 0; temp && sensor < 3 && metrics->gpu_info.current_temp_c == 0; ++sensor)
+            if (temp((uint32_t)device, sensor, /*RSMI_TEMP_CURRENT*/ 0, &milli_c) == 0)
+                metrics->gpu_info.current_temp_c = (int)(milli_c / 1000);
         if (power && power((uint32_t)device, &micro_w) == 0) metrics->gpu_info.power_draw_w = (int)(micro_w / 1000000);
         if (cap && cap((uint32_t)device, 0, &micro_w) == 0) metrics->gpu_info.power_limit_w = (int)(micro_w / 1000000);
     }
@@ -209,7 +211,10 @@ extern "C" int get_gpu_properties(BenchmarkMetrics* metrics) {
     int dev = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 1;
-    snprintf(metrics->gpu_info.name, sizeof metrics->gpu_info.name, "%s", prop.name);
+    if (prop.name[0] != '\0')
+        snprintf(metrics->gpu_info.name, sizeof metrics->gpu_info.name, "%s", prop.name);
+    else  // some driver stacks leave the marketing name empty
+        snprintf(metrics->gpu_info.name, sizeof metrics->gpu_info.name, "AMD GPU (%s)", prop.gcnArchName);
     metrics->gpu_info.memory_mb = (int)(prop.totalGlobalMem / (1024 * 1024));
     snprintf(metrics->gpu_info.compute_capability, sizeof metrics->gpu_info.compute_capability, "%s",
              prop.gcnArchName);
