@@ -12,7 +12,7 @@ configuration of reference docs/PROBLEM_SIZE_SCALING_RESULTS.md:40-47, on N row 
   value     CG iterations per second, whole job = K * iterations / (max over ranks of the time
             of K steps, bracketed by barrier + torch.cuda.synchronize() on both sides).
   scaling   strong: the 400 M-unknown problem is fixed, slabs shrink as N grows.
-  roofline  the dominant kernel of the timed region, the STENCIL5 row-direct SpMV (fused with the
+  roofline  the dominant kernel of the timed region, the STENCIL5 row-lds SpMV (fused with the
             p.Ap partials): algorithmic bytes of one launch (8*nnz + 8*cols + 8*rows of the slab,
             SURVEY.md 8d) / its average duration, from HIP events recorded on the solver's stream
             around every in-loop launch of the timed steps. Peak 8 TB/s (MI355X_MICROARCH.md).
@@ -208,6 +208,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t[0])
     hist = slab.history()
+    kernel_name = {"stencil5/row-lds": "stencil5_rowlds_kernel<true>", "stencil5/row-direct": "stencil5_rowdirect_kernel<1, true>"}.get(
+        slab.variant(), slab.variant()) + " (SpMV + p.Ap partials)"
 
     # dominant kernel: STENCIL5 SpMV of this rank's slab, average over the launches of the timed steps
     local_rows, local_nnz = slab.n_local, slab.local_nnz if slab.local_nnz > 0 else None
@@ -226,7 +228,7 @@ def main():
         except (OSError, ValueError):
             pass
     roofline = {
-        "bound": "hbm", "kernel": "stencil5_rowdirect_kernel<1, true> (SpMV + p.Ap partials)", "achieved": achieved, "peak": HBM_PEAK_GBS,
+        "bound": "hbm", "kernel": kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS,
         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
         "avg_launch_ms": avg_spmv_ms, "launches_timed": spmv_launches,
         "traffic_note": "L2-to-fabric bytes per launch from separate rocprofv3 --pmc passes (profiles/hbm_traffic.json); Infinity-Cache hits included" if traffic else None,

@@ -90,7 +90,7 @@ DECLARED_SYMBOLS = [
     "spmv_amd_comm_create_staged", "spmv_amd_comm_destroy", "spmv_amd_comm_set_world", "spmv_amd_comm_rank", "spmv_amd_comm_size", "spmv_amd_comm_selftest",
     "spmv_amd_cg_slab_create", "spmv_amd_cg_slab_create_stencil5", "spmv_amd_cg_slab_set_vectors", "spmv_amd_cg_slab_solve",
     "spmv_amd_cg_slab_gather", "spmv_amd_cg_slab_history", "spmv_amd_cg_slab_spmv", "spmv_amd_cg_slab_info",
-    "spmv_amd_cg_slab_time_spmv", "spmv_amd_cg_slab_destroy", "spmv_amd_version", "spmv_amd_write_stencil5_values",
+    "spmv_amd_cg_slab_time_spmv", "spmv_amd_cg_slab_variant", "spmv_amd_cg_slab_destroy", "spmv_amd_version", "spmv_amd_write_stencil5_values",
 ]
 # C++-linkage entry points kept under the reference's own names (Itanium-mangled).
 DECLARED_CXX_SYMBOLS = [
@@ -165,6 +165,8 @@ def lib():
     L.spmv_amd_cg_slab_info.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.spmv_amd_cg_slab_time_spmv.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float)]
     L.spmv_amd_cg_slab_destroy.argtypes = [C.c_void_p]
+    L.spmv_amd_cg_slab_variant.restype = C.c_char_p
+    L.spmv_amd_cg_slab_variant.argtypes = [C.c_void_p]
     L.load_matrix_market.argtypes = [C.c_char_p, C.POINTER(MatrixData)]
     L.write_matrix_market_stencil5.argtypes = [C.c_int, C.c_char_p]
     L.spmv_amd_write_stencil5_values.argtypes = [C.c_int, C.c_char_p, C.c_char_p, C.c_char_p]
@@ -478,6 +480,9 @@ class CgSlab:
         y = np.zeros(self.n_local, dtype=np.float64)
         lib().spmv_amd_cg_slab_spmv(self.h, x_full.ctypes.data, y.ctypes.data)
         return y
+
+    def variant(self):
+        return lib().spmv_amd_cg_slab_variant(self.h).decode()
 
     def time_spmv(self, reps):
         ms = (C.c_float * reps)()

@@ -138,8 +138,9 @@ bool partition_ok(const SpmvAmdComm* comm, int n, int grid, int n_local) {
 
 // SpMV of the slab on p (halos must be current or in flight on the side stream).
 // overlap = the halo exchange was started on the side stream and ev_halo_done marks its end.
+// spmv_done (optional): recorded behind the last SpMV launch, before the reduction of its partials.
 void slab_spmv(SpmvAmdCgSlab* s, bool with_dot, bool overlap, const int* skip,
-               const double* input = nullptr) {
+               const double* input = nullptr, hipEvent_t spmv_done = nullptr) {
     const SlabCsr& A = s->A.view;
     const double* in = input ? input : s->p;
     double* part = (with_dot && s->fused_dot) ? s->partials_spmv : nullptr;
@@ -163,6 +164,7 @@ void slab_spmv(SpmvAmdCgSlab* s, bool with_dot, bool overlap, const int* skip,
             used += launch_stencil5_spmv(A, s->p, s->Ap, 1.0, hi, s->n_local, part ? part + used : nullptr,
                                          skip, Stencil5Variant::Auto, s->shape, s->compute);
     }
+    if (spmv_done) HIP_CHECK(hipEventRecord(spmv_done, s->compute));
     if (with_dot) {
         if (part)
             launch_reduce_partials(part, used, &s->d_s->pAp, skip, s->compute, s->reduce_stage);
@@ -336,8 +338,7 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
                 s->spmv_ev.push_back(e);
             }
             HIP_CHECK(hipEventRecord(s->spmv_ev[2 * enqueued], s->compute));
-            slab_spmv(s, true, halo_in_flight, skip);
-            HIP_CHECK(hipEventRecord(s->spmv_ev[2 * enqueued + 1], s->compute));
+            slab_spmv(s, true, halo_in_flight, skip, nullptr, s->spmv_ev[2 * enqueued + 1]);
         }
         if (reduce) timed(&stats->time_allreduce_ms, nullptr, [&] { comm->allreduce_sum(&s->d_s->pAp, 1, s->compute); });
         timed(&stats->time_blas1_ms, &stats->time_axpy_update_r_ms, [&] {
@@ -441,6 +442,8 @@ extern "C" void spmv_amd_cg_slab_info(const SpmvAmdCgSlab* s, int* row_offset, i
     if (n_local) *n_local = s->n_local;
     if (local_nnz) *local_nnz = (int)s->A.view.nnz_local;
 }
+
+extern "C" const char* spmv_amd_cg_slab_variant(const SpmvAmdCgSlab* s) { return s->variant_name; }
 
 extern "C" int spmv_amd_cg_slab_time_spmv(SpmvAmdCgSlab* s, int reps, float* ms_each) {
     HIP_CHECK(hipMemsetAsync(&s->d_s->converged, 0, sizeof(int), s->compute));

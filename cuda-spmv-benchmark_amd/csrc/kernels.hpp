@@ -44,7 +44,7 @@ void launch_verify_stencil5_csr(const SlabCsr& m, int* d_mismatch, hipStream_t s
 // ---- STENCIL5 SpMV ----
 // y[r] = alpha * (A x)[r]. d_dot_partials, if non-null, receives one partial of
 // sum_r x[r]*y_unscaled[r] per launched wave (count: stencil5_partials_needed()).
-enum class Stencil5Variant { Auto, RowDirect, ColumnMarch, WaveTile, RowGeneric };
+enum class Stencil5Variant { Auto, RowDirect, ColumnMarch, WaveTile, RowGeneric, RowLds };
 // Partial-sum slots a launch over [first_row, last_row) writes (a fixed function of the slab, the
 // range and the launch shape, so reductions keep one shape for the life of a solver).
 int stencil5_partials_needed(const SlabCsr& m, int first_row, int last_row, Stencil5Variant variant,

@@ -86,7 +86,7 @@ void stencil_pick_variant() {
 }
 
 int stencil_init(MatrixData* mat) {
-    printf("[stencil5-csr] Initializing (computed offsets, row-direct kernel on gfx950)\n");
+    printf("[stencil5-csr] Initializing (computed offsets, row-lds / row-direct kernels on gfx950)\n");
     if (g_stencil.init_from_host(mat) != 0) return EXIT_FAILURE;
     g_stencil.A.verify_stencil(kDefaultStream);
     stencil_pick_variant();
@@ -412,6 +412,7 @@ extern "C" int spmv_amd_operator_select_variant(const char* mode, const char* va
     switch (which_operator(mode)) {
         case Which::Stencil:
             if (automatic) g_stencil.stencil_variant = Stencil5Variant::Auto;
+            else if (!strcmp(variant, "row-lds")) g_stencil.stencil_variant = Stencil5Variant::RowLds;
             else if (!strcmp(variant, "row-direct")) g_stencil.stencil_variant = Stencil5Variant::RowDirect;
             else if (!strcmp(variant, "column-march")) g_stencil.stencil_variant = Stencil5Variant::ColumnMarch;
             else if (!strcmp(variant, "wave-tile")) g_stencil.stencil_variant = Stencil5Variant::WaveTile;

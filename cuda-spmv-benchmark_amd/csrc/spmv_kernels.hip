@@ -454,6 +454,139 @@ __global__ __launch_bounds__(kBlock) void stencil5_rowdirect_kernel(
 }
 
 // ---------------------------------------------------------------------------------
+// STENCIL5, row-lds variant (default on slabs made of whole grid rows, n >= 512). Same index space
+// as row-direct -- a workgroup is a run of columns of ONE grid row, so no thread divides -- but the
+// coefficients take the streaming path the probes found fastest on MI355X
+// (tools/stream_probe3.hip, profiles/r01_stream_probe3.txt):
+//   * a workgroup is ONE wavefront that owns 128 consecutive columns, two rows per lane (columns
+//     j0 + lane and j0 + 64 + lane): every x / y access stays an 8-byte-per-lane coalesced access;
+//   * the tile's 640 coefficients are one contiguous run of `values` (five entries per interior
+//     row): ten fully coalesced 8-byte NONTEMPORAL loads per lane -- the run is read once and never
+//     again, so it should not displace x in L2 / Infinity Cache -- parked in a 5 KiB wave-private
+//     LDS strip and read back as [N,W,C,E,S] per row (lane stride 40 B = 10 banks, an even stride
+//     over 64 banks: conflict-free for 8-byte reads);
+//   * y leaves with a nontemporal store;
+//   * x: centre, W/E from the same cache lines, N/S from the lines the neighbouring grid rows pull
+//     through L2 / Infinity Cache (plain loads: these are the re-used bytes);
+//   * tile -> XCD: workgroups are dealt round-robin to the eight XCDs, so tile = blockIdx would
+//     scatter every 1 KiB of x / y over eight L2s. Instead each XCD takes `group` consecutive tiles
+//     of every run of 8 * group (group = 4: 512 columns = 4 KiB of x and y, 20 KiB of values per
+//     XCD and run). Measured at 20 000^2 with the real coefficient layout: group 1 3.89 ms,
+//     group 2 4.04 ms, group 4 / 8 3.63 ms, group 16 3.73 ms -- a plateau, not a spike.
+// Columns 0 and n-1 of an interior grid row (4-entry rows) are evaluated from the same strip in the
+// CSR loop's order (ascending column, sum started at 0: reference :116-119); only the first and
+// last grid row of the whole grid, whose rows have no N or S entry, walk row_ptr / col_idx.
+// No barrier: the strip is private to the wave, and LDS operations of one wave retire in order.
+// Arithmetic per interior row is exactly row-direct's (and the reference's) W,C,E,N,S fma chain.
+// ---------------------------------------------------------------------------------
+constexpr int kLdsTileCols = 128;
+
+template <bool kDot>
+__global__ __launch_bounds__(64) void stencil5_rowlds_kernel(
+    SlabCsr m, const double* __restrict__ x, double* __restrict__ y, double alpha, int gi_lo,
+    int gfirst, int col_tiles, int total_tiles, int group, double* __restrict__ dot_partials,
+    const int* __restrict__ skip_flag) {
+    __shared__ double strip[5 * kLdsTileCols];
+    if (skip_flag != nullptr && *skip_flag != 0) return;
+    const int lane = (int)threadIdx.x;
+    const int b = (int)blockIdx.x;
+    const int span = 8 * group;
+    const int tile = (b / span) * span + (b & 7) * group + ((b >> 3) % group);
+    if (tile >= total_tiles) return;
+    const int n = m.grid_size;
+    const int row_group = tile / col_tiles;
+    const int col_tile = tile - row_group * col_tiles;
+    const int li = gi_lo + row_group;  // local grid row
+    const int gi = gfirst + li;        // global grid row
+    const int j0 = col_tile * kLdsTileCols;
+    double dot_acc = 0.0;
+
+    if (gi > 0 && gi < n - 1) {
+        // slab-local position of the tile's first coefficient: row (gi, j) starts at base + 5 j - 1
+        // for j >= 1; the run of the first tile starts one entry early so that row j sits at strip
+        // position 5 j there too (row 0 itself holds [N,C,E,S] at positions 1..4)
+        const long long e = stencil_gridrow_base(gi, n) + 5LL * j0 - 1 - m.nnz_base + lane;
+        const double* __restrict__ vals = m.values;
+        double c[10];
+        if (j0 == 0 || j0 + kLdsTileCols > n - 1) {
+            // first / last tile of the grid row: part of the run lies outside the row (at the slab's
+            // ends: outside the array): clamp the addresses, those strip slots feed no row
+            const long long hi = m.nnz_local - 1;
+#pragma unroll
+            for (int k = 0; k < 10; ++k) {
+                long long idx = e + 64 * k;
+                idx = idx < 0 ? 0 : (idx > hi ? hi : idx);
+                c[k] = __builtin_nontemporal_load(vals + idx);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 10; ++k) c[k] = __builtin_nontemporal_load(vals + e + 64 * k);
+        }
+        double xc[2], xw[2], xe[2], xn[2], xs[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int j = j0 + lane + 64 * h;
+            xc[h] = xw[h] = xe[h] = xn[h] = xs[h] = 0.0;
+            if (j < n) {
+                const double* __restrict__ xl = x + ((long long)li * n + j);
+                xc[h] = xl[0], xn[h] = xl[-n], xs[h] = xl[n];
+                if (j > 0) xw[h] = xl[-1];
+                if (j < n - 1) xe[h] = xl[1];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 10; ++k) strip[64 * k + lane] = c[k];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int j = j0 + lane + 64 * h;
+            if (j < n) {
+                const double* __restrict__ v = strip + 5 * (lane + 64 * h);
+                double sum;
+                if (j > 0 && j < n - 1) {            // [N,W,C,E,S], evaluated W,C,E,N,S
+                    sum = v[1] * xw[h];
+                    sum = fma(v[2], xc[h], sum);
+                    sum = fma(v[3], xe[h], sum);
+                    sum = fma(v[0], xn[h], sum);
+                    sum = fma(v[4], xs[h], sum);
+                } else if (j == 0) {                 // [N,C,E,S] at strip positions 1..4, CSR-loop order
+                    sum = fma(v[1], xn[h], 0.0);
+                    sum = fma(v[2], xc[h], sum);
+                    sum = fma(v[3], xe[h], sum);
+                    sum = fma(v[4], xs[h], sum);
+                } else {                             // j == n-1: [N,W,C,S], CSR-loop order
+                    sum = fma(v[0], xn[h], 0.0);
+                    sum = fma(v[1], xw[h], sum);
+                    sum = fma(v[2], xc[h], sum);
+                    sum = fma(v[3], xs[h], sum);
+                }
+                if (kDot) dot_acc = fma(xc[h], sum, dot_acc);
+                __builtin_nontemporal_store(alpha * sum, y + ((long long)li * n + j));
+            }
+        }
+    } else {
+        // first / last grid row of the whole grid: every row the reference's way
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int j = j0 + lane + 64 * h;
+            if (j < n) {
+                const long long lr = (long long)li * n + j;
+                const double sum = row_reference<false>(m, x, (int)lr, gi, j);
+                if (kDot) dot_acc = fma(x[lr], sum, dot_acc);
+                y[lr] = alpha * sum;
+            }
+        }
+    }
+    if (kDot) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) dot_acc += __shfl_down(dot_acc, off);
+        if (lane == 0) dot_partials[tile] = dot_acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // STENCIL5, row-generic variant: one thread per row, the reference's own shape. Used for
 // small grids, for matrices that are not a complete 5-point stencil (kAnalytic = false:
 // every row takes the CSR loop, as the reference does when grid_size = -1).
@@ -794,11 +927,14 @@ Stencil5Plan plan_stencil5(const SlabCsr& m, int first_row, int last_row, Stenci
                           first_row % n == 0 && last_row % n == 0;
     const bool direct_ok = m.verified_stencil && n >= 2 && m.row_offset % n == 0 &&
                            m.n_local % n == 0 && first_row % n == 0 && last_row % n == 0;
+    // row-lds needs grid rows long enough that the two clamped edge tiles are a small share
+    const int lds_min_n = env_int("SPMV_AMD_ROWLDS_MIN_GRID", 512);
     if (variant == Stencil5Variant::Auto)
-        variant = direct_ok ? Stencil5Variant::RowDirect
+        variant = direct_ok ? (n >= lds_min_n ? Stencil5Variant::RowLds : Stencil5Variant::RowDirect)
                   : tile_ok ? Stencil5Variant::WaveTile
                             : Stencil5Variant::RowGeneric;
-    if (variant == Stencil5Variant::RowDirect && !direct_ok) variant = Stencil5Variant::RowGeneric;
+    if ((variant == Stencil5Variant::RowDirect || variant == Stencil5Variant::RowLds) && !direct_ok)
+        variant = Stencil5Variant::RowGeneric;
     if (variant == Stencil5Variant::ColumnMarch && !march_ok)
         variant = tile_ok ? Stencil5Variant::WaveTile : Stencil5Variant::RowGeneric;
     if (variant == Stencil5Variant::WaveTile && !tile_ok) variant = Stencil5Variant::RowGeneric;
@@ -811,6 +947,12 @@ Stencil5Plan plan_stencil5(const SlabCsr& m, int first_row, int last_row, Stenci
         p.row_blocks = (int)blocks_for(n);  // column blocks per grid row
         p.rows_per_task = env_int("SPMV_AMD_DIRECT_ROWS", 1);
         if (p.rows_per_task != 2 && p.rows_per_task != 4) p.rows_per_task = 1;
+    } else if (variant == Stencil5Variant::RowLds) {
+        p.gi_lo = first_row / n;
+        p.gi_hi = last_row / n;
+        p.row_blocks = (n + kLdsTileCols - 1) / kLdsTileCols;  // column tiles (= workgroups) per grid row
+        p.rows_per_task = env_int("SPMV_AMD_ROWLDS_GROUP", 4);  // consecutive tiles per XCD
+        if (p.rows_per_task < 1 || p.rows_per_task > 64) p.rows_per_task = 4;
     } else if (variant == Stencil5Variant::WaveTile) {
         // one tile per wave in dispatch order by default (4.65 ms at 20 000^2); SPMV_AMD_WAVETILE_ONESHOT=0
         // selects the persistent, XCD-banded walk (5.87 ms), kept for the record
@@ -851,6 +993,7 @@ int stencil5_partials_needed(const SlabCsr& m, int first_row, int last_row, Sten
     if (p.variant == Stencil5Variant::RowGeneric) return p.row_blocks * kWavesPerBlock;
     if (p.variant == Stencil5Variant::RowDirect)
         return p.row_blocks * ((p.gi_hi - p.gi_lo + p.rows_per_task - 1) / p.rows_per_task);
+    if (p.variant == Stencil5Variant::RowLds) return p.row_blocks * (p.gi_hi - p.gi_lo);
     if (p.variant == Stencil5Variant::WaveTile) return p.tile_blocks * kWavesPerBlock;
     return (p.march_blocks + (p.head_rows ? p.row_blocks : 0) + (p.tail_rows ? p.row_blocks : 0)) * kWavesPerBlock;
 }
@@ -859,6 +1002,7 @@ const char* stencil5_variant_name(const SlabCsr& m, int first_row, int last_row,
                                   const LaunchShape& shape) {
     switch (plan_stencil5(m, first_row, last_row, variant, shape).variant) {
         case Stencil5Variant::RowDirect: return "stencil5/row-direct";
+        case Stencil5Variant::RowLds: return "stencil5/row-lds";
         case Stencil5Variant::ColumnMarch: return "stencil5/column-march";
         case Stencil5Variant::WaveTile: return "stencil5/wave-tile";
         default: return m.verified_stencil ? "stencil5/row-generic" : "stencil5/row-generic(csr-loop)";
@@ -912,6 +1056,20 @@ int launch_stencil5_spmv(const SlabCsr& m, const double* x, double* y, double al
         }
 #undef SPMV_AMD_LAUNCH_DIRECT
         return (int)blocks;
+    }
+
+    if (p.variant == Stencil5Variant::RowLds) {
+        const long long tiles = (long long)p.row_blocks * (p.gi_hi - p.gi_lo);  // < 2^31 for any int32 CSR
+        const int span = 8 * p.rows_per_task;  // rows_per_task carries the tiles-per-XCD group here
+        const dim3 grid((unsigned)((tiles + span - 1) / span * span));
+        const int gfirst = m.row_offset / n;
+        if (dot)
+            hipLaunchKernelGGL((stencil5_rowlds_kernel<true>), grid, dim3(64), 0, stream, m, x, y, alpha, p.gi_lo,
+                               gfirst, p.row_blocks, (int)tiles, p.rows_per_task, d_dot_partials, d_skip_flag);
+        else
+            hipLaunchKernelGGL((stencil5_rowlds_kernel<false>), grid, dim3(64), 0, stream, m, x, y, alpha, p.gi_lo,
+                               gfirst, p.row_blocks, (int)tiles, p.rows_per_task, d_dot_partials, d_skip_flag);
+        return (int)tiles;
     }
 
     const bool vec_xy = aligned16(x) && aligned16(y);

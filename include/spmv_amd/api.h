@@ -192,13 +192,14 @@ int spmv_amd_time_run_device(const char* mode, const double* d_x, double* d_y, i
                              float* ms_each);
 
 /* Which kernel variant the last init selected: a static string, one of
- * "stencil5/row-direct" (default on verified stencils), "stencil5/column-march",
+ * "stencil5/row-lds" (default on verified stencils with grid >= 512), "stencil5/row-direct"
+ * (default on smaller verified stencils), "stencil5/column-march",
  * "stencil5/wave-tile", "stencil5/row-generic", "stencil5/row-generic(csr-loop)";
  * "csr/row-scalar", "csr/subwave4|8|16|32", "csr/wavefront"; "ell/slot-major",
  * "ell/stencil5-direct". */
 const char* spmv_amd_operator_variant(const char* mode);
 
-/* Forces a kernel variant of `mode` ("row-direct", "column-march", "wave-tile", "row-generic" /
+/* Forces a kernel variant of `mode` ("row-lds", "row-direct", "column-march", "wave-tile", "row-generic" /
  * "row-scalar", "subwave4".."subwave32", "wavefront"; NULL or "auto" = automatic). A variant
  * whose preconditions the matrix does not meet falls back to the next applicable one. */
 int spmv_amd_operator_select_variant(const char* mode, const char* variant);
@@ -265,6 +266,8 @@ int spmv_amd_cg_slab_history(SpmvAmdCgSlab* s, double* out, int cap);
 /* Slab-local SpMV on caller data: uploads x_full's slab + halos, returns y slab. */
 int spmv_amd_cg_slab_spmv(SpmvAmdCgSlab* s, const double* x_full, double* y_local);
 void spmv_amd_cg_slab_info(const SpmvAmdCgSlab* s, int* row_offset, int* n_local, int* local_nnz);
+/* The SpMV kernel variant the slab's solver launches ("stencil5/row-lds", ...): a static string. */
+const char* spmv_amd_cg_slab_variant(const SpmvAmdCgSlab* s);
 /* Average duration (HIP events on the solver's stream) of `reps` launches of the
  * slab SpMV kernel pair on the current direction vector. */
 int spmv_amd_cg_slab_time_spmv(SpmvAmdCgSlab* s, int reps, float* ms_each);

@@ -12,7 +12,7 @@ import matrices as M
 
 pytestmark = pytest.mark.gpu
 
-STENCIL_SIZES = [2, 3, 5, 81, 127, 128, 129, 200, 257, 300, 513]
+STENCIL_SIZES = [2, 3, 5, 81, 127, 128, 129, 130, 200, 257, 300, 513, 640]
 
 
 def random_stencil(O, n, seed):
@@ -28,7 +28,7 @@ def test_stencil5_csr_bit_exact_random_values(B, O, fresh_host_matrices, n):
     m = B.HostMatrix(e, n * n, n * n, n)
     op = B.Operator("stencil5-csr")
     assert op.init(m) == 0
-    assert op.variant() == "stencil5/row-direct"
+    assert op.variant() == ("stencil5/row-lds" if n >= 512 else "stencil5/row-direct")
     rp, ci, va = O.build_csr(e, n * n)
     want = O.spmv_stencil5(rp, ci, va, x, n)
     got, ms = op.run_timed(x)
@@ -40,7 +40,7 @@ def test_stencil5_csr_bit_exact_random_values(B, O, fresh_host_matrices, n):
     assert op.run_device(Shift(dx), Shift(dy)) == 0
     assert np.array_equal(dy.to_host()[1:], want)
     # the same matrix forced through the other kernel variants (aligned and odd-address vectors)
-    for forced in ("column-march", "wave-tile", "row-generic"):
+    for forced in ("row-lds", "row-direct", "column-march", "wave-tile", "row-generic"):
         op.select_variant(forced)
         if n >= 128:
             assert op.variant() == "stencil5/" + forced
