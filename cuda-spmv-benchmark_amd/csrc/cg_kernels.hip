@@ -11,17 +11,20 @@
 // wave -> single-block tree), so a solve is bit-reproducible run to run; the summation order
 // differs from the reference's 256-wide blocks, which SURVEY.md section 8 allows (1e-10).
 //
-// All streaming kernels move 16 bytes per lane, one pair per thread on a one-shot grid: on MI355X
-// that beat every capped grid-stride shape tried (tools/stream_probe.hip: p-update 1.66 ms vs
-// 1.88-2.05 ms, x/r-update 3.20 ms vs 3.33-3.47 ms at 4e8 rows). Kernels that reduce write one
-// partial per block (wave trees, then the four wave sums in wave order).
+// All streaming kernels move 16 bytes per lane, one pair per thread on a one-shot grid of
+// ONE-WAVE workgroups, with nontemporal loads and stores for every stream that is touched once per
+// pass (everything except the store of p, whose lines the next SpMV's neighbour loads re-use).
+// Measured on MI355X at 4e8 rows, non-zero data (tools/stream_probe4.hip, profiles/r01_stream_probe4.txt):
+// r-update 1.71 ms (256-thread blocks, plain accesses) -> 1.47 ms, x/p-update 2.89 -> 2.68 ms; capped
+// grid-stride shapes were slower still (tools/stream_probe.hip). Kernels that reduce write one
+// partial per workgroup (= per wave: a shuffle tree, no LDS).
 #include "kernels.hpp"
 
 namespace spmv_amd {
 namespace {
 
-constexpr int kBlock = 256;
-constexpr int kWavesPerBlock = 4;
+constexpr int kBlock = 256;   // the reduction kernels
+constexpr int kStream = 64;   // the streaming kernels: one wavefront per workgroup
 constexpr int kReduceStageBlocks = 256;
 
 typedef double d2 __attribute__((ext_vector_type(2)));
@@ -36,20 +39,24 @@ __device__ __forceinline__ double wave_sum(double v) {
 // handled by thread 0 of block 0 in each kernel.
 #define SPMV_AMD_STREAM_LOOP(n)                                                     \
     const size_t pairs = (n) >> 1;                                                  \
-    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;                     \
+    const size_t i = (size_t)blockIdx.x * kStream + threadIdx.x;                    \
     if (i < pairs)
 
-// Block partial of a per-thread value: written by thread 0 to partials[blockIdx.x].
+// Workgroup (= wave) partial of a per-thread value: written by lane 0 to partials[blockIdx.x].
 __device__ __forceinline__ void block_partial(double acc, double* __restrict__ partials) {
-    __shared__ double wave_part[kWavesPerBlock];
     acc = wave_sum(acc);
-    if ((threadIdx.x & 63) == 0) wave_part[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0)
-        partials[blockIdx.x] = ((wave_part[0] + wave_part[1]) + wave_part[2]) + wave_part[3];
+    if (threadIdx.x == 0) partials[blockIdx.x] = acc;
 }
 
-__global__ __launch_bounds__(kBlock) void fill_kernel(double* __restrict__ d, size_t n, double value) {
+// 16-byte accesses of streams that are read / written once per pass
+__device__ __forceinline__ d2 load_once(const double* __restrict__ base, size_t pair) {
+    return __builtin_nontemporal_load(reinterpret_cast<const d2*>(base) + pair);
+}
+__device__ __forceinline__ void store_once(double* __restrict__ base, size_t pair, d2 v) {
+    __builtin_nontemporal_store(v, reinterpret_cast<d2*>(base) + pair);
+}
+
+__global__ __launch_bounds__(kStream) void fill_kernel(double* __restrict__ d, size_t n, double value) {
     SPMV_AMD_STREAM_LOOP(n) {
         d2 v = {value, value};
         reinterpret_cast<d2*>(d)[i] = v;
@@ -57,53 +64,53 @@ __global__ __launch_bounds__(kBlock) void fill_kernel(double* __restrict__ d, si
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) d[n - 1] = value;
 }
 
-__global__ __launch_bounds__(kBlock) void axpy_kernel(size_t n, double a, const double* __restrict__ x,
+__global__ __launch_bounds__(kStream) void axpy_kernel(size_t n, double a, const double* __restrict__ x,
                                                       double* __restrict__ y) {
     SPMV_AMD_STREAM_LOOP(n) {
-        const d2 xv = reinterpret_cast<const d2*>(x)[i];
-        d2 yv = reinterpret_cast<d2*>(y)[i];
+        const d2 xv = load_once(x, i);
+        d2 yv = load_once(y, i);
         yv.x = fma(a, xv.x, yv.x);
         yv.y = fma(a, xv.y, yv.y);
-        reinterpret_cast<d2*>(y)[i] = yv;
+        store_once(y, i, yv);
     }
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) y[n - 1] = fma(a, x[n - 1], y[n - 1]);
 }
 
-__global__ __launch_bounds__(kBlock) void axpby_kernel(size_t n, double a, const double* __restrict__ x,
+__global__ __launch_bounds__(kStream) void axpby_kernel(size_t n, double a, const double* __restrict__ x,
                                                        double b, const double* y, double* z) {
     SPMV_AMD_STREAM_LOOP(n) {
-        const d2 xv = reinterpret_cast<const d2*>(x)[i];
-        const d2 yv = reinterpret_cast<const d2*>(y)[i];
+        const d2 xv = load_once(x, i);
+        const d2 yv = load_once(y, i);
         d2 zv;
         zv.x = fma(a, xv.x, b * yv.x);
         zv.y = fma(a, xv.y, b * yv.y);
-        reinterpret_cast<d2*>(z)[i] = zv;
+        store_once(z, i, zv);
     }
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) z[n - 1] = fma(a, x[n - 1], b * y[n - 1]);
 }
 
 template <bool kSubtract>
-__global__ __launch_bounds__(kBlock) void axpy_dev_kernel(size_t n, const double* __restrict__ d_a,
+__global__ __launch_bounds__(kStream) void axpy_dev_kernel(size_t n, const double* __restrict__ d_a,
                                                           const double* __restrict__ x,
                                                           double* __restrict__ y) {
     const double a = kSubtract ? -(*d_a) : *d_a;
     SPMV_AMD_STREAM_LOOP(n) {
-        const d2 xv = reinterpret_cast<const d2*>(x)[i];
-        d2 yv = reinterpret_cast<d2*>(y)[i];
+        const d2 xv = load_once(x, i);
+        d2 yv = load_once(y, i);
         yv.x = fma(a, xv.x, yv.x);
         yv.y = fma(a, xv.y, yv.y);
-        reinterpret_cast<d2*>(y)[i] = yv;
+        store_once(y, i, yv);
     }
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) y[n - 1] = fma(a, x[n - 1], y[n - 1]);
 }
 
-__global__ __launch_bounds__(kBlock) void update_p_dev_kernel(size_t n, const double* __restrict__ r,
+__global__ __launch_bounds__(kStream) void update_p_dev_kernel(size_t n, const double* __restrict__ r,
                                                               const double* __restrict__ d_b,
                                                               double* __restrict__ p) {
     const double b = *d_b;
     SPMV_AMD_STREAM_LOOP(n) {
-        const d2 rv = reinterpret_cast<const d2*>(r)[i];
-        d2 pv = reinterpret_cast<d2*>(p)[i];
+        const d2 rv = load_once(r, i);
+        d2 pv = load_once(p, i);
         pv.x = fma(b, pv.x, rv.x);
         pv.y = fma(b, pv.y, rv.y);
         reinterpret_cast<d2*>(p)[i] = pv;
@@ -112,13 +119,13 @@ __global__ __launch_bounds__(kBlock) void update_p_dev_kernel(size_t n, const do
 }
 
 // One partial per wave: lanes accumulate their grid-stride elements in order, then a tree.
-__global__ __launch_bounds__(kBlock) void dot_partials_kernel(size_t n, const double* __restrict__ x,
+__global__ __launch_bounds__(kStream) void dot_partials_kernel(size_t n, const double* __restrict__ x,
                                                               const double* __restrict__ y,
                                                               double* __restrict__ partials) {
     double acc = 0.0;
     SPMV_AMD_STREAM_LOOP(n) {
-        const d2 xv = reinterpret_cast<const d2*>(x)[i];
-        const d2 yv = reinterpret_cast<const d2*>(y)[i];
+        const d2 xv = load_once(x, i);
+        const d2 yv = load_once(y, i);
         acc = fma(xv.x, yv.x, acc);
         acc = fma(xv.y, yv.y, acc);
     }
@@ -179,19 +186,19 @@ __global__ void check_convergence_kernel(const double* rr_new, double b_norm, do
 
 // ---- fused steps of the slab solver ----
 
-__global__ __launch_bounds__(kBlock) void cg_init_residual_kernel(size_t n, const double* __restrict__ b,
+__global__ __launch_bounds__(kStream) void cg_init_residual_kernel(size_t n, const double* __restrict__ b,
                                                                   const double* __restrict__ Ap,
                                                                   double* __restrict__ r,
                                                                   double* __restrict__ p,
                                                                   double* __restrict__ partials) {
     double acc = 0.0;
     SPMV_AMD_STREAM_LOOP(n) {
-        const d2 bv = reinterpret_cast<const d2*>(b)[i];
-        const d2 av = reinterpret_cast<const d2*>(Ap)[i];
+        const d2 bv = load_once(b, i);
+        const d2 av = load_once(Ap, i);
         d2 rv;
         rv.x = fma(-1.0, av.x, bv.x);  // axpy_kernel(-1.0, Ap, b) then r = b (mgpu :475-476)
         rv.y = fma(-1.0, av.y, bv.y);
-        reinterpret_cast<d2*>(r)[i] = rv;
+        store_once(r, i, rv);
         reinterpret_cast<d2*>(p)[i] = rv;
         acc = fma(rv.x, rv.x, acc);
         acc = fma(rv.y, rv.y, acc);
@@ -206,7 +213,7 @@ __global__ __launch_bounds__(kBlock) void cg_init_residual_kernel(size_t n, cons
 }
 
 // r -= alpha*Ap with the r.r partials (axpy_kernel(-alpha, Ap, r) + the dot, mgpu :612,627).
-__global__ __launch_bounds__(kBlock) void cg_update_r_kernel(size_t n, const CgScalars* __restrict__ s,
+__global__ __launch_bounds__(kStream) void cg_update_r_kernel(size_t n, const CgScalars* __restrict__ s,
                                                              const double* __restrict__ Ap,
                                                              double* __restrict__ r,
                                                              double* __restrict__ partials) {
@@ -216,11 +223,11 @@ __global__ __launch_bounds__(kBlock) void cg_update_r_kernel(size_t n, const CgS
     const double alpha = s->rr_old / s->pAp;
     double acc = 0.0;
     SPMV_AMD_STREAM_LOOP(n) {
-        const d2 av = reinterpret_cast<const d2*>(Ap)[i];
-        d2 rv = reinterpret_cast<d2*>(r)[i];
+        const d2 av = load_once(Ap, i);
+        d2 rv = load_once(r, i);
         rv.x = fma(-alpha, av.x, rv.x);
         rv.y = fma(-alpha, av.y, rv.y);
-        reinterpret_cast<d2*>(r)[i] = rv;
+        store_once(r, i, rv);
         acc = fma(rv.x, rv.x, acc);
         acc = fma(rv.y, rv.y, acc);
     }
@@ -238,7 +245,7 @@ __global__ __launch_bounds__(kBlock) void cg_update_r_kernel(size_t n, const CgS
 // the converging one finds s->iterations != iteration and does nothing.
 // x_in is x itself except in the first iteration of a solve, where it is the stored initial guess:
 // the solve never has to copy x0 into x first.
-__global__ __launch_bounds__(kBlock) void cg_update_px_kernel(size_t n, const CgScalars* __restrict__ s,
+__global__ __launch_bounds__(kStream) void cg_update_px_kernel(size_t n, const CgScalars* __restrict__ s,
                                                               const double* __restrict__ r,
                                                               double* __restrict__ p,
                                                               const double* x_in, double* x, int iteration) {
@@ -246,13 +253,13 @@ __global__ __launch_bounds__(kBlock) void cg_update_px_kernel(size_t n, const Cg
     const bool advance = s->converged == 0;
     const double alpha = s->alpha, beta = s->beta;
     SPMV_AMD_STREAM_LOOP(n) {
-        d2 pv = reinterpret_cast<d2*>(p)[i];
-        d2 xv = reinterpret_cast<const d2*>(x_in)[i];
+        d2 pv = load_once(p, i);
+        d2 xv = load_once(x_in, i);
         xv.x = fma(alpha, pv.x, xv.x);
         xv.y = fma(alpha, pv.y, xv.y);
-        reinterpret_cast<d2*>(x)[i] = xv;
+        store_once(x, i, xv);
         if (advance) {
-            const d2 rv = reinterpret_cast<const d2*>(r)[i];
+            const d2 rv = load_once(r, i);
             pv.x = fma(1.0, rv.x, beta * pv.x);
             pv.y = fma(1.0, rv.y, beta * pv.y);
             reinterpret_cast<d2*>(p)[i] = pv;
@@ -304,7 +311,7 @@ __global__ void cg_scalars_step_kernel(CgScalars* s, double tol, double* history
 }
 
 inline unsigned stream_grid(size_t n) {
-    const size_t want = ((n >> 1) + kBlock - 1) / kBlock;
+    const size_t want = ((n >> 1) + kStream - 1) / kStream;
     return (unsigned)(want < 1 ? 1 : want);
 }
 
@@ -312,32 +319,32 @@ inline unsigned stream_grid(size_t n) {
 
 void launch_fill(double* d, size_t n, double value, hipStream_t stream) {
     if (n == 0) return;
-    hipLaunchKernelGGL(fill_kernel, dim3(stream_grid(n)), dim3(kBlock), 0, stream, d, n, value);
+    hipLaunchKernelGGL(fill_kernel, dim3(stream_grid(n)), dim3(kStream), 0, stream, d, n, value);
 }
 
 void launch_axpy(size_t n, double a, const double* x, double* y, hipStream_t stream) {
     if (n == 0) return;
-    hipLaunchKernelGGL(axpy_kernel, dim3(stream_grid(n)), dim3(kBlock), 0, stream, n, a, x, y);
+    hipLaunchKernelGGL(axpy_kernel, dim3(stream_grid(n)), dim3(kStream), 0, stream, n, a, x, y);
 }
 
 void launch_axpby(size_t n, double a, const double* x, double b, const double* y, double* z,
                   hipStream_t stream) {
     if (n == 0) return;
-    hipLaunchKernelGGL(axpby_kernel, dim3(stream_grid(n)), dim3(kBlock), 0, stream, n, a, x, b, y, z);
+    hipLaunchKernelGGL(axpby_kernel, dim3(stream_grid(n)), dim3(kStream), 0, stream, n, a, x, b, y, z);
 }
 
 void launch_axpy_dev(size_t n, const double* d_a, const double* x, double* y, bool subtract,
                      hipStream_t stream) {
     if (n == 0) return;
     if (subtract)
-        hipLaunchKernelGGL(axpy_dev_kernel<true>, dim3(stream_grid(n)), dim3(kBlock), 0, stream, n, d_a, x, y);
+        hipLaunchKernelGGL(axpy_dev_kernel<true>, dim3(stream_grid(n)), dim3(kStream), 0, stream, n, d_a, x, y);
     else
-        hipLaunchKernelGGL(axpy_dev_kernel<false>, dim3(stream_grid(n)), dim3(kBlock), 0, stream, n, d_a, x, y);
+        hipLaunchKernelGGL(axpy_dev_kernel<false>, dim3(stream_grid(n)), dim3(kStream), 0, stream, n, d_a, x, y);
 }
 
 void launch_update_p_dev(size_t n, const double* r, const double* d_b, double* p, hipStream_t stream) {
     if (n == 0) return;
-    hipLaunchKernelGGL(update_p_dev_kernel, dim3(stream_grid(n)), dim3(kBlock), 0, stream, n, r, d_b, p);
+    hipLaunchKernelGGL(update_p_dev_kernel, dim3(stream_grid(n)), dim3(kStream), 0, stream, n, r, d_b, p);
 }
 
 size_t dot_scratch_doubles(size_t n) { return (size_t)stream_grid(n) + kReduceStageBlocks; }
@@ -347,7 +354,7 @@ void launch_dot(size_t n, const double* x, const double* y, double* scratch, dou
                 hipStream_t stream) {
     // scratch = [one partial per block | kReduceStageBlocks stage slots]
     const unsigned blocks = stream_grid(n);
-    hipLaunchKernelGGL(dot_partials_kernel, dim3(blocks), dim3(kBlock), 0, stream, n, x, y, scratch);
+    hipLaunchKernelGGL(dot_partials_kernel, dim3(blocks), dim3(kStream), 0, stream, n, x, y, scratch);
     launch_reduce_partials(scratch, (int)blocks, d_result, nullptr, stream, scratch + blocks);
 }
 
@@ -363,18 +370,18 @@ void launch_check_convergence(const double* d_rr_new, double b_norm, double tol,
 
 void launch_cg_init_residual(size_t n, const double* b, const double* Ap, double* r, double* p,
                              double* partials, hipStream_t stream) {
-    hipLaunchKernelGGL(cg_init_residual_kernel, dim3(stream_grid(n)), dim3(kBlock), 0, stream, n, b, Ap,
+    hipLaunchKernelGGL(cg_init_residual_kernel, dim3(stream_grid(n)), dim3(kStream), 0, stream, n, b, Ap,
                        r, p, partials);
 }
 
 void launch_cg_update_r(size_t n, const CgScalars* s, const double* Ap, double* r, double* partials,
                         hipStream_t stream) {
-    hipLaunchKernelGGL(cg_update_r_kernel, dim3(stream_grid(n)), dim3(kBlock), 0, stream, n, s, Ap, r, partials);
+    hipLaunchKernelGGL(cg_update_r_kernel, dim3(stream_grid(n)), dim3(kStream), 0, stream, n, s, Ap, r, partials);
 }
 
 void launch_cg_update_px(size_t n, const CgScalars* s, const double* r, double* p, const double* x_in,
                          double* x, int iteration, hipStream_t stream) {
-    hipLaunchKernelGGL(cg_update_px_kernel, dim3(stream_grid(n)), dim3(kBlock), 0, stream, n, s, r, p, x_in, x,
+    hipLaunchKernelGGL(cg_update_px_kernel, dim3(stream_grid(n)), dim3(kStream), 0, stream, n, s, r, p, x_in, x,
                        iteration);
 }
 

@@ -663,6 +663,7 @@ __global__ __launch_bounds__(kBlock) void csr_row_scalar_kernel(SlabCsr m, const
 constexpr int kCsrStreamPerThread = 4;                         // entries each thread fetches in phase 1
 constexpr int kCsrStreamCap = kBlock * kCsrStreamPerThread;    // 1024 entries: 16 KiB of LDS, 8 blocks per CU
 
+template <bool kNtLoad, bool kNtStore>
 __global__ __launch_bounds__(kBlock) void csr_stream_kernel(SlabCsr m, const double* __restrict__ x,
                                                             double* __restrict__ y, double alpha,
                                                             int rows_per_block) {
@@ -687,8 +688,9 @@ __global__ __launch_bounds__(kBlock) void csr_stream_kernel(SlabCsr m, const dou
         for (int u = 0; u < kCsrStreamPerThread; ++u) {
             const int e = kb + (int)threadIdx.x + u * kBlock;
             const bool live = e < ke;
-            c[u] = live ? m.col_idx[e] : m.row_offset;
-            v[u] = live ? m.values[e] : 0.0;
+            // the span is read once per SpMV, fully coalesced: nontemporal
+            c[u] = !live ? m.row_offset : kNtLoad ? __builtin_nontemporal_load(m.col_idx + e) : m.col_idx[e];
+            v[u] = !live ? 0.0 : kNtLoad ? __builtin_nontemporal_load(m.values + e) : m.values[e];
         }
 #pragma unroll
         for (int u = 0; u < kCsrStreamPerThread; ++u) xv[u] = x_at(x, (long long)c[u] - m.row_offset, lo, hi);
@@ -701,7 +703,8 @@ __global__ __launch_bounds__(kBlock) void csr_stream_kernel(SlabCsr m, const dou
         if (has_row) {
             double sum = 0.0;
             for (int k = k0 - kb; k < k1 - kb; ++k) sum = fma(sv[k], sx[k], sum);
-            y[row] = alpha * sum;
+            if (kNtStore) __builtin_nontemporal_store(alpha * sum, y + row);
+            else y[row] = alpha * sum;
         }
     } else if (has_row) {
         double sum = 0.0;
@@ -763,6 +766,7 @@ __global__ __launch_bounds__(kBlock) void ell_transpose_kernel(int rows, int wid
     }
 }
 
+template <bool kNt>
 __device__ __forceinline__ double ell_row_walk(int rows, int width, const int* __restrict__ idx,
                                                const double* __restrict__ val,
                                                const double* __restrict__ x, long long r) {
@@ -774,8 +778,10 @@ __device__ __forceinline__ double ell_row_walk(int rows, int width, const int* _
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const bool live = base + u < width;
-            c[u] = live ? idx[(long long)(base + u) * rows + r] : -1;
-            v[u] = live ? val[(long long)(base + u) * rows + r] : 0.0;
+            // slot-major planes are read once per SpMV: nontemporal, so they do not displace x
+            const long long at = (long long)(base + u) * rows + r;
+            c[u] = !live ? -1 : kNt ? __builtin_nontemporal_load(idx + at) : idx[at];
+            v[u] = !live ? 0.0 : kNt ? __builtin_nontemporal_load(val + at) : val[at];
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) xv[u] = c[u] >= 0 ? x[c[u]] : 0.0;
@@ -790,41 +796,53 @@ __device__ __forceinline__ double ell_finish(double alpha, double beta, double s
     return beta == 0.0 ? alpha * sum : fma(alpha, sum, beta * y_old);
 }
 
-__global__ __launch_bounds__(kBlock) void ell_spmv_kernel(int rows, int width, const int* __restrict__ idx,
-                                                          const double* __restrict__ val,
-                                                          const double* __restrict__ x,
-                                                          double* __restrict__ y, double alpha,
-                                                          double beta) {
-    const long long r = (long long)blockIdx.x * kBlock + threadIdx.x;
+// Workgroup size and nontemporal plane loads / y store are template parameters chosen by the launcher
+// from measurements (see launch_ell_spmv).
+template <int kEllBlock, bool kNt>
+__global__ __launch_bounds__(kEllBlock) void ell_spmv_kernel(int rows, int width, const int* __restrict__ idx,
+                                                             const double* __restrict__ val,
+                                                             const double* __restrict__ x,
+                                                             double* __restrict__ y, double alpha,
+                                                             double beta) {
+    const long long r = (long long)blockIdx.x * kEllBlock + threadIdx.x;
     if (r >= rows) return;
-    const double sum = ell_row_walk(rows, width, idx, val, x, r);
-    y[r] = ell_finish(alpha, beta, sum, beta == 0.0 ? 0.0 : y[r]);
+    const double sum = ell_row_walk<kNt>(rows, width, idx, val, x, r);
+    const double out = ell_finish(alpha, beta, sum, beta == 0.0 ? 0.0 : y[r]);
+    if (kNt) __builtin_nontemporal_store(out, y + r);
+    else y[r] = out;
 }
 
 // Interior rows of a stencil stored as ELL: slots [N,W,C,E,S], columns computed, indices
 // never read (the contract of reference include/spmv_stencil.h:25-42).
-__global__ __launch_bounds__(kBlock) void ell_stencil5_kernel(int rows, int width, int n,
-                                                              const int* __restrict__ idx,
-                                                              const double* __restrict__ val,
-                                                              const double* __restrict__ x,
-                                                              double* __restrict__ y, double alpha,
-                                                              double beta) {
-    const long long r = (long long)blockIdx.x * kBlock + threadIdx.x;
+template <int kEllBlock, bool kNt>
+__global__ __launch_bounds__(kEllBlock) void ell_stencil5_kernel(int rows, int width, int n,
+                                                                 const int* __restrict__ idx,
+                                                                 const double* __restrict__ val,
+                                                                 const double* __restrict__ x,
+                                                                 double* __restrict__ y, double alpha,
+                                                                 double beta) {
+    const long long r = (long long)blockIdx.x * kEllBlock + threadIdx.x;
     if (r >= rows) return;
     const int i = (int)(r / n), j = (int)(r - (long long)i * n);
     double sum;
     if (width >= 5 && stencil_is_interior(i, j, n)) {
         const double* __restrict__ v = val + r;
         const long long R = rows;
-        sum = v[1 * R] * x[r - 1];
-        sum = fma(v[2 * R], x[r], sum);
-        sum = fma(v[3 * R], x[r + 1], sum);
-        sum = fma(v[0], x[r - n], sum);
-        sum = fma(v[4 * R], x[r + n], sum);
+        const double v0 = kNt ? __builtin_nontemporal_load(v) : v[0], v1 = kNt ? __builtin_nontemporal_load(v + R) : v[R],
+                     v2 = kNt ? __builtin_nontemporal_load(v + 2 * R) : v[2 * R],
+                     v3 = kNt ? __builtin_nontemporal_load(v + 3 * R) : v[3 * R],
+                     v4 = kNt ? __builtin_nontemporal_load(v + 4 * R) : v[4 * R];
+        sum = v1 * x[r - 1];
+        sum = fma(v2, x[r], sum);
+        sum = fma(v3, x[r + 1], sum);
+        sum = fma(v0, x[r - n], sum);
+        sum = fma(v4, x[r + n], sum);
     } else {
-        sum = ell_row_walk(rows, width, idx, val, x, r);
+        sum = ell_row_walk<kNt>(rows, width, idx, val, x, r);
     }
-    y[r] = ell_finish(alpha, beta, sum, beta == 0.0 ? 0.0 : y[r]);
+    const double out = ell_finish(alpha, beta, sum, beta == 0.0 ? 0.0 : y[r]);
+    if (kNt) __builtin_nontemporal_store(out, y + r);
+    else y[r] = out;
 }
 
 // ---------------------------------------------------------------------------------
@@ -1148,8 +1166,18 @@ void launch_csr_spmv(const SlabCsr& m, const double* x, double* y, double alpha,
             int per_block = (int)(0.9 * kCsrStreamCap / (avg > 1.0 ? avg : 1.0));
             per_block = per_block > kBlock ? kBlock : (per_block < 16 ? 16 : per_block & ~15);
             per_block = env_int("SPMV_AMD_CSR_STREAM_ROWS", per_block);
-            hipLaunchKernelGGL(csr_stream_kernel, dim3((unsigned)((rows + per_block - 1) / per_block)), dim3(kBlock),
-                               0, stream, m, x, y, alpha, per_block);
+            const dim3 grid((unsigned)((rows + per_block - 1) / per_block));
+            // bit 0: nontemporal span loads, bit 1: nontemporal y store. Measured on MI355X (10 000^2 / 15 000^2):
+            // plain 1.40 / 3.11 ms, nt loads 1.53 / 3.52, nt store 1.41 / 3.20, both 1.53 / 3.44 -> plain.
+            // (Block spans are not line-aligned and neighbouring blocks share their edge lines.)
+            const int nt = env_int("SPMV_AMD_CSR_NT", 0);
+#define SPMV_AMD_CSR_STREAM(L, S) \
+    hipLaunchKernelGGL((csr_stream_kernel<L, S>), grid, dim3(kBlock), 0, stream, m, x, y, alpha, per_block)
+            if ((nt & 3) == 3) SPMV_AMD_CSR_STREAM(true, true);
+            else if (nt & 1) SPMV_AMD_CSR_STREAM(true, false);
+            else if (nt & 2) SPMV_AMD_CSR_STREAM(false, true);
+            else SPMV_AMD_CSR_STREAM(false, false);
+#undef SPMV_AMD_CSR_STREAM
             break;
         }
         case CsrVariant::RowScalar:
@@ -1178,8 +1206,17 @@ void launch_ell_transpose(int rows, int width, const int* idx_rowmajor, const do
 void launch_ell_spmv(int rows, int width, const int* idx, const double* val, const double* x,
                      double* y, double alpha, double beta, hipStream_t stream) {
     if (rows == 0) return;
-    hipLaunchKernelGGL(ell_spmv_kernel, dim3(blocks_for(rows)), dim3(kBlock), 0, stream, rows, width,
-                       idx, val, x, y, alpha, beta);
+    // bit 0: one-wave workgroups, bit 1: nontemporal planes / y. Measured on MI355X at 15 000^2 (generic /
+    // stencil-aware): 0: 3.22 / 2.32 ms, 1: 3.00 / 2.51, 2: 2.96 / 2.26, 3: 3.00 / 2.47 -> 2.
+    const int shape = env_int("SPMV_AMD_ELL_SHAPE", 2);
+#define SPMV_AMD_ELL(B, NT)                                                                                   \
+    hipLaunchKernelGGL((ell_spmv_kernel<B, NT>), dim3((unsigned)(((long long)rows + B - 1) / B)), dim3(B), 0, \
+                       stream, rows, width, idx, val, x, y, alpha, beta)
+    if ((shape & 3) == 3) SPMV_AMD_ELL(64, true);
+    else if (shape & 1) SPMV_AMD_ELL(64, false);
+    else if (shape & 2) SPMV_AMD_ELL(256, true);
+    else SPMV_AMD_ELL(256, false);
+#undef SPMV_AMD_ELL
 }
 
 void launch_ell_stencil5_spmv(int rows, int width, int grid_size, const int* idx,
@@ -1190,8 +1227,15 @@ void launch_ell_stencil5_spmv(int rows, int width, int grid_size, const int* idx
         launch_ell_spmv(rows, width, idx, val, x, y, alpha, beta, stream);
         return;
     }
-    hipLaunchKernelGGL(ell_stencil5_kernel, dim3(blocks_for(rows)), dim3(kBlock), 0, stream, rows,
-                       width, grid_size, idx, val, x, y, alpha, beta);
+    const int shape = env_int("SPMV_AMD_ELL_SHAPE", 2);
+#define SPMV_AMD_ELL5(B, NT)                                                                                      \
+    hipLaunchKernelGGL((ell_stencil5_kernel<B, NT>), dim3((unsigned)(((long long)rows + B - 1) / B)), dim3(B), 0, \
+                       stream, rows, width, grid_size, idx, val, x, y, alpha, beta)
+    if ((shape & 3) == 3) SPMV_AMD_ELL5(64, true);
+    else if (shape & 1) SPMV_AMD_ELL5(64, false);
+    else if (shape & 2) SPMV_AMD_ELL5(256, true);
+    else SPMV_AMD_ELL5(256, false);
+#undef SPMV_AMD_ELL5
 }
 
 }  // namespace spmv_amd

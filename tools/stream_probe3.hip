@@ -167,7 +167,7 @@ __global__ __launch_bounds__(64) void lds8x2_grid(const double* __restrict__ v, 
 // grid-row tiles of COLS columns (COLS / 64 rows per lane). ALIGNED: the coefficient run is fetched as an
 // aligned window (whole 128-byte lines: no line is shared by two load instructions of the wave).
 // PAIR: blocks b and b + 8 (same XCD under round-robin dispatch) take adjacent tiles.
-template <int COLS, bool ALIGNED, int PAIR>
+template <int COLS, bool ALIGNED, int PAIR, bool PADROW = false>
 __global__ __launch_bounds__(64) void lds_grid(const double* __restrict__ v, const double* __restrict__ x,
                                                double* __restrict__ y, int n, int tiles) {
     constexpr int R = COLS / 64;           // rows per lane
@@ -175,10 +175,20 @@ __global__ __launch_bounds__(64) void lds_grid(const double* __restrict__ v, con
     __shared__ double lds[64 * NL];
     const int lane = threadIdx.x;
     unsigned b = blockIdx.x;
-    if (PAIR > 1) b = (b / (8 * PAIR)) * (8 * PAIR) + (b & 7) * PAIR + ((b >> 3) % PAIR);
-    const int gi = 1 + b / tiles;
+    int gi, tile;
+    if (PADROW) {
+        // every grid row is padded to a multiple of 8 * PAIR tiles: XCD k always owns the same columns
+        const unsigned padded = (tiles + 8 * PAIR - 1) / (8 * PAIR) * (8 * PAIR);
+        gi = 1 + b / padded;
+        const unsigned w = b - (gi - 1) * padded;
+        tile = (w / (8 * PAIR)) * (8 * PAIR) + (w & 7) * PAIR + ((w >> 3) % PAIR);
+        if (tile >= tiles) return;
+    } else {
+        if (PAIR > 1) b = (b / (8 * PAIR)) * (8 * PAIR) + (b & 7) * PAIR + ((b >> 3) % PAIR);
+        gi = 1 + b / tiles;
+        tile = b - (gi - 1) * tiles;
+    }
     if (gi > n - 2) return;
-    const int tile = b - (gi - 1) * tiles;
     const int j0 = tile * COLS;
     const long long base = (4LL * n - 2) + (long long)(gi - 1) * (5LL * n - 2);
     const long long s0 = base + 5LL * j0 - 1;
@@ -322,13 +332,12 @@ int main(int argc, char** argv) {
 #define LG(COLS, AL, PR, label) do { const int tl = (n + COLS - 1) / COLS; const unsigned nb = ((unsigned)tl * (n - 2) + 31) & ~31u; RUN(label, hipLaunchKernelGGL((lds_grid<COLS, AL, PR>), dim3(nb), dim3(64), 0, 0, v, x, y, n, tl)); } while (0)
         if (data == 1) {
 #define LF(COLS, G, label) do { const long long nt_ = ((long long)n * (n - 2)) / COLS; const unsigned nb = (unsigned)((nt_ + 8 * G - 1) / (8 * G) * (8 * G)); RUN(label, hipLaunchKernelGGL((lds_flat<COLS, G>), dim3(nb), dim3(64), 0, 0, v, x, y, n, nt_)); } while (0)
+#define LGP(COLS, PR, label) do { const int tl = (n + COLS - 1) / COLS; const unsigned pd = (tl + 8 * PR - 1) / (8 * PR) * (8 * PR); RUN(label, hipLaunchKernelGGL((lds_grid<COLS, false, PR, true>), dim3(pd * (n - 2)), dim3(64), 0, 0, v, x, y, n, tl)); } while (0)
             for (int rep = 0; rep < 2; ++rep) {
-            LG(64, false, 1, "grid  64 cols G=1"); LG(64, false, 2, "grid  64 cols G=2"); LG(64, false, 4, "grid  64 cols G=4"); LG(64, false, 8, "grid  64 cols G=8"); LG(64, false, 16, "grid  64 cols G=16");
-            LG(128, false, 1, "grid 128 cols G=1"); LG(128, false, 2, "grid 128 cols G=2"); LG(128, false, 4, "grid 128 cols G=4"); LG(128, false, 8, "grid 128 cols G=8"); LG(128, false, 16, "grid 128 cols G=16");
-            LG(256, false, 1, "grid 256 cols G=1"); LG(256, false, 2, "grid 256 cols G=2"); LG(256, false, 4, "grid 256 cols G=4"); LG(256, false, 8, "grid 256 cols G=8");
-            LF(64, 1, "flat  64 rows G=1"); LF(64, 2, "flat  64 rows G=2"); LF(64, 4, "flat  64 rows G=4"); LF(64, 8, "flat  64 rows G=8"); LF(64, 16, "flat  64 rows G=16");
-            LF(128, 1, "flat 128 rows G=1"); LF(128, 2, "flat 128 rows G=2"); LF(128, 4, "flat 128 rows G=4"); LF(128, 8, "flat 128 rows G=8"); LF(128, 16, "flat 128 rows G=16");
-            LF(256, 1, "flat 256 rows G=1"); LF(256, 2, "flat 256 rows G=2"); LF(256, 4, "flat 256 rows G=4"); LF(256, 8, "flat 256 rows G=8");
+            LG(128, false, 1, "grid 128 cols G=1"); LG(128, false, 4, "grid 128 cols G=4"); LG(128, false, 8, "grid 128 cols G=8");
+            LGP(128, 1, "grid 128 cols G=1, rows padded (XCD <-> columns fixed)"); LGP(128, 2, "grid 128 cols G=2, rows padded"); LGP(128, 4, "grid 128 cols G=4, rows padded"); LGP(128, 8, "grid 128 cols G=8, rows padded");
+            LGP(64, 1, "grid  64 cols G=1, rows padded"); LGP(64, 4, "grid  64 cols G=4, rows padded"); LGP(64, 8, "grid  64 cols G=8, rows padded"); LGP(64, 16, "grid  64 cols G=16, rows padded");
+            LGP(256, 1, "grid 256 cols G=1, rows padded"); LGP(256, 2, "grid 256 cols G=2, rows padded"); LGP(256, 4, "grid 256 cols G=4, rows padded");
             }
         }
     }
