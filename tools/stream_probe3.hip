@@ -263,6 +263,57 @@ __global__ __launch_bounds__(64) void lds_flat(const double* __restrict__ v, con
         if (f[h]) __builtin_nontemporal_store(row5(q[0], q[1], q[2], q[3], q[4], xw[h], xc[h], xe[h], xn[h], xs[h]), y + r0 + lane + 64 * h);
     }
 }
+// 128 columns x ROWS grid rows per wave: the centre row of one step is the north row of the next, so a
+// tile fetches ROWS + 2 x rows instead of 3 * ROWS (fewer N/S re-reads through L2 / Infinity Cache)
+template <int ROWS, int G>
+__global__ __launch_bounds__(64) void lds_grid_rows(const double* __restrict__ v, const double* __restrict__ x,
+                                                    double* __restrict__ y, int n, int tiles, int total) {
+    __shared__ double lds[640 * ROWS];
+    const int lane = threadIdx.x;
+    unsigned b = blockIdx.x;
+    if (G > 1) b = (b / (8 * G)) * (8 * G) + (b & 7) * G + ((b >> 3) % G);
+    if ((int)b >= total) return;
+    const int rg = b / tiles, tile = b - rg * tiles;
+    const int gi0 = 1 + rg * ROWS;
+    const int j0 = tile * 128;
+    const long long hi = 5LL * n * n - 4LL * n - 1;
+    double c[10 * ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        const long long base = (4LL * n - 2) + (long long)(gi0 + r - 1) * (5LL * n - 2);
+        const long long e = base + 5LL * j0 - 1 + lane;
+#pragma unroll
+        for (int k = 0; k < 10; ++k) { long long idx = e + 64 * k; idx = idx > hi ? hi : idx; c[10 * r + k] = __builtin_nontemporal_load(v + idx); }
+    }
+    double xr[ROWS + 2][2], xw[ROWS][2], xe[ROWS][2];
+    bool f[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int j = j0 + lane + 64 * h;
+        f[h] = j > 0 && j < n - 1;
+        if (f[h]) {
+            const double* xl = x + (long long)(gi0 - 1) * n + j;
+#pragma unroll
+            for (int r = 0; r < ROWS + 2; ++r) xr[r][h] = (gi0 - 1 + r < n) ? xl[(long long)r * n] : 0.0;
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) { xw[r][h] = xl[(long long)(r + 1) * n - 1]; xe[r][h] = xl[(long long)(r + 1) * n + 1]; }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 10 * ROWS; ++k) lds[64 * k + lane] = c[k];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const double* q = lds + 640 * r + 5 * (lane + 64 * h);
+            if (f[h] && gi0 + r < n - 1)
+                __builtin_nontemporal_store(row5(q[0], q[1], q[2], q[3], q[4], xw[r][h], xr[r + 1][h], xe[r][h], xr[r][h], xr[r + 2][h]),
+                                            y + (long long)(gi0 + r) * n + j0 + lane + 64 * h);
+        }
+}
 __global__ void fill_pattern(double* p, size_t count, int mode) {
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= count) return;
@@ -332,12 +383,13 @@ int main(int argc, char** argv) {
 #define LG(COLS, AL, PR, label) do { const int tl = (n + COLS - 1) / COLS; const unsigned nb = ((unsigned)tl * (n - 2) + 31) & ~31u; RUN(label, hipLaunchKernelGGL((lds_grid<COLS, AL, PR>), dim3(nb), dim3(64), 0, 0, v, x, y, n, tl)); } while (0)
         if (data == 1) {
 #define LF(COLS, G, label) do { const long long nt_ = ((long long)n * (n - 2)) / COLS; const unsigned nb = (unsigned)((nt_ + 8 * G - 1) / (8 * G) * (8 * G)); RUN(label, hipLaunchKernelGGL((lds_flat<COLS, G>), dim3(nb), dim3(64), 0, 0, v, x, y, n, nt_)); } while (0)
-#define LGP(COLS, PR, label) do { const int tl = (n + COLS - 1) / COLS; const unsigned pd = (tl + 8 * PR - 1) / (8 * PR) * (8 * PR); RUN(label, hipLaunchKernelGGL((lds_grid<COLS, false, PR, true>), dim3(pd * (n - 2)), dim3(64), 0, 0, v, x, y, n, tl)); } while (0)
+#define LGR(ROWS, G, label) do { const int tl = (n + 127) / 128; const int tot = tl * ((n - 2 + ROWS - 1) / ROWS); RUN(label, hipLaunchKernelGGL((lds_grid_rows<ROWS, G>), dim3((unsigned)((tot + 8 * G - 1) / (8 * G) * (8 * G))), dim3(64), 0, 0, v, x, y, n, tl, tot)); } while (0)
             for (int rep = 0; rep < 2; ++rep) {
-            LG(128, false, 1, "grid 128 cols G=1"); LG(128, false, 4, "grid 128 cols G=4"); LG(128, false, 8, "grid 128 cols G=8");
-            LGP(128, 1, "grid 128 cols G=1, rows padded (XCD <-> columns fixed)"); LGP(128, 2, "grid 128 cols G=2, rows padded"); LGP(128, 4, "grid 128 cols G=4, rows padded"); LGP(128, 8, "grid 128 cols G=8, rows padded");
-            LGP(64, 1, "grid  64 cols G=1, rows padded"); LGP(64, 4, "grid  64 cols G=4, rows padded"); LGP(64, 8, "grid  64 cols G=8, rows padded"); LGP(64, 16, "grid  64 cols G=16, rows padded");
-            LGP(256, 1, "grid 256 cols G=1, rows padded"); LGP(256, 2, "grid 256 cols G=2, rows padded"); LGP(256, 4, "grid 256 cols G=4, rows padded");
+            LG(128, false, 4, "grid 128 cols G=4");
+            LGR(1, 4, "grid 128 cols x 1 row  G=4 (check)");
+            LGR(2, 1, "grid 128 cols x 2 rows G=1"); LGR(2, 2, "grid 128 cols x 2 rows G=2"); LGR(2, 4, "grid 128 cols x 2 rows G=4"); LGR(2, 8, "grid 128 cols x 2 rows G=8");
+            LGR(3, 1, "grid 128 cols x 3 rows G=1"); LGR(3, 2, "grid 128 cols x 3 rows G=2"); LGR(3, 4, "grid 128 cols x 3 rows G=4"); LGR(3, 8, "grid 128 cols x 3 rows G=8");
+            LGR(4, 1, "grid 128 cols x 4 rows G=1"); LGR(4, 2, "grid 128 cols x 4 rows G=2"); LGR(4, 4, "grid 128 cols x 4 rows G=4");
             }
         }
     }
