@@ -20,6 +20,8 @@
 // partial per workgroup (= per wave: a shuffle tree, no LDS).
 #include "kernels.hpp"
 
+#include <stdlib.h>
+
 namespace spmv_amd {
 namespace {
 
@@ -171,6 +173,93 @@ __global__ __launch_bounds__(kBlock) void reduce_slices_kernel(const double* __r
     if (threadIdx.x == 0) stage[blockIdx.x] = s[0];
 }
 
+// The CG scalar step (see cg_scalars_step_kernel below), callable from the tail of a reduction.
+__device__ __forceinline__ void cg_scalars_step(CgScalars* s, double tol, double* history, int* host_record,
+                                                int sequence) {
+    if (!s->converged) {
+        s->alpha = s->rr_old / s->pAp;  // the alpha update_r used (same division), kept for the x update
+        const double res = sqrt(s->rr_new);
+        s->residual = res;
+        s->iterations += 1;
+        if (history != nullptr && s->iterations < s->max_history) history[s->iterations] = res;
+        if (res / s->b_norm < tol) {
+            s->converged = 1;
+        } else {
+            s->beta = s->rr_new / s->rr_old;
+            s->rr_old = s->rr_new;
+        }
+    }
+    if (host_record != nullptr) {
+        // status record in host-coherent pinned memory: payload first, then the sequence number with
+        // system-scope release, so a host that sees `sequence` sees this iteration's payload
+        host_record[1] = s->converged;
+        host_record[2] = s->iterations;
+        __hip_atomic_store(&host_record[0], sequence, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+// Both stages of the wide reduction in ONE launch: block b sums its slice exactly as
+// reduce_slices_kernel does and publishes stage[b]; the block that draws the last ticket then sums
+// the stage values exactly as reduce_partials_kernel does (thread-strided, 256-wide tree), so the
+// result is bit-identical to the two-launch form and independent of which block finishes last.
+// Cross-XCD visibility: stage values and the ticket counter are agent-scope atomics (the L2s of the
+// eight XCDs are not coherent for plain accesses); the acq_rel ticket orders a block's stage store
+// before its ticket and the last block's stage loads after the final ticket.
+// step_scalars != nullptr (single-rank solves: no all-reduce between the sum and the step): the
+// last block also runs the CG scalar step on the freshly written sum.
+struct StepArgs {
+    CgScalars* scalars;
+    double tol;
+    double* history;
+    int* host_record;
+    int sequence;
+};
+
+__global__ __launch_bounds__(kBlock) void reduce_fused_kernel(const double* __restrict__ partials, int count,
+                                                              int slice, double* stage, unsigned* ticket,
+                                                              double* __restrict__ out,
+                                                              const int* __restrict__ skip_flag, StepArgs step) {
+    __shared__ double s[kBlock];
+    __shared__ int last_block;
+    if (skip_flag != nullptr && *skip_flag != 0) {
+        // converged: nothing to sum, but a pending status record must still be published
+        if (step.scalars != nullptr && blockIdx.x == 0 && threadIdx.x == 0)
+            cg_scalars_step(step.scalars, step.tol, step.history, step.host_record, step.sequence);
+        return;
+    }
+    const int lo = blockIdx.x * slice;
+    const int hi = min(lo + slice, count);
+    double acc = 0.0;
+    for (int i = lo + threadIdx.x; i < hi; i += kBlock) acc += partials[i];
+    s[threadIdx.x] = acc;
+    __syncthreads();
+    for (int stride = kBlock / 2; stride > 0; stride >>= 1) {
+        if ((int)threadIdx.x < stride) s[threadIdx.x] += s[threadIdx.x + stride];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(&stage[blockIdx.x], s[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        last_block = (t == gridDim.x - 1) ? 1 : 0;
+    }
+    __syncthreads();
+    if (!last_block) return;
+    acc = 0.0;
+    for (int i = threadIdx.x; i < (int)gridDim.x; i += kBlock)
+        acc += __hip_atomic_load(&stage[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s[threadIdx.x] = acc;
+    __syncthreads();
+    for (int stride = kBlock / 2; stride > 0; stride >>= 1) {
+        if ((int)threadIdx.x < stride) s[threadIdx.x] += s[threadIdx.x + stride];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        *out = s[0];
+        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+        if (step.scalars != nullptr) cg_scalars_step(step.scalars, step.tol, step.history, step.host_record, step.sequence);
+    }
+}
+
 __global__ void scalar_divide_kernel(const double* num, const double* den, double* out) {
     if (threadIdx.x == 0 && blockIdx.x == 0) *out = (*num) / (*den);
 }
@@ -262,6 +351,7 @@ __global__ __launch_bounds__(kStream) void cg_update_px_kernel(size_t n, const C
             const d2 rv = load_once(r, i);
             pv.x = fma(1.0, rv.x, beta * pv.x);
             pv.y = fma(1.0, rv.y, beta * pv.y);
+            // plain store: a nontemporal one measured the same (15.89-15.97 ms per solve at 50 M rows either way)
             reinterpret_cast<d2*>(p)[i] = pv;
         }
     }
@@ -288,26 +378,7 @@ __global__ void cg_scalars_init_kernel(CgScalars* s, double* history) {
 __global__ void cg_scalars_step_kernel(CgScalars* s, double tol, double* history, int* host_record,
                                        int sequence) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    if (!s->converged) {
-        s->alpha = s->rr_old / s->pAp;  // the alpha update_r used (same division), kept for the x update
-        const double res = sqrt(s->rr_new);
-        s->residual = res;
-        s->iterations += 1;
-        if (history != nullptr && s->iterations < s->max_history) history[s->iterations] = res;
-        if (res / s->b_norm < tol) {
-            s->converged = 1;
-        } else {
-            s->beta = s->rr_new / s->rr_old;
-            s->rr_old = s->rr_new;
-        }
-    }
-    if (host_record != nullptr) {
-        // status record in host-coherent pinned memory: payload first, then the sequence number with
-        // system-scope release, so a host that sees `sequence` sees this iteration's payload
-        host_record[1] = s->converged;
-        host_record[2] = s->iterations;
-        __hip_atomic_store(&host_record[0], sequence, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
+    cg_scalars_step(s, tol, history, host_record, sequence);
 }
 
 inline unsigned stream_grid(size_t n) {
@@ -347,7 +418,7 @@ void launch_update_p_dev(size_t n, const double* r, const double* d_b, double* p
     hipLaunchKernelGGL(update_p_dev_kernel, dim3(stream_grid(n)), dim3(kStream), 0, stream, n, r, d_b, p);
 }
 
-size_t dot_scratch_doubles(size_t n) { return (size_t)stream_grid(n) + kReduceStageBlocks; }
+size_t dot_scratch_doubles(size_t n) { return (size_t)stream_grid(n) + kReduceStageBlocks + 1; }
 int cg_partial_count(size_t n) { return (int)stream_grid(n); }
 
 void launch_dot(size_t n, const double* x, const double* y, double* scratch, double* d_result,
@@ -385,24 +456,59 @@ void launch_cg_update_px(size_t n, const CgScalars* s, const double* r, double* 
                        iteration);
 }
 
+// Two launches by default. SPMV_AMD_REDUCE_ONE_LAUNCH=1 selects reduce_fused_kernel (same result bits):
+// measured on MI355X it is the SLOWER form -- 16.07 vs 15.98 ms per 15-iteration solve at 50 M rows, i.e.
+// ~6 us per iteration worse although it removes three launches: the agent-scope release / acquire of 256
+// blocks (L2 write-back + invalidate each) costs more than the ~2 us kernel boundaries it saves.
+static bool reduce_in_two_launches() {
+    static const bool two = [] {
+        const char* v = getenv("SPMV_AMD_REDUCE_ONE_LAUNCH");
+        return !(v != nullptr && v[0] == '1');
+    }();
+    return two;
+}
+
 void launch_reduce_partials(const double* partials, int count, double* d_out, const int* d_skip_flag,
                             hipStream_t stream, double* stage) {
     // One block walking tens of thousands of partials is latency-bound (0.3 ms for 200k on MI355X);
-    // with a stage buffer the sum is split over kReduceStageBlocks blocks first. Both shapes are fixed.
+    // with a stage buffer the sum is split over kReduceStageBlocks blocks first, in one launch whose
+    // last-finishing block adds the stage values. Both shapes are fixed.
     if (stage != nullptr && count > 4 * kBlock) {
         const int slice = (count + kReduceStageBlocks - 1) / kReduceStageBlocks;
         const int blocks = (count + slice - 1) / slice;
-        hipLaunchKernelGGL(reduce_slices_kernel, dim3(blocks), dim3(kBlock), 0, stream, partials, count,
-                           slice, stage, d_skip_flag);
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(kBlock), 0, stream, stage, blocks, d_out,
-                           d_skip_flag);
+        if (reduce_in_two_launches()) {
+            hipLaunchKernelGGL(reduce_slices_kernel, dim3(blocks), dim3(kBlock), 0, stream, partials, count, slice,
+                               stage, d_skip_flag);
+            hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(kBlock), 0, stream, stage, blocks, d_out,
+                               d_skip_flag);
+            return;
+        }
+        hipLaunchKernelGGL(reduce_fused_kernel, dim3(blocks), dim3(kBlock), 0, stream, partials, count, slice, stage,
+                           reinterpret_cast<unsigned*>(stage + kReduceStageBlocks), d_out, d_skip_flag,
+                           StepArgs{nullptr, 0.0, nullptr, nullptr, 0});
         return;
     }
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(kBlock), 0, stream, partials, count, d_out,
                        d_skip_flag);
 }
 
-int reduce_stage_doubles() { return kReduceStageBlocks; }
+void launch_reduce_partials_and_step(const double* partials, int count, double* d_out, const int* d_skip_flag,
+                                     hipStream_t stream, double* stage, CgScalars* s, double tol, double* history,
+                                     int* host_record, int sequence) {
+    if (stage != nullptr && count > 4 * kBlock && !reduce_in_two_launches()) {
+        const int slice = (count + kReduceStageBlocks - 1) / kReduceStageBlocks;
+        const int blocks = (count + slice - 1) / slice;
+        hipLaunchKernelGGL(reduce_fused_kernel, dim3(blocks), dim3(kBlock), 0, stream, partials, count, slice, stage,
+                           reinterpret_cast<unsigned*>(stage + kReduceStageBlocks), d_out, d_skip_flag,
+                           StepArgs{s, tol, history, host_record, sequence});
+        return;
+    }
+    launch_reduce_partials(partials, count, d_out, d_skip_flag, stream, stage);
+    launch_cg_scalars_step(s, tol, history, host_record, sequence, stream);
+}
+
+// stage values + one slot for the ticket counter, which must be ZERO before the first launch
+int reduce_stage_doubles() { return kReduceStageBlocks + 1; }
 
 void launch_cg_scalars_init(CgScalars* s, double* history, hipStream_t stream) {
     hipLaunchKernelGGL(cg_scalars_init_kernel, dim3(1), dim3(1), 0, stream, s, history);

@@ -38,6 +38,7 @@ struct Vectors {
         p = device_alloc<double>(n);
         Ap = device_alloc<double>(n);
         scratch = device_alloc<double>(dot_scratch_doubles(n));
+        HIP_CHECK(hipMemset(scratch, 0, dot_scratch_doubles(n) * sizeof(double)));  // ticket counter of the reduction
     }
     void release() {
         device_release(x);

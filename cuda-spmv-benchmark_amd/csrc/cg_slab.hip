@@ -20,6 +20,7 @@
 //    first and last grid row of the slab are launched once the halo has landed. Each row is
 //    computed by the same code whichever launch it falls in, so overlap cannot change results.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -56,9 +57,12 @@ struct SpmvAmdCgSlab {
     const char* variant_name = "";
     bool fused_dot = false;
     std::vector<double> history;
-    // event pairs around every in-loop SpMV (recorded without any host sync, resolved after the
-    // loop) so that time_spmv_ms is the live sum over the timed region even with timers off
+    // event pairs around every spmv_event_stride-th in-loop SpMV (recorded without any host sync,
+    // resolved after the loop): time_spmv_ms with timers off is the live average of those launches
+    // times the iteration count. Stride 1 = every launch; SPMV_AMD_SPMV_EVENT_STRIDE=4 / 0 (none)
+    // changed a 16 ms solve at 50 M rows by < 0.5 %, so every launch is timed.
     std::vector<hipEvent_t> spmv_ev;
+    int spmv_event_stride = 1;
     int poll_sequence = 0;
     double last_spmv_ms = 0.0;
     int last_spmv_launches = 0;
@@ -92,8 +96,12 @@ void make_common(SpmvAmdCgSlab* s) {
     s->p = s->p_alloc + lead;
     HIP_CHECK(hipMemset(s->p_alloc, 0, (lead + nl + (size_t)s->halo + 2) * sizeof(double)));
     s->shape = current_launch_shape();
+    if (const char* v = getenv("SPMV_AMD_SPMV_EVENT_STRIDE")) s->spmv_event_stride = atoi(v);
     s->partials_blas = device_alloc<double>(dot_scratch_doubles(nl));
     s->reduce_stage = device_alloc<double>((size_t)reduce_stage_doubles());
+    // both end in the ticket counter of the one-launch reduction, which starts at zero
+    HIP_CHECK(hipMemset(s->partials_blas, 0, dot_scratch_doubles(nl) * sizeof(double)));
+    HIP_CHECK(hipMemset(s->reduce_stage, 0, (size_t)reduce_stage_doubles() * sizeof(double)));
     s->d_s = device_alloc<CgScalars>(1);
     HIP_CHECK(hipMemset(s->d_s, 0, sizeof(CgScalars)));
     HIP_CHECK(hipHostMalloc((void**)&s->h_poll, sizeof(*s->h_poll), hipHostMallocCoherent | hipHostMallocMapped));
@@ -326,33 +334,50 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
     start_p_halo();
 
     // ---- iterations ----
-    int enqueued = 0;
+    int enqueued = 0, sampled = 0;
+    std::vector<int> sampled_iteration;  // 0-based loop index of each timed SpMV
     bool done = false;
     while (!done && enqueued < config->max_iters) {
         if (detail) {
             timed(&stats->time_spmv_ms, nullptr, [&] { slab_spmv(s, true, halo_in_flight, skip); });
         } else {
-            while (s->spmv_ev.size() < 2 * (size_t)(enqueued + 1)) {
-                hipEvent_t e;
-                HIP_CHECK(hipEventCreate(&e));
-                s->spmv_ev.push_back(e);
+            const bool sample = s->spmv_event_stride > 0 && enqueued % s->spmv_event_stride == 0;
+            if (sample) {
+                while (s->spmv_ev.size() < 2 * (size_t)(sampled + 1)) {
+                    hipEvent_t e;
+                    HIP_CHECK(hipEventCreate(&e));
+                    s->spmv_ev.push_back(e);
+                }
+                HIP_CHECK(hipEventRecord(s->spmv_ev[2 * sampled], s->compute));
+                slab_spmv(s, true, halo_in_flight, skip, nullptr, s->spmv_ev[2 * sampled + 1]);
+                sampled_iteration.push_back(enqueued);
+                ++sampled;
+            } else {
+                slab_spmv(s, true, halo_in_flight, skip);
             }
-            HIP_CHECK(hipEventRecord(s->spmv_ev[2 * enqueued], s->compute));
-            slab_spmv(s, true, halo_in_flight, skip, nullptr, s->spmv_ev[2 * enqueued + 1]);
         }
         if (reduce) timed(&stats->time_allreduce_ms, nullptr, [&] { comm->allreduce_sum(&s->d_s->pAp, 1, s->compute); });
         timed(&stats->time_blas1_ms, &stats->time_axpy_update_r_ms, [&] {
             launch_cg_update_r(nl, s->d_s, s->Ap, s->r, s->partials_blas, s->compute);
         });
-        timed(&stats->time_reductions_ms, &stats->time_dot_rs_new_ms, [&] {
-            launch_reduce_partials(s->partials_blas, cg_partial_count(nl), &s->d_s->rr_new, skip, s->compute, s->reduce_stage);
-        });
-        if (reduce) timed(&stats->time_allreduce_ms, nullptr, [&] { comm->allreduce_sum(&s->d_s->rr_new, 1, s->compute); });
         // the scalar step publishes {sequence, converged, iterations} straight into host-coherent pinned
-        // memory: no copy command sits between it and the p update on the stream
+        // memory: no copy command sits between it and the p update on the stream. Without an all-reduce
+        // between the sum and the step, the step runs in the tail of the reduction's launch.
         ++s->poll_sequence;
-        launch_cg_scalars_step(s->d_s, config->tolerance, s->d_hist, &s->h_poll->sequence, s->poll_sequence,
-                               s->compute);
+        if (reduce) {
+            timed(&stats->time_reductions_ms, &stats->time_dot_rs_new_ms, [&] {
+                launch_reduce_partials(s->partials_blas, cg_partial_count(nl), &s->d_s->rr_new, skip, s->compute, s->reduce_stage);
+            });
+            timed(&stats->time_allreduce_ms, nullptr, [&] { comm->allreduce_sum(&s->d_s->rr_new, 1, s->compute); });
+            launch_cg_scalars_step(s->d_s, config->tolerance, s->d_hist, &s->h_poll->sequence, s->poll_sequence,
+                                   s->compute);
+        } else {
+            timed(&stats->time_reductions_ms, &stats->time_dot_rs_new_ms, [&] {
+                launch_reduce_partials_and_step(s->partials_blas, cg_partial_count(nl), &s->d_s->rr_new, skip, s->compute,
+                                                s->reduce_stage, s->d_s, config->tolerance, s->d_hist,
+                                                &s->h_poll->sequence, s->poll_sequence);
+            });
+        }
         ++enqueued;
 
         // p <- r + beta p, its halo exchange, and (when overlapping) nothing else before the host
@@ -379,14 +404,17 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
 
     CgScalars fin;
     HIP_CHECK(hipMemcpy(&fin, s->d_s, sizeof fin, hipMemcpyDeviceToHost));
-    if (!detail) {  // SpMV launches that did real work: one per counted iteration
+    if (!detail) {  // timed SpMV launches that did real work (one per counted iteration), scaled to all of them
         double ms_sum = 0.0;
-        for (int k = 0; k < fin.iterations && k < enqueued; ++k) {
+        int used = 0;
+        for (int k = 0; k < sampled; ++k) {
+            if (sampled_iteration[k] >= fin.iterations) continue;
             float ms = 0.f;
             HIP_CHECK(hipEventElapsedTime(&ms, s->spmv_ev[2 * k], s->spmv_ev[2 * k + 1]));
             ms_sum += ms;
+            ++used;
         }
-        stats->time_spmv_ms = ms_sum;
+        stats->time_spmv_ms = used > 0 ? ms_sum / used * fin.iterations : 0.0;
     }
     s->last_spmv_ms = stats->time_spmv_ms;
     s->last_spmv_launches = fin.iterations;

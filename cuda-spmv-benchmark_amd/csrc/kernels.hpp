@@ -103,7 +103,7 @@ void launch_axpy_dev(size_t n, const double* d_a, const double* x, double* y, bo
 void launch_update_p_dev(size_t n, const double* r, const double* d_b, double* p,
                          hipStream_t stream);
 // result = sum x[i]*y[i], fixed reduction shape (deterministic run to run). scratch must
-// hold dot_scratch_doubles(n) doubles.
+// hold dot_scratch_doubles(n) doubles and be zeroed once after allocation (ticket counter).
 size_t dot_scratch_doubles(size_t n);
 void launch_dot(size_t n, const double* x, const double* y, double* scratch, double* d_result,
                 hipStream_t stream);
@@ -128,10 +128,16 @@ void launch_cg_update_px(size_t n, const CgScalars* s, const double* r, double* 
                          double* x, int iteration, hipStream_t stream);
 int cg_partial_count(size_t n);  // partial slots written by the two reducing kernels above
 // *d_out = sum of partials[0..count) in a fixed order. `stage` (reduce_stage_doubles() doubles,
-// may be null) lets large counts be summed by many blocks first.
+// may be null; its LAST slot is a ticket counter and must be zero before the first use) lets
+// large counts be summed by many blocks first, in the same launch.
 int reduce_stage_doubles();
 void launch_reduce_partials(const double* partials, int count, double* d_out,
                             const int* d_skip_flag, hipStream_t stream, double* stage = nullptr);
+// The same reduction followed by launch_cg_scalars_step(), in one launch when the wide path is taken
+// (only valid when no all-reduce has to happen between the sum and the step).
+void launch_reduce_partials_and_step(const double* partials, int count, double* d_out, const int* d_skip_flag,
+                                     hipStream_t stream, double* stage, CgScalars* s, double tol, double* history,
+                                     int* host_record, int sequence);
 // After the (all-reduced) r.r is known: b_norm (first call), residual, history, convergence
 // flag, beta, rr_old <- rr_new, iteration counter.
 void launch_cg_scalars_init(CgScalars* s, double* history, hipStream_t stream);
