@@ -103,10 +103,16 @@ def test_reference_entry_point_cg_solve_mgpu_partitioned(B, O, fresh_host_matric
     assert np.array_equal(x2, x) and st2.time_spmv_ms > 0 and st2.time_blas1_ms > 0
 
 
-def test_slab_spmv_matches_halo_oracle(B, O, fresh_host_matrices):
+@pytest.mark.parametrize("n,rowlds_min_grid,variant", [(256, None, "stencil5/row-direct"), (640, None, "stencil5/row-lds"),
+                                                       (130, "2", "stencil5/row-lds"), (260, "2", "stencil5/row-lds"),
+                                                       (64, "2", "stencil5/row-lds")])
+def test_slab_spmv_matches_halo_oracle(B, O, fresh_host_matrices, monkeypatch, n, rowlds_min_grid, variant):
     """Slab-local SpMV with halos for every rank of a 1/2/4-way split, one rank at a time on this
-    GPU (staged communicator with trivial callbacks: spmv() fills the halos from the full vector)."""
-    n = 256
+    GPU (staged communicator with trivial callbacks: spmv() fills the halos from the full vector).
+    Random coefficients, so a coefficient taken from the wrong CSR position cannot go unnoticed; the
+    row-lds kernel is also forced onto small grids (one or two clamped tiles per grid row)."""
+    if rowlds_min_grid is not None:
+        monkeypatch.setenv("SPMV_AMD_ROWLDS_MIN_GRID", rowlds_min_grid)
     e = O.stencil5_coo(n)
     rng = np.random.default_rng(1)
     e["value"] = rng.uniform(-3, 3, len(e))
@@ -120,6 +126,8 @@ def test_slab_spmv_matches_halo_oracle(B, O, fresh_host_matrices):
             slab = B.CgSlab.from_matrix(m, comm)
             off, nl = O.partition_rows(n * n, world, rank)
             assert (slab.row_offset, slab.n_local) == (off, nl)
+            if (n * n) % (world * n) == 0:  # slabs of whole grid rows; others run wave-tile / row-generic
+                assert slab.variant() == variant
             base = rp[off]
             lrp = (rp[off:off + nl + 1] - base).astype(np.int32)
             hp = x[off - n:off] if rank > 0 else None

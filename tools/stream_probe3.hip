@@ -314,6 +314,62 @@ __global__ __launch_bounds__(64) void lds_grid_rows(const double* __restrict__ v
                                             y + (long long)(gi0 + r) * n + j0 + lane + 64 * h);
         }
 }
+// What would a CG iteration cost with the direction update folded into the SpMV? One pass that reads r, the old
+// p (both at the five stencil points) and x, and writes x += a p_old, p_new = r + b p_old (other buffer) and
+// Ap = A p_new: 88 B/row instead of 56 (SpMV) + 40 (x / p update) = 96 in two passes.
+template <int G>
+__global__ __launch_bounds__(64) void fused_grid(const double* __restrict__ v, const double* __restrict__ r,
+                                                 const double* __restrict__ pold, double* __restrict__ pnew,
+                                                 double* __restrict__ xv, double* __restrict__ y, int n, int tiles,
+                                                 double a, double bta) {
+    __shared__ double lds[640];
+    const int lane = threadIdx.x;
+    unsigned b = blockIdx.x;
+    if (G > 1) b = (b / (8 * G)) * (8 * G) + (b & 7) * G + ((b >> 3) % G);
+    const int gi = 1 + b / tiles;
+    if (gi > n - 2) return;
+    const int tile = b - (gi - 1) * tiles;
+    const int j0 = tile * 128;
+    const long long base = (4LL * n - 2) + (long long)(gi - 1) * (5LL * n - 2);
+    const long long e = base + 5LL * j0 - 1 + lane;
+    const long long hi = 5LL * n * n - 4LL * n - 1;
+    double c[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) { long long idx = e + 64 * k; idx = idx > hi ? hi : idx; c[k] = __builtin_nontemporal_load(v + idx); }
+    double pc[2], pw[2], pe[2], pn[2], ps[2], xo[2];
+    bool f[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int j = j0 + lane + 64 * h;
+        f[h] = j > 0 && j < n - 1;
+        if (f[h]) {
+            const long long at = (long long)gi * n + j;
+            const double *rl = r + at, *pl = pold + at;
+            const double p0 = pl[0];
+            pc[h] = fma(1.0, rl[0], bta * p0);
+            pw[h] = fma(1.0, rl[-1], bta * pl[-1]);
+            pe[h] = fma(1.0, rl[1], bta * pl[1]);
+            pn[h] = fma(1.0, rl[-n], bta * pl[-n]);
+            ps[h] = fma(1.0, rl[n], bta * pl[n]);
+            xo[h] = fma(a, p0, __builtin_nontemporal_load(xv + at));
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 10; ++k) lds[64 * k + lane] = c[k];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const double* q = lds + 5 * (lane + 64 * h);
+        if (f[h]) {
+            const long long at = (long long)gi * n + j0 + lane + 64 * h;
+            __builtin_nontemporal_store(xo[h], xv + at);
+            pnew[at] = pc[h];
+            __builtin_nontemporal_store(row5(q[0], q[1], q[2], q[3], q[4], pw[h], pc[h], pe[h], pn[h], ps[h]), y + at);
+        }
+    }
+}
 __global__ void fill_pattern(double* p, size_t count, int mode) {
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= count) return;
@@ -383,13 +439,19 @@ int main(int argc, char** argv) {
 #define LG(COLS, AL, PR, label) do { const int tl = (n + COLS - 1) / COLS; const unsigned nb = ((unsigned)tl * (n - 2) + 31) & ~31u; RUN(label, hipLaunchKernelGGL((lds_grid<COLS, AL, PR>), dim3(nb), dim3(64), 0, 0, v, x, y, n, tl)); } while (0)
         if (data == 1) {
 #define LF(COLS, G, label) do { const long long nt_ = ((long long)n * (n - 2)) / COLS; const unsigned nb = (unsigned)((nt_ + 8 * G - 1) / (8 * G) * (8 * G)); RUN(label, hipLaunchKernelGGL((lds_flat<COLS, G>), dim3(nb), dim3(64), 0, 0, v, x, y, n, nt_)); } while (0)
-#define LGR(ROWS, G, label) do { const int tl = (n + 127) / 128; const int tot = tl * ((n - 2 + ROWS - 1) / ROWS); RUN(label, hipLaunchKernelGGL((lds_grid_rows<ROWS, G>), dim3((unsigned)((tot + 8 * G - 1) / (8 * G) * (8 * G))), dim3(64), 0, 0, v, x, y, n, tl, tot)); } while (0)
+            {
+            double *r_, *p2_, *x2_;
+            CK(hipMalloc(&r_, rows * 8)); CK(hipMalloc(&p2_, rows * 8)); CK(hipMalloc(&x2_, rows * 8));
+            hipLaunchKernelGGL(fill_pattern, dim3(blocks_for(rows, 256)), dim3(256), 0, 0, r_, rows, 2);
+            hipLaunchKernelGGL(fill_pattern, dim3(blocks_for(rows, 256)), dim3(256), 0, 0, x2_, rows, 2);
+            CK(hipMemset(p2_, 0, rows * 8));
+            CK(hipDeviceSynchronize());
+            const int tl = (n + 127) / 128;
+#define FG(G, label) do { const unsigned nb = ((unsigned)tl * (n - 2) + 8 * G - 1) / (8 * G) * (8 * G); double ms = time_ms([&] { hipLaunchKernelGGL((fused_grid<G>), dim3(nb), dim3(64), 0, 0, v, r_, x, p2_, x2_, y, n, tl, 1e-9, 0.999); }); printf("%-64s : %7.3f ms  %8.1f GB/s (88 B/row)\n", label, ms, rows * 88.0 / ms / 1e6); fflush(stdout); } while (0)
             for (int rep = 0; rep < 2; ++rep) {
-            LG(128, false, 4, "grid 128 cols G=4");
-            LGR(1, 4, "grid 128 cols x 1 row  G=4 (check)");
-            LGR(2, 1, "grid 128 cols x 2 rows G=1"); LGR(2, 2, "grid 128 cols x 2 rows G=2"); LGR(2, 4, "grid 128 cols x 2 rows G=4"); LGR(2, 8, "grid 128 cols x 2 rows G=8");
-            LGR(3, 1, "grid 128 cols x 3 rows G=1"); LGR(3, 2, "grid 128 cols x 3 rows G=2"); LGR(3, 4, "grid 128 cols x 3 rows G=4"); LGR(3, 8, "grid 128 cols x 3 rows G=8");
-            LGR(4, 1, "grid 128 cols x 4 rows G=1"); LGR(4, 2, "grid 128 cols x 4 rows G=2"); LGR(4, 4, "grid 128 cols x 4 rows G=4");
+                LG(128, false, 4, "grid 128 cols G=4 (SpMV alone, 56 B/row)");
+                FG(1, "fused SpMV + x/p update, G=1"); FG(2, "fused SpMV + x/p update, G=2"); FG(4, "fused SpMV + x/p update, G=4"); FG(8, "fused SpMV + x/p update, G=8");
+            }
             }
         }
     }
