@@ -10,10 +10,11 @@
 // which is what oracle/spmv_oracle.c evaluates on the CPU.
 //
 // Memory contract: STENCIL5 is HBM-bound at 56 B per interior row (40 B values, 8 B x,
-// 8 B y). The wave-tile kernel streams `values` with fully coalesced 16-byte loads,
-// transposes them through a wave-private LDS strip, reads x/y as 16-byte pairs and
-// keeps the +-grid_size neighbour rows L2-resident by giving each XCD a contiguous
-// band of tiles (blockIdx % 8 is only a locality label, never a correctness input).
+// 8 B y). Five kernels implement it; the default (row-lds, further down) streams `values`
+// with fully coalesced nontemporal 8-byte loads through a wave-private LDS strip, keeps x / y
+// at 8 bytes per lane and deals tiles to the XCDs in groups; the others (row-direct,
+// column-march, wave-tile, row-generic) are the earlier shapes, kept selectable and tested.
+// blockIdx -> tile mappings are performance choices only, never a correctness input.
 #include "kernels.hpp"
 
 #include <stdlib.h>

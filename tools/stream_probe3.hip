@@ -370,6 +370,57 @@ __global__ __launch_bounds__(64) void fused_grid(const double* __restrict__ v, c
         }
     }
 }
+// cache-policy bits on the coefficient loads of the 128-column grid tile (G = 4): POL 0 plain, 1 nt, 2 sc1,
+// 3 sc0 sc1, 4 sc0 sc1 nt, 5 sc1 nt, 6 sc0, 7 sc0 nt
+template <int POL> __device__ __forceinline__ double ld_pol(const double* p) {
+    double v;
+    if (POL == 0) asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    if (POL == 1) asm volatile("global_load_dwordx2 %0, %1, off nt" : "=v"(v) : "v"(p) : "memory");
+    if (POL == 2) asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+    if (POL == 3) asm volatile("global_load_dwordx2 %0, %1, off sc0 sc1" : "=v"(v) : "v"(p) : "memory");
+    if (POL == 4) asm volatile("global_load_dwordx2 %0, %1, off sc0 sc1 nt" : "=v"(v) : "v"(p) : "memory");
+    if (POL == 5) asm volatile("global_load_dwordx2 %0, %1, off sc1 nt" : "=v"(v) : "v"(p) : "memory");
+    if (POL == 6) asm volatile("global_load_dwordx2 %0, %1, off sc0" : "=v"(v) : "v"(p) : "memory");
+    if (POL == 7) asm volatile("global_load_dwordx2 %0, %1, off sc0 nt" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+template <int POL>
+__global__ __launch_bounds__(64) void lds_grid_pol(const double* __restrict__ v, const double* __restrict__ x,
+                                                   double* __restrict__ y, int n, int tiles) {
+    __shared__ double lds[640];
+    const int lane = threadIdx.x;
+    unsigned b = blockIdx.x;
+    b = (b / 32) * 32 + (b & 7) * 4 + ((b >> 3) % 4);
+    const int gi = 1 + b / tiles;
+    if (gi > n - 2) return;
+    const int tile = b - (gi - 1) * tiles;
+    const int j0 = tile * 128;
+    const long long base = (4LL * n - 2) + (long long)(gi - 1) * (5LL * n - 2);
+    const long long e = base + 5LL * j0 - 1 + lane;
+    const long long hi = 5LL * n * n - 4LL * n - 1;
+    double c[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) { long long idx = e + 64 * k; idx = idx > hi ? hi : idx; c[k] = ld_pol<POL>(v + idx); }
+    double xc[2], xw[2], xe[2], xn[2], xs[2];
+    bool f[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int j = j0 + lane + 64 * h;
+        f[h] = j > 0 && j < n - 1;
+        if (f[h]) { const double* xl = x + (long long)gi * n + j; xc[h] = xl[0], xw[h] = xl[-1], xe[h] = xl[1], xn[h] = xl[-n], xs[h] = xl[n]; }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int k = 0; k < 10; ++k) lds[64 * k + lane] = c[k];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const double* q = lds + 5 * (lane + 64 * h);
+        if (f[h]) __builtin_nontemporal_store(row5(q[0], q[1], q[2], q[3], q[4], xw[h], xc[h], xe[h], xn[h], xs[h]), y + (long long)gi * n + j0 + lane + 64 * h);
+    }
+}
 __global__ void fill_pattern(double* p, size_t count, int mode) {
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= count) return;
@@ -439,19 +490,11 @@ int main(int argc, char** argv) {
 #define LG(COLS, AL, PR, label) do { const int tl = (n + COLS - 1) / COLS; const unsigned nb = ((unsigned)tl * (n - 2) + 31) & ~31u; RUN(label, hipLaunchKernelGGL((lds_grid<COLS, AL, PR>), dim3(nb), dim3(64), 0, 0, v, x, y, n, tl)); } while (0)
         if (data == 1) {
 #define LF(COLS, G, label) do { const long long nt_ = ((long long)n * (n - 2)) / COLS; const unsigned nb = (unsigned)((nt_ + 8 * G - 1) / (8 * G) * (8 * G)); RUN(label, hipLaunchKernelGGL((lds_flat<COLS, G>), dim3(nb), dim3(64), 0, 0, v, x, y, n, nt_)); } while (0)
-            {
-            double *r_, *p2_, *x2_;
-            CK(hipMalloc(&r_, rows * 8)); CK(hipMalloc(&p2_, rows * 8)); CK(hipMalloc(&x2_, rows * 8));
-            hipLaunchKernelGGL(fill_pattern, dim3(blocks_for(rows, 256)), dim3(256), 0, 0, r_, rows, 2);
-            hipLaunchKernelGGL(fill_pattern, dim3(blocks_for(rows, 256)), dim3(256), 0, 0, x2_, rows, 2);
-            CK(hipMemset(p2_, 0, rows * 8));
-            CK(hipDeviceSynchronize());
-            const int tl = (n + 127) / 128;
-#define FG(G, label) do { const unsigned nb = ((unsigned)tl * (n - 2) + 8 * G - 1) / (8 * G) * (8 * G); double ms = time_ms([&] { hipLaunchKernelGGL((fused_grid<G>), dim3(nb), dim3(64), 0, 0, v, r_, x, p2_, x2_, y, n, tl, 1e-9, 0.999); }); printf("%-64s : %7.3f ms  %8.1f GB/s (88 B/row)\n", label, ms, rows * 88.0 / ms / 1e6); fflush(stdout); } while (0)
+#define LP(P, label) do { const int tl = (n + 127) / 128; const unsigned nb = ((unsigned)tl * (n - 2) + 31) & ~31u; RUN(label, hipLaunchKernelGGL((lds_grid_pol<P>), dim3(nb), dim3(64), 0, 0, v, x, y, n, tl)); } while (0)
             for (int rep = 0; rep < 2; ++rep) {
-                LG(128, false, 4, "grid 128 cols G=4 (SpMV alone, 56 B/row)");
-                FG(1, "fused SpMV + x/p update, G=1"); FG(2, "fused SpMV + x/p update, G=2"); FG(4, "fused SpMV + x/p update, G=4"); FG(8, "fused SpMV + x/p update, G=8");
-            }
+                LG(128, false, 4, "grid 128 cols G=4 (builtin nt loads)");
+                LP(0, "coefficient loads plain"); LP(1, "coefficient loads nt"); LP(2, "coefficient loads sc1"); LP(3, "coefficient loads sc0 sc1");
+                LP(4, "coefficient loads sc0 sc1 nt"); LP(5, "coefficient loads sc1 nt"); LP(6, "coefficient loads sc0"); LP(7, "coefficient loads sc0 nt");
             }
         }
     }
