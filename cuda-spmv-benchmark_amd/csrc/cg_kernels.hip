@@ -305,13 +305,16 @@ __global__ __launch_bounds__(kStream) void cg_init_residual_kernel(size_t n, con
 __global__ __launch_bounds__(kStream) void cg_update_r_kernel(size_t n, const CgScalars* __restrict__ s,
                                                              const double* __restrict__ Ap,
                                                              double* __restrict__ r,
-                                                             double* __restrict__ partials) {
+                                                             double* __restrict__ partials, int reverse) {
     if (s->converged) return;
     // alpha = rr_old / pAp from the (all-reduced) dot product: one IEEE division of two wave-uniform
     // scalars per thread, the same value the scalar step stores for the x update further down
     const double alpha = s->rr_old / s->pAp;
     double acc = 0.0;
-    SPMV_AMD_STREAM_LOOP(n) {
+    const unsigned block = reverse ? gridDim.x - 1 - blockIdx.x : blockIdx.x;  // logical workgroup
+    const size_t pairs = n >> 1;
+    const size_t i = (size_t)block * kStream + threadIdx.x;
+    if (i < pairs) {
         const d2 av = load_once(Ap, i);
         d2 rv = load_once(r, i);
         rv.x = fma(-alpha, av.x, rv.x);
@@ -320,12 +323,13 @@ __global__ __launch_bounds__(kStream) void cg_update_r_kernel(size_t n, const Cg
         acc = fma(rv.x, rv.x, acc);
         acc = fma(rv.y, rv.y, acc);
     }
-    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    if ((n & 1) && block == 0 && threadIdx.x == 0) {
         const double rv = fma(-alpha, Ap[n - 1], r[n - 1]);
         r[n - 1] = rv;
         acc = fma(rv, rv, acc);
     }
-    block_partial(acc, partials);
+    acc = wave_sum(acc);
+    if (threadIdx.x == 0) partials[block] = acc;
 }
 
 // x += alpha*p of iteration `iteration` and, unless that iteration converged, p = 1.0*r + beta*p, in
@@ -337,11 +341,15 @@ __global__ __launch_bounds__(kStream) void cg_update_r_kernel(size_t n, const Cg
 __global__ __launch_bounds__(kStream) void cg_update_px_kernel(size_t n, const CgScalars* __restrict__ s,
                                                               const double* __restrict__ r,
                                                               double* __restrict__ p,
-                                                              const double* x_in, double* x, int iteration) {
+                                                              const double* x_in, double* x, int iteration,
+                                                              int reverse) {
     if (s->iterations != iteration) return;
     const bool advance = s->converged == 0;
     const double alpha = s->alpha, beta = s->beta;
-    SPMV_AMD_STREAM_LOOP(n) {
+    const unsigned block = reverse ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
+    const size_t pairs = n >> 1;
+    const size_t i = (size_t)block * kStream + threadIdx.x;
+    if (i < pairs) {
         d2 pv = load_once(p, i);
         d2 xv = load_once(x_in, i);
         xv.x = fma(alpha, pv.x, xv.x);
@@ -355,7 +363,7 @@ __global__ __launch_bounds__(kStream) void cg_update_px_kernel(size_t n, const C
             reinterpret_cast<d2*>(p)[i] = pv;
         }
     }
-    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    if ((n & 1) && block == 0 && threadIdx.x == 0) {
         const double pv = p[n - 1];
         x[n - 1] = fma(alpha, pv, x_in[n - 1]);
         if (advance) p[n - 1] = fma(1.0, r[n - 1], beta * pv);
@@ -446,14 +454,15 @@ void launch_cg_init_residual(size_t n, const double* b, const double* Ap, double
 }
 
 void launch_cg_update_r(size_t n, const CgScalars* s, const double* Ap, double* r, double* partials,
-                        hipStream_t stream) {
-    hipLaunchKernelGGL(cg_update_r_kernel, dim3(stream_grid(n)), dim3(kStream), 0, stream, n, s, Ap, r, partials);
+                        hipStream_t stream, bool reverse) {
+    hipLaunchKernelGGL(cg_update_r_kernel, dim3(stream_grid(n)), dim3(kStream), 0, stream, n, s, Ap, r, partials,
+                       reverse ? 1 : 0);
 }
 
 void launch_cg_update_px(size_t n, const CgScalars* s, const double* r, double* p, const double* x_in,
-                         double* x, int iteration, hipStream_t stream) {
+                         double* x, int iteration, hipStream_t stream, bool reverse) {
     hipLaunchKernelGGL(cg_update_px_kernel, dim3(stream_grid(n)), dim3(kStream), 0, stream, n, s, r, p, x_in, x,
-                       iteration);
+                       iteration, reverse ? 1 : 0);
 }
 
 // Two launches by default. SPMV_AMD_REDUCE_ONE_LAUNCH=1 selects reduce_fused_kernel (same result bits):

@@ -63,6 +63,14 @@ struct SpmvAmdCgSlab {
     // changed a 16 ms solve at 50 M rows by < 0.5 %, so every launch is timed.
     std::vector<hipEvent_t> spmv_ev;
     int spmv_event_stride = 1;
+    // Sweep-direction alternation: consecutive streaming kernels of the loop walk the vectors in opposite
+    // directions, so each starts on the addresses its predecessor touched last and finds part of them in
+    // the 256 MiB Infinity Cache. Results and partial slots are independent of the direction. Measured on
+    // MI355X, whole solve: 50 M rows (the per-GPU slab of an 8-GPU run) 15.90 -> 15.60 ms, SpMV launches
+    // 0.520 -> 0.496 ms; 100 M rows -0.5 %, 200 M rows -0.8 %, 400 M rows unchanged. Making the producers'
+    // stores / consumers' loads plain instead of nontemporal did not raise the hit share (SPMV_AMD_PINGPONG=0
+    // switches the alternation off).
+    bool pingpong = true;
     int poll_sequence = 0;
     double last_spmv_ms = 0.0;
     int last_spmv_launches = 0;
@@ -97,6 +105,7 @@ void make_common(SpmvAmdCgSlab* s) {
     HIP_CHECK(hipMemset(s->p_alloc, 0, (lead + nl + (size_t)s->halo + 2) * sizeof(double)));
     s->shape = current_launch_shape();
     if (const char* v = getenv("SPMV_AMD_SPMV_EVENT_STRIDE")) s->spmv_event_stride = atoi(v);
+    if (const char* v = getenv("SPMV_AMD_PINGPONG")) s->pingpong = v[0] == '1';
     s->partials_blas = device_alloc<double>(dot_scratch_doubles(nl));
     s->reduce_stage = device_alloc<double>((size_t)reduce_stage_doubles());
     // both end in the ticket counter of the one-launch reduction, which starts at zero
@@ -338,6 +347,10 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
     std::vector<int> sampled_iteration;  // 0-based loop index of each timed SpMV
     bool done = false;
     while (!done && enqueued < config->max_iters) {
+        // SpMV and x/p update of iteration k walk one way, the r update between them the other way; the
+        // direction flips every iteration, so every kernel starts where the previous one ended
+        const bool backward = s->pingpong && (enqueued & 1) == 0;  // iteration 0 follows the forward initial-residual pass
+        s->shape.reverse = backward;
         if (detail) {
             timed(&stats->time_spmv_ms, nullptr, [&] { slab_spmv(s, true, halo_in_flight, skip); });
         } else {
@@ -358,7 +371,7 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
         }
         if (reduce) timed(&stats->time_allreduce_ms, nullptr, [&] { comm->allreduce_sum(&s->d_s->pAp, 1, s->compute); });
         timed(&stats->time_blas1_ms, &stats->time_axpy_update_r_ms, [&] {
-            launch_cg_update_r(nl, s->d_s, s->Ap, s->r, s->partials_blas, s->compute);
+            launch_cg_update_r(nl, s->d_s, s->Ap, s->r, s->partials_blas, s->compute, s->pingpong && !backward);
         });
         // the scalar step publishes {sequence, converged, iterations} straight into host-coherent pinned
         // memory: no copy command sits between it and the p update on the stream. Without an all-reduce
@@ -383,7 +396,7 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
         // p <- r + beta p, its halo exchange, and (when overlapping) nothing else before the host
         // looks at the status: the GPU works on these while the host waits for the record.
         timed(&stats->time_blas1_ms, &stats->time_axpby_update_p_ms, [&] {
-            launch_cg_update_px(nl, s->d_s, s->r, s->p, enqueued == 1 ? s->x0 : s->x, s->x, enqueued, s->compute);
+            launch_cg_update_px(nl, s->d_s, s->r, s->p, enqueued == 1 ? s->x0 : s->x, s->x, enqueued, s->compute, backward);
         });
         start_p_halo();
         wait_for_status(s);
@@ -395,6 +408,7 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
                    now.residual / now.b_norm, now.alpha);
         }
     }
+    s->shape.reverse = false;
     if (enqueued == 0)  // no iteration ran (max_iters == 0): the solution is the initial guess
         HIP_CHECK(hipMemcpyAsync(s->x, s->x0, vbytes, hipMemcpyDeviceToDevice, s->compute));
     total.end(s->compute);

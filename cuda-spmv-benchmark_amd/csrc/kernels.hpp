@@ -29,6 +29,9 @@ struct SlabCsr {
 struct LaunchShape {
     int compute_units = 256;
     int blocks_per_cu = 7;
+    // walk the tiles from the last to the first (row-lds kernel): results are identical, only the order in
+    // which addresses are touched changes (sweep direction alternation of the CG loop, cg_slab.hip)
+    bool reverse = false;
 };
 
 // ---- structure ----
@@ -119,13 +122,14 @@ void launch_check_convergence(const double* d_rr_new, double b_norm, double tol,
 void launch_cg_init_residual(size_t n, const double* b, const double* Ap, double* r, double* p,
                              double* partials, hipStream_t stream);
 // alpha = rr_old / pAp (per thread, from the scalars) ; r -= alpha Ap ; partials of r.r
+// reverse: workgroups walk the vectors from the end (same results, same partial slots).
 void launch_cg_update_r(size_t n, const CgScalars* s, const double* Ap, double* r, double* partials,
-                        hipStream_t stream);
+                        hipStream_t stream, bool reverse = false);
 // x += alpha p (the update of iteration `iteration`), then p = 1.0*r + beta*p unless that iteration
 // converged; one pass over p (axpy + axpby of cg_solver_mgpu_partitioned.cu:598,682 fused).
 // x = x_in + alpha p: x_in is x, or the stored initial guess in the first iteration of a solve.
 void launch_cg_update_px(size_t n, const CgScalars* s, const double* r, double* p, const double* x_in,
-                         double* x, int iteration, hipStream_t stream);
+                         double* x, int iteration, hipStream_t stream, bool reverse = false);
 int cg_partial_count(size_t n);  // partial slots written by the two reducing kernels above
 // *d_out = sum of partials[0..count) in a fixed order. `stage` (reduce_stage_doubles() doubles,
 // may be null; its LAST slot is a ticket counter and must be zero before the first use) lets

@@ -485,15 +485,16 @@ constexpr int kLdsTileCols = 128;
 template <bool kDot>
 __global__ __launch_bounds__(64) void stencil5_rowlds_kernel(
     SlabCsr m, const double* __restrict__ x, double* __restrict__ y, double alpha, int gi_lo,
-    int gfirst, int col_tiles, int total_tiles, int group, double* __restrict__ dot_partials,
+    int gfirst, int col_tiles, int total_tiles, int group, int reverse, double* __restrict__ dot_partials,
     const int* __restrict__ skip_flag) {
     __shared__ double strip[5 * kLdsTileCols];
     if (skip_flag != nullptr && *skip_flag != 0) return;
     const int lane = (int)threadIdx.x;
     const int b = (int)blockIdx.x;
     const int span = 8 * group;
-    const int tile = (b / span) * span + (b & 7) * group + ((b >> 3) % group);
+    int tile = (b / span) * span + (b & 7) * group + ((b >> 3) % group);
     if (tile >= total_tiles) return;
+    if (reverse) tile = total_tiles - 1 - tile;  // same tiles, same partial slots, walked from the end
     const int n = m.grid_size;
     const int row_group = tile / col_tiles;
     const int col_tile = tile - row_group * col_tiles;
@@ -1084,10 +1085,12 @@ int launch_stencil5_spmv(const SlabCsr& m, const double* x, double* y, double al
         const int gfirst = m.row_offset / n;
         if (dot)
             hipLaunchKernelGGL((stencil5_rowlds_kernel<true>), grid, dim3(64), 0, stream, m, x, y, alpha, p.gi_lo,
-                               gfirst, p.row_blocks, (int)tiles, p.rows_per_task, d_dot_partials, d_skip_flag);
+                               gfirst, p.row_blocks, (int)tiles, p.rows_per_task, shape.reverse ? 1 : 0, d_dot_partials,
+                               d_skip_flag);
         else
             hipLaunchKernelGGL((stencil5_rowlds_kernel<false>), grid, dim3(64), 0, stream, m, x, y, alpha, p.gi_lo,
-                               gfirst, p.row_blocks, (int)tiles, p.rows_per_task, d_dot_partials, d_skip_flag);
+                               gfirst, p.row_blocks, (int)tiles, p.rows_per_task, shape.reverse ? 1 : 0, d_dot_partials,
+                               d_skip_flag);
         return (int)tiles;
     }
 
