@@ -175,12 +175,13 @@ __global__ __launch_bounds__(kBlock) void reduce_slices_kernel(const double* __r
 
 // The CG scalar step (see cg_scalars_step_kernel below), callable from the tail of a reduction.
 __device__ __forceinline__ void cg_scalars_step(CgScalars* s, double tol, double* history, int* host_record,
-                                                int sequence) {
+                                                int sequence, double* alpha_ring, int ring_slots) {
     if (!s->converged) {
         s->alpha = s->rr_old / s->pAp;  // the alpha update_r used (same division), kept for the x update
         const double res = sqrt(s->rr_new);
         s->residual = res;
         s->iterations += 1;
+        if (alpha_ring != nullptr) alpha_ring[(s->iterations - 1) % ring_slots] = s->alpha;
         if (history != nullptr && s->iterations < s->max_history) history[s->iterations] = res;
         if (res / s->b_norm < tol) {
             s->converged = 1;
@@ -213,6 +214,8 @@ struct StepArgs {
     double* history;
     int* host_record;
     int sequence;
+    double* alpha_ring;
+    int ring_slots;
 };
 
 __global__ __launch_bounds__(kBlock) void reduce_fused_kernel(const double* __restrict__ partials, int count,
@@ -224,7 +227,8 @@ __global__ __launch_bounds__(kBlock) void reduce_fused_kernel(const double* __re
     if (skip_flag != nullptr && *skip_flag != 0) {
         // converged: nothing to sum, but a pending status record must still be published
         if (step.scalars != nullptr && blockIdx.x == 0 && threadIdx.x == 0)
-            cg_scalars_step(step.scalars, step.tol, step.history, step.host_record, step.sequence);
+            cg_scalars_step(step.scalars, step.tol, step.history, step.host_record, step.sequence, step.alpha_ring,
+                            step.ring_slots);
         return;
     }
     const int lo = blockIdx.x * slice;
@@ -256,7 +260,9 @@ __global__ __launch_bounds__(kBlock) void reduce_fused_kernel(const double* __re
     if (threadIdx.x == 0) {
         *out = s[0];
         __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
-        if (step.scalars != nullptr) cg_scalars_step(step.scalars, step.tol, step.history, step.host_record, step.sequence);
+        if (step.scalars != nullptr)
+            cg_scalars_step(step.scalars, step.tol, step.history, step.host_record, step.sequence, step.alpha_ring,
+                            step.ring_slots);
     }
 }
 
@@ -384,9 +390,77 @@ __global__ void cg_scalars_init_kernel(CgScalars* s, double* history) {
 // rr_new holds the (all-reduced) new r.r: stopping test (strict <, on ||r||/||r0||), iteration
 // count including the converging iteration, beta, rr_old <- rr_new (mgpu :652-676,716).
 __global__ void cg_scalars_step_kernel(CgScalars* s, double tol, double* history, int* host_record,
-                                       int sequence) {
+                                       int sequence, double* alpha_ring, int ring_slots) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    cg_scalars_step(s, tol, history, host_record, sequence);
+    cg_scalars_step(s, tol, history, host_record, sequence, alpha_ring, ring_slots);
+}
+
+// Direction update written out of place (deferred x update, cg_slab.hip): p_out = 1.0*r + beta*p_in.
+__global__ __launch_bounds__(kStream) void cg_update_p_ring_kernel(size_t n, const CgScalars* __restrict__ s,
+                                                                   const double* __restrict__ r,
+                                                                   const double* __restrict__ p_in,
+                                                                   double* __restrict__ p_out, int iteration,
+                                                                   int reverse) {
+    if (s->iterations != iteration || s->converged != 0) return;
+    const double beta = s->beta;
+    const unsigned block = reverse ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
+    const size_t pairs = n >> 1;
+    const size_t i = (size_t)block * kStream + threadIdx.x;
+    if (i < pairs) {
+        const d2 rv = load_once(r, i);
+        d2 pv = load_once(p_in, i);
+        pv.x = fma(1.0, rv.x, beta * pv.x);
+        pv.y = fma(1.0, rv.y, beta * pv.y);
+        reinterpret_cast<d2*>(p_out)[i] = pv;  // plain: the next SpMV's neighbour loads re-use these lines
+    }
+    if ((n & 1) && block == 0 && threadIdx.x == 0) p_out[n - 1] = fma(1.0, r[n - 1], beta * p_in[n - 1]);
+}
+
+// x = x_in + sum of alpha_j p_j over the ring window, one fma per term in iteration order: the chain
+// x <- fma(alpha_j, p_j, x) the per-iteration x updates evaluate (axpy_kernel, mgpu :598), read in one pass.
+__global__ __launch_bounds__(kStream) void cg_flush_x_kernel(size_t n, const double* __restrict__ alphas, RingSlots ring,
+                                                             int slots, int first_slot, int count,
+                                                             const double* x_in, double* x) {
+    const size_t pairs = n >> 1;
+    const size_t i = (size_t)blockIdx.x * kStream + threadIdx.x;
+    if (i < pairs) {
+        d2 xv = load_once(x_in, i);
+        int slot = first_slot;
+        int j = 0;
+        for (; j + 4 <= count; j += 4) {  // four directions in flight per lane
+            d2 pv[4];
+            double a[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int sl = (slot + u) % slots;
+                pv[u] = load_once(ring.p[sl], i);
+                a[u] = alphas[sl];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                xv.x = fma(a[u], pv[u].x, xv.x);
+                xv.y = fma(a[u], pv[u].y, xv.y);
+            }
+            slot = (slot + 4) % slots;
+        }
+        for (; j < count; ++j) {
+            const d2 pv = load_once(ring.p[slot], i);
+            const double a = alphas[slot];
+            xv.x = fma(a, pv.x, xv.x);
+            xv.y = fma(a, pv.y, xv.y);
+            slot = (slot + 1) % slots;
+        }
+        store_once(x, i, xv);
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        double xv = x_in[n - 1];
+        int slot = first_slot;
+        for (int j = 0; j < count; ++j) {
+            xv = fma(alphas[slot], ring.p[slot][n - 1], xv);
+            slot = (slot + 1) % slots;
+        }
+        x[n - 1] = xv;
+    }
 }
 
 inline unsigned stream_grid(size_t n) {
@@ -494,7 +568,7 @@ void launch_reduce_partials(const double* partials, int count, double* d_out, co
         }
         hipLaunchKernelGGL(reduce_fused_kernel, dim3(blocks), dim3(kBlock), 0, stream, partials, count, slice, stage,
                            reinterpret_cast<unsigned*>(stage + kReduceStageBlocks), d_out, d_skip_flag,
-                           StepArgs{nullptr, 0.0, nullptr, nullptr, 0});
+                           StepArgs{nullptr, 0.0, nullptr, nullptr, 0, nullptr, 0});
         return;
     }
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(kBlock), 0, stream, partials, count, d_out,
@@ -503,17 +577,17 @@ void launch_reduce_partials(const double* partials, int count, double* d_out, co
 
 void launch_reduce_partials_and_step(const double* partials, int count, double* d_out, const int* d_skip_flag,
                                      hipStream_t stream, double* stage, CgScalars* s, double tol, double* history,
-                                     int* host_record, int sequence) {
+                                     int* host_record, int sequence, double* alpha_ring, int ring_slots) {
     if (stage != nullptr && count > 4 * kBlock && !reduce_in_two_launches()) {
         const int slice = (count + kReduceStageBlocks - 1) / kReduceStageBlocks;
         const int blocks = (count + slice - 1) / slice;
         hipLaunchKernelGGL(reduce_fused_kernel, dim3(blocks), dim3(kBlock), 0, stream, partials, count, slice, stage,
                            reinterpret_cast<unsigned*>(stage + kReduceStageBlocks), d_out, d_skip_flag,
-                           StepArgs{s, tol, history, host_record, sequence});
+                           StepArgs{s, tol, history, host_record, sequence, alpha_ring, ring_slots});
         return;
     }
     launch_reduce_partials(partials, count, d_out, d_skip_flag, stream, stage);
-    launch_cg_scalars_step(s, tol, history, host_record, sequence, stream);
+    launch_cg_scalars_step(s, tol, history, host_record, sequence, stream, alpha_ring, ring_slots);
 }
 
 // stage values + one slot for the ticket counter, which must be ZERO before the first launch
@@ -524,9 +598,22 @@ void launch_cg_scalars_init(CgScalars* s, double* history, hipStream_t stream) {
 }
 
 void launch_cg_scalars_step(CgScalars* s, double tol, double* history, int* host_record, int sequence,
-                            hipStream_t stream) {
+                            hipStream_t stream, double* alpha_ring, int ring_slots) {
     hipLaunchKernelGGL(cg_scalars_step_kernel, dim3(1), dim3(1), 0, stream, s, tol, history, host_record,
-                       sequence);
+                       sequence, alpha_ring, ring_slots);
+}
+
+void launch_cg_update_p_ring(size_t n, const CgScalars* s, const double* r, const double* p_in, double* p_out,
+                             int iteration, hipStream_t stream, bool reverse) {
+    hipLaunchKernelGGL(cg_update_p_ring_kernel, dim3(stream_grid(n)), dim3(kStream), 0, stream, n, s, r, p_in, p_out,
+                       iteration, reverse ? 1 : 0);
+}
+
+void launch_cg_flush_x(size_t n, const double* alphas, const RingSlots& ring, int slots, int first_slot, int count,
+                       const double* x_in, double* x, hipStream_t stream) {
+    if (n == 0 || count <= 0) return;
+    hipLaunchKernelGGL(cg_flush_x_kernel, dim3(stream_grid(n)), dim3(kStream), 0, stream, n, alphas, ring, slots,
+                       first_slot, count, x_in, x);
 }
 
 }  // namespace spmv_amd

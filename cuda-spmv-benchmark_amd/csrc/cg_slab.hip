@@ -42,7 +42,17 @@ struct SpmvAmdCgSlab {
     DeviceCsr A;
     double *x = nullptr, *x0 = nullptr, *r = nullptr, *Ap = nullptr, *b = nullptr;
     double* p_alloc = nullptr;  // [pad | prev halo | local | next halo]
-    double* p = nullptr;        // local part, 16-byte aligned
+    double* p = nullptr;        // local part of the CURRENT direction vector, 16-byte aligned
+    // Direction ring (deferred x update). With ring_slots > 1 the direction update is written out of place into
+    // the next of ring_slots halo-carrying buffers, and x = x0 + sum alpha_k p_k is evaluated by one flush pass per
+    // ring_slots iterations (and at the end) instead of a read-modify-write of x in every iteration: the loop
+    // moves 56 + 24 + 24 B/row plus 8 B/row for the deferred re-read of p_k (+ 16/ring_slots for x) instead of
+    // 56 + 24 + 40. The fma chain per element of x is the same, in the same order. Costs ring_slots - 1 extra
+    // vectors of HBM (48 GB at 400 M rows and 16 slots, of 288 GB); ring_slots = 1 is the in-place form.
+    std::vector<double*> ring_alloc;  // allocations, ring_alloc[0] == p_alloc
+    std::vector<double*> ring;        // local parts
+    int ring_slots = 1;
+    double* d_alpha_ring = nullptr;
     double* partials_spmv = nullptr;  // dot partials of the SpMV launches (interior, head, tail back to back)
     double* partials_blas = nullptr;
     double* reduce_stage = nullptr;
@@ -100,9 +110,35 @@ void make_common(SpmvAmdCgSlab* s) {
     s->Ap = device_alloc<double>(nl);
     s->b = device_alloc<double>(nl);
     const size_t lead = ((size_t)s->halo + 1) & ~(size_t)1;  // keeps the local part 16-byte aligned
-    s->p_alloc = device_alloc<double>(lead + nl + (size_t)s->halo + 2);
+    const size_t slot_doubles = lead + nl + (size_t)s->halo + 2;
+    s->p_alloc = device_alloc<double>(slot_doubles);
     s->p = s->p_alloc + lead;
-    HIP_CHECK(hipMemset(s->p_alloc, 0, (lead + nl + (size_t)s->halo + 2) * sizeof(double)));
+    HIP_CHECK(hipMemset(s->p_alloc, 0, slot_doubles * sizeof(double)));
+    s->ring_alloc.assign(1, s->p_alloc);
+    s->ring.assign(1, s->p);
+    {
+        // as many direction buffers as fit comfortably (default 16, SPMV_AMD_P_RING=1 keeps the in-place update)
+        int want = kMaxRingSlots;
+        const char* forced = getenv("SPMV_AMD_P_RING");
+        if (forced) want = atoi(forced);
+        want = want < 1 ? 1 : (want > kMaxRingSlots ? kMaxRingSlots : want);
+        size_t free_b = 0, total_b = 0;
+        HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+        const size_t keep_free = (size_t)4 << 30;  // leave room for the caller's own buffers
+        const size_t per_slot = slot_doubles * sizeof(double);
+        const int asked = want;
+        while (want > 1 && (size_t)(want - 1) * per_slot + keep_free > free_b) --want;
+        if (want < asked && want < 4) want = 1;  // a ring cut short by memory flushes too often to pay
+        for (int k = 1; k < want; ++k) {
+            double* a = device_alloc<double>(slot_doubles);
+            HIP_CHECK(hipMemset(a, 0, slot_doubles * sizeof(double)));
+            s->ring_alloc.push_back(a);
+            s->ring.push_back(a + lead);
+        }
+        s->ring_slots = want;
+        s->d_alpha_ring = device_alloc<double>(kMaxRingSlots);
+        HIP_CHECK(hipMemset(s->d_alpha_ring, 0, kMaxRingSlots * sizeof(double)));
+    }
     s->shape = current_launch_shape();
     if (const char* v = getenv("SPMV_AMD_SPMV_EVENT_STRIDE")) s->spmv_event_stride = atoi(v);
     if (const char* v = getenv("SPMV_AMD_PINGPONG")) s->pingpong = v[0] == '1';
@@ -306,6 +342,12 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
         if (bucket2) *bucket2 += ms;
     };
 
+    s->p = s->ring[0];
+    const int slots = s->ring_slots;
+    RingSlots ring_view;
+    for (int k = 0; k < kMaxRingSlots; ++k) ring_view.p[k] = s->ring[(size_t)k % s->ring.size()];
+    int window_start = 0;  // first iteration whose alpha_k p_k is not in x yet (ring mode)
+
     comm->barrier();
     total.begin(s->compute);
 
@@ -383,21 +425,38 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
             });
             timed(&stats->time_allreduce_ms, nullptr, [&] { comm->allreduce_sum(&s->d_s->rr_new, 1, s->compute); });
             launch_cg_scalars_step(s->d_s, config->tolerance, s->d_hist, &s->h_poll->sequence, s->poll_sequence,
-                                   s->compute);
+                                   s->compute, s->d_alpha_ring, slots);
         } else {
             timed(&stats->time_reductions_ms, &stats->time_dot_rs_new_ms, [&] {
                 launch_reduce_partials_and_step(s->partials_blas, cg_partial_count(nl), &s->d_s->rr_new, skip, s->compute,
                                                 s->reduce_stage, s->d_s, config->tolerance, s->d_hist,
-                                                &s->h_poll->sequence, s->poll_sequence);
+                                                &s->h_poll->sequence, s->poll_sequence, s->d_alpha_ring, slots);
             });
         }
         ++enqueued;
 
         // p <- r + beta p, its halo exchange, and (when overlapping) nothing else before the host
         // looks at the status: the GPU works on these while the host waits for the record.
-        timed(&stats->time_blas1_ms, &stats->time_axpby_update_p_ms, [&] {
-            launch_cg_update_px(nl, s->d_s, s->r, s->p, enqueued == 1 ? s->x0 : s->x, s->x, enqueued, s->compute, backward);
-        });
+        if (slots == 1) {
+            timed(&stats->time_blas1_ms, &stats->time_axpby_update_p_ms, [&] {
+                launch_cg_update_px(nl, s->d_s, s->r, s->p, enqueued == 1 ? s->x0 : s->x, s->x, enqueued, s->compute, backward);
+            });
+        } else {
+            // the slot the new direction goes to still holds p of iteration enqueued - slots: fold the whole
+            // window into x first (alpha of this iteration is already on the stream: the step above wrote it)
+            if (enqueued - window_start == slots) {
+                timed(&stats->time_blas1_ms, nullptr, [&] {
+                    launch_cg_flush_x(nl, s->d_alpha_ring, ring_view, slots, window_start % slots, slots,
+                                      window_start == 0 ? s->x0 : s->x, s->x, s->compute);
+                });
+                window_start = enqueued;
+            }
+            double* p_next = s->ring[(size_t)(enqueued % slots)];
+            timed(&stats->time_blas1_ms, &stats->time_axpby_update_p_ms, [&] {
+                launch_cg_update_p_ring(nl, s->d_s, s->r, s->p, p_next, enqueued, s->compute, backward);
+            });
+            s->p = p_next;
+        }
         start_p_halo();
         wait_for_status(s);
         if (s->h_poll->converged) done = true;
@@ -409,6 +468,12 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
         }
     }
     s->shape.reverse = false;
+    if (slots > 1 && enqueued > window_start)  // x <- x + the directions of the last window
+        timed(&stats->time_blas1_ms, nullptr, [&] {
+            launch_cg_flush_x(nl, s->d_alpha_ring, ring_view, slots, window_start % slots, enqueued - window_start,
+                              window_start == 0 ? s->x0 : s->x, s->x, s->compute);
+        });
+    s->p = s->ring[0];
     if (enqueued == 0)  // no iteration ran (max_iters == 0): the solution is the initial guess
         HIP_CHECK(hipMemcpyAsync(s->x, s->x0, vbytes, hipMemcpyDeviceToDevice, s->compute));
     total.end(s->compute);
@@ -512,7 +577,9 @@ extern "C" void spmv_amd_cg_slab_destroy(SpmvAmdCgSlab* s) {
     device_release(s->r);
     device_release(s->Ap);
     device_release(s->b);
-    device_release(s->p_alloc);
+    for (double*& a : s->ring_alloc) device_release(a);
+    s->p_alloc = nullptr;
+    device_release(s->d_alpha_ring);
     device_release(s->partials_spmv);
     device_release(s->partials_blas);
     device_release(s->reduce_stage);

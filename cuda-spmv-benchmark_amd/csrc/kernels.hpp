@@ -130,6 +130,19 @@ void launch_cg_update_r(size_t n, const CgScalars* s, const double* Ap, double* 
 // x = x_in + alpha p: x_in is x, or the stored initial guess in the first iteration of a solve.
 void launch_cg_update_px(size_t n, const CgScalars* s, const double* r, double* p, const double* x_in,
                          double* x, int iteration, hipStream_t stream, bool reverse = false);
+// ---- deferred x update (cg_slab.hip, "direction ring") ----
+// p_out = 1.0*r + beta*p_in for iteration `iteration` unless it converged: the direction update written out
+// of place, so that p_in stays available for a later x update. Same per-element arithmetic as above.
+void launch_cg_update_p_ring(size_t n, const CgScalars* s, const double* r, const double* p_in, double* p_out,
+                             int iteration, hipStream_t stream, bool reverse = false);
+// x = x_in + sum_j alpha[slot_j] * p[slot_j], slot_j = (first_slot + j) % slots for j = 0..count-1, added in that
+// order with one fma each: element for element the x the per-iteration updates x += alpha_j p_j produce.
+constexpr int kMaxRingSlots = 16;
+struct RingSlots {
+    const double* p[kMaxRingSlots];
+};
+void launch_cg_flush_x(size_t n, const double* alphas, const RingSlots& ring, int slots, int first_slot, int count,
+                       const double* x_in, double* x, hipStream_t stream);
 int cg_partial_count(size_t n);  // partial slots written by the two reducing kernels above
 // *d_out = sum of partials[0..count) in a fixed order. `stage` (reduce_stage_doubles() doubles,
 // may be null; its LAST slot is a ticket counter and must be zero before the first use) lets
@@ -141,13 +154,14 @@ void launch_reduce_partials(const double* partials, int count, double* d_out,
 // (only valid when no all-reduce has to happen between the sum and the step).
 void launch_reduce_partials_and_step(const double* partials, int count, double* d_out, const int* d_skip_flag,
                                      hipStream_t stream, double* stage, CgScalars* s, double tol, double* history,
-                                     int* host_record, int sequence);
+                                     int* host_record, int sequence, double* alpha_ring = nullptr, int ring_slots = 0);
 // After the (all-reduced) r.r is known: b_norm (first call), residual, history, convergence
 // flag, beta, rr_old <- rr_new, iteration counter.
 void launch_cg_scalars_init(CgScalars* s, double* history, hipStream_t stream);
 // host_record (may be null): three ints in host-coherent pinned memory, {sequence, converged, iterations};
 // the kernel publishes the iteration's status there so the host needs no copy command on the stream.
+// alpha_ring (may be null): alpha of the iteration is also stored at alpha_ring[(iterations - 1) % ring_slots].
 void launch_cg_scalars_step(CgScalars* s, double tol, double* history, int* host_record, int sequence,
-                            hipStream_t stream);
+                            hipStream_t stream, double* alpha_ring = nullptr, int ring_slots = 0);
 
 }  // namespace spmv_amd

@@ -84,6 +84,38 @@ def test_slab_solver_single_rank(B, O, fresh_host_matrices, n):
     s2.destroy()
 
 
+@pytest.mark.parametrize("n,maxiter", [(81, 1000), (200, 1000), (200, 7), (64, 0), (130, 5)])
+def test_direction_ring_is_bit_identical_to_in_place_updates(B, O, fresh_host_matrices, monkeypatch, n, maxiter):
+    """Deferred x update: with any ring length the solver evaluates, element for element, the fma chain
+    x <- fma(alpha_k, p_k, x) of the per-iteration update (ring length 1), so x, the history and the iteration
+    count agree bit for bit -- through several wrap-arounds of short rings, with a non-zero x0, and when the
+    iteration limit cuts the solve short (window flushed at the limit)."""
+    rng = np.random.default_rng(n)
+    e = O.stencil5_coo(n)
+    b, x0 = rng.standard_normal(n * n), 0.1 * rng.standard_normal(n * n)
+    results = {}
+    for ring in (1, 2, 3, 4, 5, 16):
+        monkeypatch.setenv("SPMV_AMD_P_RING", str(ring))
+        B.lib().spmv_amd_reset_host_matrices()
+        m = B.HostMatrix(e, n * n, n * n, n)
+        slab = B.CgSlab.from_matrix(m)
+        slab.set_vectors(b, x0)
+        st = slab.solve(max_iters=maxiter)
+        results[ring] = (st.iterations, st.converged, slab.history().copy(), slab.gather().copy())
+        st2 = slab.solve(max_iters=maxiter)  # a second solve starts from x0 again, ring rewound
+        assert st2.iterations == st.iterations and np.array_equal(slab.gather(), results[ring][3])
+        slab.destroy()
+    it1, conv1, h1, x1 = results[1]
+    if maxiter == 0:
+        assert it1 == 0 and np.array_equal(x1, x0)
+    for ring, (it, conv, h, x) in results.items():
+        assert (it, conv) == (it1, conv1) and np.array_equal(h, h1) and np.array_equal(x, x1), ring
+    rp, ci, va = O.build_csr(e, n * n)
+    if maxiter == 1000:
+        xo, ho, ro = O.cg_partitioned(rp, ci, va, n, b, x0, world=1)
+        assert it1 == ro.iterations and hist_err(h1, ho) < TOL and np.max(np.abs(x1 - xo)) <= TOL * np.max(np.abs(xo))
+
+
 def test_reference_entry_point_cg_solve_mgpu_partitioned(B, O, fresh_host_matrices):
     import ctypes as C
     n = 100
