@@ -317,7 +317,7 @@ __global__ __launch_bounds__(64) void lds_grid_rows(const double* __restrict__ v
 // What would a CG iteration cost with the direction update folded into the SpMV? One pass that reads r, the old
 // p (both at the five stencil points) and x, and writes x += a p_old, p_new = r + b p_old (other buffer) and
 // Ap = A p_new: 88 B/row instead of 56 (SpMV) + 40 (x / p update) = 96 in two passes.
-template <int G>
+template <int G, bool WITHX = true>
 __global__ __launch_bounds__(64) void fused_grid(const double* __restrict__ v, const double* __restrict__ r,
                                                  const double* __restrict__ pold, double* __restrict__ pnew,
                                                  double* __restrict__ xv, double* __restrict__ y, int n, int tiles,
@@ -351,7 +351,7 @@ __global__ __launch_bounds__(64) void fused_grid(const double* __restrict__ v, c
             pe[h] = fma(1.0, rl[1], bta * pl[1]);
             pn[h] = fma(1.0, rl[-n], bta * pl[-n]);
             ps[h] = fma(1.0, rl[n], bta * pl[n]);
-            xo[h] = fma(a, p0, __builtin_nontemporal_load(xv + at));
+            if (WITHX) xo[h] = fma(a, p0, __builtin_nontemporal_load(xv + at));
         }
     }
 #pragma unroll
@@ -364,7 +364,7 @@ __global__ __launch_bounds__(64) void fused_grid(const double* __restrict__ v, c
         const double* q = lds + 5 * (lane + 64 * h);
         if (f[h]) {
             const long long at = (long long)gi * n + j0 + lane + 64 * h;
-            __builtin_nontemporal_store(xo[h], xv + at);
+            if (WITHX) __builtin_nontemporal_store(xo[h], xv + at);
             pnew[at] = pc[h];
             __builtin_nontemporal_store(row5(q[0], q[1], q[2], q[3], q[4], pw[h], pc[h], pe[h], pn[h], ps[h]), y + at);
         }
@@ -490,11 +490,18 @@ int main(int argc, char** argv) {
 #define LG(COLS, AL, PR, label) do { const int tl = (n + COLS - 1) / COLS; const unsigned nb = ((unsigned)tl * (n - 2) + 31) & ~31u; RUN(label, hipLaunchKernelGGL((lds_grid<COLS, AL, PR>), dim3(nb), dim3(64), 0, 0, v, x, y, n, tl)); } while (0)
         if (data == 1) {
 #define LF(COLS, G, label) do { const long long nt_ = ((long long)n * (n - 2)) / COLS; const unsigned nb = (unsigned)((nt_ + 8 * G - 1) / (8 * G) * (8 * G)); RUN(label, hipLaunchKernelGGL((lds_flat<COLS, G>), dim3(nb), dim3(64), 0, 0, v, x, y, n, nt_)); } while (0)
-#define LP(P, label) do { const int tl = (n + 127) / 128; const unsigned nb = ((unsigned)tl * (n - 2) + 31) & ~31u; RUN(label, hipLaunchKernelGGL((lds_grid_pol<P>), dim3(nb), dim3(64), 0, 0, v, x, y, n, tl)); } while (0)
+            {
+            double *r_, *p2_;
+            CK(hipMalloc(&r_, rows * 8)); CK(hipMalloc(&p2_, rows * 8));
+            hipLaunchKernelGGL(fill_pattern, dim3(blocks_for(rows, 256)), dim3(256), 0, 0, r_, rows, 2);
+            CK(hipMemset(p2_, 0, rows * 8));
+            CK(hipDeviceSynchronize());
+            const int tl = (n + 127) / 128;
+#define FG2(G, label) do { const unsigned nb = ((unsigned)tl * (n - 2) + 8 * G - 1) / (8 * G) * (8 * G); double ms = time_ms([&] { hipLaunchKernelGGL((fused_grid<G, false>), dim3(nb), dim3(64), 0, 0, v, r_, x, p2_, (double*)nullptr, y, n, tl, 1e-9, 0.999); }); printf("%-64s : %7.3f ms  %8.1f GB/s (72 B/row)\n", label, ms, rows * 72.0 / ms / 1e6); fflush(stdout); } while (0)
             for (int rep = 0; rep < 2; ++rep) {
-                LG(128, false, 4, "grid 128 cols G=4 (builtin nt loads)");
-                LP(0, "coefficient loads plain"); LP(1, "coefficient loads nt"); LP(2, "coefficient loads sc1"); LP(3, "coefficient loads sc0 sc1");
-                LP(4, "coefficient loads sc0 sc1 nt"); LP(5, "coefficient loads sc1 nt"); LP(6, "coefficient loads sc0"); LP(7, "coefficient loads sc0 nt");
+                LG(128, false, 4, "grid 128 cols G=4 (SpMV alone, 56 B/row)");
+                FG2(1, "fused SpMV + out-of-place p update, G=1"); FG2(2, "fused SpMV + out-of-place p update, G=2"); FG2(4, "fused SpMV + out-of-place p update, G=4"); FG2(8, "fused SpMV + out-of-place p update, G=8");
+            }
             }
         }
     }
