@@ -7,8 +7,9 @@ Workload (BASELINE.json metric "SpMV effective GB/s (fp64, 20k x 20k STENCIL5); 
 configuration of reference docs/PROBLEM_SIZE_SCALING_RESULTS.md:40-47, on N row slabs.
 
   step      one complete CG solve (14 iterations to tolerance), the unit the reference times;
-            inputs (slab CSR, b, x0) are resident in HBM before the timed region; each step
-            restores x <- x0 on the device first.
+            inputs (slab CSR, b, x0) are resident in HBM before the timed region; every step starts
+            from the stored x0 and ends with the solution x in HBM (the deferred x update's flush pass
+            is inside the solve).
   value     CG iterations per second, whole job = K * iterations / (max over ranks of the time
             of K steps, bracketed by barrier + torch.cuda.synchronize() on both sides).
   scaling   strong: the 400 M-unknown problem is fixed, slabs shrink as N grows.
