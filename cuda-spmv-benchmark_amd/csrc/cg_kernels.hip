@@ -427,21 +427,32 @@ __global__ __launch_bounds__(kStream) void cg_flush_x_kernel(size_t n, const dou
         d2 xv = load_once(x_in, i);
         int slot = first_slot;
         int j = 0;
-        for (; j + 4 <= count; j += 4) {  // four directions in flight per lane
-            d2 pv[4];
-            double a[4];
+        constexpr int kInFlight = 8;  // directions in flight per lane
+        for (; j + kInFlight <= count; j += kInFlight) {
+            d2 pv[kInFlight];
+            double a[kInFlight];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < kInFlight; ++u) {
                 const int sl = (slot + u) % slots;
                 pv[u] = load_once(ring.p[sl], i);
                 a[u] = alphas[sl];
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < kInFlight; ++u) {
                 xv.x = fma(a[u], pv[u].x, xv.x);
                 xv.y = fma(a[u], pv[u].y, xv.y);
             }
-            slot = (slot + 4) % slots;
+            slot = (slot + kInFlight) % slots;
+        }
+        for (; j + 2 <= count; j += 2) {
+            const int s1 = (slot + 1) % slots;
+            const d2 p0 = load_once(ring.p[slot], i), p1 = load_once(ring.p[s1], i);
+            const double a0 = alphas[slot], a1 = alphas[s1];
+            xv.x = fma(a0, p0.x, xv.x);
+            xv.y = fma(a0, p0.y, xv.y);
+            xv.x = fma(a1, p1.x, xv.x);
+            xv.y = fma(a1, p1.y, xv.y);
+            slot = (slot + 2) % slots;
         }
         for (; j < count; ++j) {
             const d2 pv = load_once(ring.p[slot], i);
