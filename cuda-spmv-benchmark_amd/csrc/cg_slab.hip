@@ -10,9 +10,12 @@
 //  * the direction vector p lives in ONE allocation [prev halo | local rows | next halo], so the
 //    +-grid_size neighbours of the first/last grid row are ordinary addresses and the slab kernel
 //    is the single-GPU wave-tile kernel with a row offset; RCCL receives straight into the halos;
-//  * SpMV is fused with the p.Ap partial sums; r -= a Ap carries the r.r partials; x += a p rides
-//    with the direction update p = r + b p (one pass over p instead of two);
-//    152 -> 120 bytes per row per iteration, element-wise results unchanged;
+//  * SpMV is fused with the p.Ap partial sums; r -= a Ap carries the r.r partials; the direction update
+//    p' = r + b p is written out of place into a ring of direction buffers and x = x0 + sum a_k p_k is
+//    evaluated by one flush pass per ring length (deferred x update; the in-place form, where x += a p
+//    rides with the direction update, remains for short rings);
+//    152 -> 113 bytes per row per iteration, element-wise results unchanged;
+//  * consecutive streaming kernels sweep the vectors in alternating directions (Infinity-Cache reuse);
 //  * scalars (alpha, beta, the norms, the convergence flag, the iteration counter) stay in HBM;
 //    kernels of iterations enqueued past convergence see the flag and return, so the host reads
 //    one 8-byte record per iteration while the GPU is already busy with the next SpMV;

@@ -491,17 +491,19 @@ int main(int argc, char** argv) {
         if (data == 1) {
 #define LF(COLS, G, label) do { const long long nt_ = ((long long)n * (n - 2)) / COLS; const unsigned nb = (unsigned)((nt_ + 8 * G - 1) / (8 * G) * (8 * G)); RUN(label, hipLaunchKernelGGL((lds_flat<COLS, G>), dim3(nb), dim3(64), 0, 0, v, x, y, n, nt_)); } while (0)
             {
-            double *r_, *p2_;
-            CK(hipMalloc(&r_, rows * 8)); CK(hipMalloc(&p2_, rows * 8));
-            hipLaunchKernelGGL(fill_pattern, dim3(blocks_for(rows, 256)), dim3(256), 0, 0, r_, rows, 2);
-            CK(hipMemset(p2_, 0, rows * 8));
-            CK(hipDeviceSynchronize());
-            const int tl = (n + 127) / 128;
-#define FG2(G, label) do { const unsigned nb = ((unsigned)tl * (n - 2) + 8 * G - 1) / (8 * G) * (8 * G); double ms = time_ms([&] { hipLaunchKernelGGL((fused_grid<G, false>), dim3(nb), dim3(64), 0, 0, v, r_, x, p2_, (double*)nullptr, y, n, tl, 1e-9, 0.999); }); printf("%-64s : %7.3f ms  %8.1f GB/s (72 B/row)\n", label, ms, rows * 72.0 / ms / 1e6); fflush(stdout); } while (0)
-            for (int rep = 0; rep < 2; ++rep) {
-                LG(128, false, 4, "grid 128 cols G=4 (SpMV alone, 56 B/row)");
-                FG2(1, "fused SpMV + out-of-place p update, G=1"); FG2(2, "fused SpMV + out-of-place p update, G=2"); FG2(4, "fused SpMV + out-of-place p update, G=4"); FG2(8, "fused SpMV + out-of-place p update, G=8");
-            }
+            // does the relative placement of the three arrays matter? x and y shifted inside larger allocations
+            double *xb, *yb;
+            const size_t slack = 64u << 20;
+            CK(hipMalloc(&xb, rows * 8 + slack)); CK(hipMalloc(&yb, rows * 8 + slack));
+            const int tl = (n + 127) / 128; const unsigned nb = ((unsigned)tl * (n - 2) + 31) & ~31u;
+            for (size_t xoff : {(size_t)0, (size_t)256, (size_t)1024, (size_t)4096, (size_t)16384, (size_t)65536, (size_t)(1u << 20), (size_t)(2u << 20), (size_t)(16u << 20)})
+                for (size_t yoff : {(size_t)0, (size_t)1024, (size_t)65536, (size_t)(1u << 20)}) {
+                    double* xs = xb + xoff / 8; double* ys = yb + yoff / 8;
+                    hipLaunchKernelGGL(fill_pattern, dim3(blocks_for(rows, 256)), dim3(256), 0, 0, xs, rows, 2);
+                    CK(hipDeviceSynchronize());
+                    double ms = time_ms([&] { hipLaunchKernelGGL((lds_grid<128, false, 4>), dim3(nb), dim3(64), 0, 0, v, xs, ys, n, tl); });
+                    printf("x offset %9zu B, y offset %8zu B : %7.3f ms\n", xoff, yoff, ms); fflush(stdout);
+                }
             }
         }
     }
