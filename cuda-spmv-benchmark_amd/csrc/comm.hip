@@ -60,6 +60,13 @@ struct RcclComm final : SpmvAmdComm {
     void allreduce_sum(double* d_buf, int count, hipStream_t stream) override {
         RCCL_CHECK(ncclAllReduce(d_buf, d_buf, (size_t)count, ncclDouble, ncclSum, coll, stream));
     }
+    bool loopback(const double* d_send, double* d_recv, int count, hipStream_t stream) override {
+        RCCL_CHECK(ncclGroupStart());
+        RCCL_CHECK(ncclSend(d_send, (size_t)count, ncclDouble, rank, p2p, stream));
+        RCCL_CHECK(ncclRecv(d_recv, (size_t)count, ncclDouble, rank, p2p, stream));
+        RCCL_CHECK(ncclGroupEnd());
+        return true;
+    }
     void gather_to_root(const double* d_local, int n_local, double* h_full, const int* counts,
                         const int* displs) override {
         hipStream_t s = nullptr;
@@ -261,6 +268,29 @@ extern "C" int spmv_amd_comm_selftest(SpmvAmdComm* comm) {
             if (comm->rank > 0 && h[2 * count + i] != (double)(comm->rank - 1)) bad = 1;
             if (comm->rank < comm->world - 1 && h[3 * count + i] != (double)(comm->rank + 1)) bad = 1;
         }
+    }
+    // the transport's point-to-point calls with this rank as its own peer, on a non-default stream while the
+    // default stream is busy: what a one-GPU box can run of the halo exchange's RCCL path
+    {
+        const int count = 20000;  // one halo row of the headline problem
+        std::vector<double> h((size_t)count);
+        for (int i = 0; i < count; ++i) h[(size_t)i] = 1000.0 * comm->rank + i;
+        double* a = device_alloc<double>((size_t)count);
+        double* b = device_alloc<double>((size_t)count);
+        HIP_CHECK(hipMemcpy(a, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemset(b, 0, h.size() * sizeof(double)));
+        hipStream_t side = nullptr;
+        HIP_CHECK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+        if (comm->loopback(a, b, count, side)) {
+            HIP_CHECK(hipStreamSynchronize(side));
+            std::vector<double> back((size_t)count);
+            HIP_CHECK(hipMemcpy(back.data(), b, back.size() * sizeof(double), hipMemcpyDeviceToHost));
+            for (int i = 0; i < count; ++i)
+                if (back[(size_t)i] != h[(size_t)i]) bad = 1;
+        }
+        HIP_CHECK(hipStreamDestroy(side));
+        device_release(a);
+        device_release(b);
     }
     comm->barrier();
     return bad;

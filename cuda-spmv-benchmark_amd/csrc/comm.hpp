@@ -37,6 +37,10 @@ struct SpmvAmdComm {
                                 const int* counts, const int* displs) = 0;
     virtual void barrier() = 0;
     virtual const char* transport() const = 0;
+    // Self-test aid: moves `count` device doubles from d_send to d_recv through the transport's own
+    // point-to-point path with this rank as its own peer (RCCL: ncclSend + ncclRecv to self in one group),
+    // so a one-GPU box runs the send / recv calls the halo exchange is made of. False = not supported.
+    virtual bool loopback(const double*, double*, int, hipStream_t) { return false; }
 };
 
 namespace spmv_amd {
