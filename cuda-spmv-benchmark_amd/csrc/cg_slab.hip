@@ -93,17 +93,27 @@ namespace {
 
 void make_common(SpmvAmdCgSlab* s) {
     const size_t nl = (size_t)s->n_local;
-    s->has_prev = s->comm->rank > 0;
-    s->has_next = s->comm->rank < s->comm->world - 1;
-    s->halo = (s->comm->world > 1) ? s->grid : 0;
+    s->has_prev = s->comm->rank > 0 || s->comm->self_neighbour;
+    s->has_next = s->comm->rank < s->comm->world - 1 || s->comm->self_neighbour;
+    s->halo = s->comm->exchanges_halos() ? s->grid : 0;
     s->A.view.halo_before = s->has_prev ? s->halo : 0;
     s->A.view.halo_after = s->has_next ? s->halo : 0;
     HIP_CHECK(hipStreamCreateWithFlags(&s->compute, hipStreamNonBlocking));
     {
-        // the halo exchange must get CUs while the interior SpMV saturates the chip: highest priority
-        int least = 0, greatest = 0;
-        HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        HIP_CHECK(hipStreamCreateWithPriority(&s->side, hipStreamNonBlocking, greatest));
+        // The side stream has the DEFAULT priority. A highest-priority side stream (so that the halo exchange
+        // gets CUs at once while the interior SpMV saturates the chip) was measured with the rank as its own
+        // neighbour (SPMV_AMD_SELF_NEIGHBOUR=1, 50 M rows): every kernel of the normal-priority compute stream
+        // slows down while such a queue exists -- SpMV 0.50 -> 0.66 ms, 5 us kernels -> 50 us, a solve
+        // 15.7 -> 25.3 ms -- whether the exchange is RCCL send/recv or a plain copy. At equal priority the
+        // exchange kernel starts 50-90 us into the interior SpMV and ends long before it (rocprofv3 trace).
+        const char* pr = getenv("SPMV_AMD_SIDE_PRIORITY");  // "high" re-creates the measured configuration
+        if (pr && pr[0] == 'h') {
+            int least = 0, greatest = 0;
+            HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+            HIP_CHECK(hipStreamCreateWithPriority(&s->side, hipStreamNonBlocking, greatest));
+        } else {
+            HIP_CHECK(hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking));
+        }
     }
     HIP_CHECK(hipEventCreateWithFlags(&s->ev_p_ready, hipEventDisableTiming));
     HIP_CHECK(hipEventCreateWithFlags(&s->ev_halo_done, hipEventDisableTiming));
@@ -179,7 +189,7 @@ void make_common(SpmvAmdCgSlab* s) {
 }
 
 bool partition_ok(const SpmvAmdComm* comm, int n, int grid, int n_local) {
-    if (comm->world == 1) return true;
+    if (!comm->exchanges_halos()) return true;
     if (grid <= 0) {
         fprintf(stderr, "[cg-slab] multi-GPU solve needs a stencil matrix (grid_size > 0)\n");
         return false;
@@ -213,12 +223,20 @@ void slab_spmv(SpmvAmdCgSlab* s, bool with_dot, bool overlap, const int* skip,
         used = launch_stencil5_spmv(A, s->p, s->Ap, 1.0, lo, hi, part, skip, Stencil5Variant::Auto,
                                     s->shape, s->compute);
         HIP_CHECK(hipStreamWaitEvent(s->compute, s->ev_halo_done, 0));
-        if (lo > 0)
-            used += launch_stencil5_spmv(A, s->p, s->Ap, 1.0, 0, lo, part ? part + used : nullptr, skip,
-                                         Stencil5Variant::Auto, s->shape, s->compute);
-        if (hi < s->n_local)
-            used += launch_stencil5_spmv(A, s->p, s->Ap, 1.0, hi, s->n_local, part ? part + used : nullptr,
-                                         skip, Stencil5Variant::Auto, s->shape, s->compute);
+        if (lo > 0 && hi < s->n_local && lo == A.grid_size && s->n_local - hi == A.grid_size) {
+            // a rank with two neighbours: its first and last grid row in one launch
+            LaunchShape forward = s->shape;
+            forward.reverse = false;
+            used += launch_stencil5_spmv_first_and_last_gridrow(A, s->p, s->Ap, 1.0, part ? part + used : nullptr, skip,
+                                                                forward, s->compute);
+        } else {
+            if (lo > 0)
+                used += launch_stencil5_spmv(A, s->p, s->Ap, 1.0, 0, lo, part ? part + used : nullptr, skip,
+                                             Stencil5Variant::Auto, s->shape, s->compute);
+            if (hi < s->n_local)
+                used += launch_stencil5_spmv(A, s->p, s->Ap, 1.0, hi, s->n_local, part ? part + used : nullptr,
+                                             skip, Stencil5Variant::Auto, s->shape, s->compute);
+        }
     }
     if (spmv_done) HIP_CHECK(hipEventRecord(spmv_done, s->compute));
     if (with_dot) {
@@ -247,7 +265,7 @@ void wait_for_status(SpmvAmdCgSlab* s) {
 }
 
 void exchange_p_halo(SpmvAmdCgSlab* s, hipStream_t stream) {
-    if (s->comm->world == 1) return;
+    if (!s->comm->exchanges_halos()) return;
     s->comm->halo_exchange(s->p, s->p + (s->n_local - s->halo), s->p - s->halo, s->p + s->n_local,
                            s->halo, stream);
 }
@@ -311,7 +329,7 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
     const bool detail = config->enable_detailed_timers != 0;
     const int* skip = &s->d_s->converged;
     SpmvAmdComm* comm = s->comm;
-    const bool multi = comm->world > 1;       // halo exchange needed
+    const bool multi = comm->exchanges_halos();  // halo exchange needed
     const bool reduce = comm->collective();   // all-reduce of the dot products needed
     memset(stats, 0, sizeof(*stats));
 
@@ -374,7 +392,9 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
     bool halo_in_flight = false;
     auto start_p_halo = [&] {  // halo rows of the new p: side stream, under the interior SpMV
         if (!multi) return;
-        if (detail) {
+        // SPMV_AMD_NO_OVERLAP=1: exchange on the compute stream, for A/B runs of the overlap
+        static const bool no_overlap = [] { const char* v = getenv("SPMV_AMD_NO_OVERLAP"); return v && v[0] == '1'; }();
+        if (detail || no_overlap) {
             timed(&stats->time_allgather_ms, nullptr, [&] { exchange_p_halo(s, s->compute); });
             halo_in_flight = false;
             return;
@@ -537,8 +557,10 @@ extern "C" int spmv_amd_cg_slab_history(SpmvAmdCgSlab* s, double* out, int cap) 
 
 extern "C" int spmv_amd_cg_slab_spmv(SpmvAmdCgSlab* s, const double* x_full, double* y_local) {
     upload(s->p, x_full + s->row_offset, (size_t)s->n_local);
-    if (s->has_prev) upload(s->p - s->halo, x_full + s->row_offset - s->halo, (size_t)s->halo);
-    if (s->has_next) upload(s->p + s->n_local, x_full + s->row_offset + s->n_local, (size_t)s->halo);
+    if (s->has_prev && s->row_offset >= s->halo)
+        upload(s->p - s->halo, x_full + s->row_offset - s->halo, (size_t)s->halo);
+    if (s->has_next && s->row_offset + s->n_local + s->halo <= s->n)
+        upload(s->p + s->n_local, x_full + s->row_offset + s->n_local, (size_t)s->halo);
     slab_spmv(s, /*with_dot=*/false, /*overlap=*/false, nullptr);
     HIP_CHECK(hipStreamSynchronize(s->compute));
     HIP_CHECK(hipGetLastError());

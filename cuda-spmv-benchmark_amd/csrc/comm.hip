@@ -45,15 +45,16 @@ struct RcclComm final : SpmvAmdComm {
     }
     void halo_exchange(const double* d_send_prev, const double* d_send_next, double* d_recv_prev,
                        double* d_recv_next, int count, hipStream_t stream) override {
-        if (world == 1) return;
+        if (!exchanges_halos()) return;
+        const int prev = self_neighbour ? rank : rank - 1, next = self_neighbour ? rank : rank + 1;
         RCCL_CHECK(ncclGroupStart());
-        if (rank > 0) {
-            RCCL_CHECK(ncclSend(d_send_prev, (size_t)count, ncclDouble, rank - 1, p2p, stream));
-            RCCL_CHECK(ncclRecv(d_recv_prev, (size_t)count, ncclDouble, rank - 1, p2p, stream));
+        if (self_neighbour || rank > 0) {
+            RCCL_CHECK(ncclSend(d_send_prev, (size_t)count, ncclDouble, prev, p2p, stream));
+            RCCL_CHECK(ncclRecv(d_recv_prev, (size_t)count, ncclDouble, prev, p2p, stream));
         }
-        if (rank < world - 1) {
-            RCCL_CHECK(ncclSend(d_send_next, (size_t)count, ncclDouble, rank + 1, p2p, stream));
-            RCCL_CHECK(ncclRecv(d_recv_next, (size_t)count, ncclDouble, rank + 1, p2p, stream));
+        if (self_neighbour || rank < world - 1) {
+            RCCL_CHECK(ncclSend(d_send_next, (size_t)count, ncclDouble, next, p2p, stream));
+            RCCL_CHECK(ncclRecv(d_recv_next, (size_t)count, ncclDouble, next, p2p, stream));
         }
         RCCL_CHECK(ncclGroupEnd());
     }
@@ -199,6 +200,8 @@ extern "C" SpmvAmdComm* spmv_amd_comm_create_rccl(int rank, int world, const voi
     c->world = world;
     const char* force = getenv("SPMV_AMD_FORCE_COLLECTIVES");
     c->force_collectives = force != nullptr && force[0] == '1';
+    const char* self_nb = getenv("SPMV_AMD_SELF_NEIGHBOUR");
+    c->self_neighbour = world == 1 && self_nb != nullptr && self_nb[0] == '1';
     {
         // Creation failures are reported to the caller (NULL), who may choose another transport;
         // failures later, inside a solve, end the process like every HIP error does.

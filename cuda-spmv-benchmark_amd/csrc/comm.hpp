@@ -24,6 +24,13 @@ struct SpmvAmdComm {
     // 1-GPU box drives the RCCL calls of the CG loop; a 1-rank all-reduce is the identity.
     bool force_collectives = false;
     bool collective() const { return world > 1 || force_collectives; }
+    // Test hook (SPMV_AMD_SELF_NEIGHBOUR=1, one RCCL rank): the rank is its own previous and next neighbour.
+    // The solver then runs the whole multi-rank pipeline -- halo-carrying buffers, send / recv on the side
+    // stream under the interior SpMV, event waits, split SpMV launches -- on one GPU. The rows that would
+    // read the halos are the first and last grid row of the GLOBAL grid, which have no north / south entry,
+    // so the received values are never used and the solve must reproduce the plain single-rank result.
+    bool self_neighbour = false;
+    bool exchanges_halos() const { return world > 1 || self_neighbour; }
     virtual ~SpmvAmdComm() {}
     // Exchanges `count` doubles with rank-1 (send_prev/recv_prev) and rank+1 (send_next/recv_next);
     // pointers are device pointers, NULL where there is no neighbour. Ordered on `stream`.

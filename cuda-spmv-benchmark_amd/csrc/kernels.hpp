@@ -62,6 +62,12 @@ int launch_stencil5_spmv(const SlabCsr& m, const double* x, double* y, double al
                           const int* d_skip_flag, Stencil5Variant variant,
                           const LaunchShape& shape, hipStream_t stream);
 
+// The first and the last grid row of a slab made of whole grid rows (the rows that wait for the halos), in one
+// launch where the row-lds kernel applies, in two otherwise. Partial slots: first grid row's, then last grid row's.
+int launch_stencil5_spmv_first_and_last_gridrow(const SlabCsr& m, const double* x, double* y, double alpha,
+                                                double* d_dot_partials, const int* d_skip_flag,
+                                                const LaunchShape& shape, hipStream_t stream);
+
 // ---- CSR SpMV ----
 enum class CsrVariant { Auto, Stream, RowScalar, Wavefront, SubWave4, SubWave8, SubWave16, SubWave32 };
 CsrVariant csr_auto_variant(const SlabCsr& m);

@@ -484,7 +484,7 @@ constexpr int kLdsTileCols = 128;
 
 template <bool kDot>
 __global__ __launch_bounds__(64) void stencil5_rowlds_kernel(
-    SlabCsr m, const double* __restrict__ x, double* __restrict__ y, double alpha, int gi_lo,
+    SlabCsr m, const double* __restrict__ x, double* __restrict__ y, double alpha, int gi_lo, int row_step,
     int gfirst, int col_tiles, int total_tiles, int group, int reverse, double* __restrict__ dot_partials,
     const int* __restrict__ skip_flag) {
     __shared__ double strip[5 * kLdsTileCols];
@@ -498,7 +498,7 @@ __global__ __launch_bounds__(64) void stencil5_rowlds_kernel(
     const int n = m.grid_size;
     const int row_group = tile / col_tiles;
     const int col_tile = tile - row_group * col_tiles;
-    const int li = gi_lo + row_group;  // local grid row
+    const int li = gi_lo + row_group * row_step;  // local grid row (row_step > 1: a launch over separate grid rows)
     const int gi = gfirst + li;        // global grid row
     const int j0 = col_tile * kLdsTileCols;
     double dot_acc = 0.0;
@@ -1084,11 +1084,11 @@ int launch_stencil5_spmv(const SlabCsr& m, const double* x, double* y, double al
         const dim3 grid((unsigned)((tiles + span - 1) / span * span));
         const int gfirst = m.row_offset / n;
         if (dot)
-            hipLaunchKernelGGL((stencil5_rowlds_kernel<true>), grid, dim3(64), 0, stream, m, x, y, alpha, p.gi_lo,
+            hipLaunchKernelGGL((stencil5_rowlds_kernel<true>), grid, dim3(64), 0, stream, m, x, y, alpha, p.gi_lo, 1,
                                gfirst, p.row_blocks, (int)tiles, p.rows_per_task, shape.reverse ? 1 : 0, d_dot_partials,
                                d_skip_flag);
         else
-            hipLaunchKernelGGL((stencil5_rowlds_kernel<false>), grid, dim3(64), 0, stream, m, x, y, alpha, p.gi_lo,
+            hipLaunchKernelGGL((stencil5_rowlds_kernel<false>), grid, dim3(64), 0, stream, m, x, y, alpha, p.gi_lo, 1,
                                gfirst, p.row_blocks, (int)tiles, p.rows_per_task, shape.reverse ? 1 : 0, d_dot_partials,
                                d_skip_flag);
         return (int)tiles;
@@ -1138,6 +1138,34 @@ int launch_stencil5_spmv(const SlabCsr& m, const double* x, double* y, double al
     if (p.head_rows) used += launch_rows(first_row, first_row + n, dot ? d_dot_partials + used : nullptr);
     if (p.tail_rows) used += launch_rows(last_row - n, last_row, dot ? d_dot_partials + used : nullptr);
     return used;
+}
+
+int launch_stencil5_spmv_first_and_last_gridrow(const SlabCsr& m, const double* x, double* y, double alpha,
+                                                double* d_dot_partials, const int* d_skip_flag,
+                                                const LaunchShape& shape, hipStream_t stream) {
+    const int n = m.grid_size;
+    const int local_gridrows = n > 0 ? m.n_local / n : 0;
+    const Stencil5Plan head = plan_stencil5(m, 0, n > 0 ? n : 0, Stencil5Variant::Auto, shape);
+    if (n <= 0 || local_gridrows < 2 || head.variant != Stencil5Variant::RowLds) {
+        // two launches over the two row ranges (any variant)
+        int used = launch_stencil5_spmv(m, x, y, alpha, 0, n, d_dot_partials, d_skip_flag, Stencil5Variant::Auto, shape, stream);
+        used += launch_stencil5_spmv(m, x, y, alpha, m.n_local - n, m.n_local, d_dot_partials ? d_dot_partials + used : nullptr,
+                                     d_skip_flag, Stencil5Variant::Auto, shape, stream);
+        return used;
+    }
+    // one launch: row group 0 is local grid row 0, row group 1 is the last local grid row; the partial slots
+    // are those of the two separate launches back to back
+    const int tiles = 2 * head.row_blocks;
+    const int span = 8 * head.rows_per_task;
+    const dim3 grid((unsigned)((tiles + span - 1) / span * span));
+    const int gfirst = m.row_offset / n;
+    if (d_dot_partials)
+        hipLaunchKernelGGL((stencil5_rowlds_kernel<true>), grid, dim3(64), 0, stream, m, x, y, alpha, 0, local_gridrows - 1,
+                           gfirst, head.row_blocks, tiles, head.rows_per_task, 0, d_dot_partials, d_skip_flag);
+    else
+        hipLaunchKernelGGL((stencil5_rowlds_kernel<false>), grid, dim3(64), 0, stream, m, x, y, alpha, 0, local_gridrows - 1,
+                           gfirst, head.row_blocks, tiles, head.rows_per_task, 0, d_dot_partials, d_skip_flag);
+    return tiles;
 }
 
 // Measured on MI355X, 10 000^2 stencil as CSR (5 nnz/row): stream 1.37 ms (4 entries per thread,

@@ -97,6 +97,32 @@ def test_bench_distributed_path_with_one_rank():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("grid", [640, 200])
+def test_multi_rank_pipeline_over_rccl_with_the_rank_as_its_own_neighbour(grid):
+    """SPMV_AMD_SELF_NEIGHBOUR=1: one RCCL rank that is its own previous and next neighbour. The solver runs the
+    complete multi-rank pipeline on this one GPU -- ncclSend / ncclRecv of the halo rows on the side stream under
+    the interior SpMV, the event waits, the split SpMV launches, ncclAllReduce of both dot products -- and, because
+    the first and last grid row of the global grid have no north / south entry, must reproduce the plain solve
+    (the split launches change the order of the dot partials, hence 1e-10 rather than bit equality)."""
+    import json
+    env = dict(os.environ, SPMV_AMD_BENCH_FORCE_DIST="1", SPMV_AMD_FORCE_COLLECTIVES="1", SPMV_AMD_SELF_NEIGHBOUR="1",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+           "--grid", str(grid), "--no-cpu-baseline", "--no-spmv"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    nb = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    plain = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--grid", str(grid),
+                            "--no-cpu-baseline", "--no-spmv"], capture_output=True, text=True, timeout=600)
+    assert plain.returncode == 0, plain.stdout + plain.stderr
+    one = json.loads([l for l in plain.stdout.splitlines() if l.startswith("{")][-1])
+    assert nb["config"]["transport"] == "rccl" and nb["config"]["converged"]
+    assert nb["config"]["iterations_per_solve"] == one["config"]["iterations_per_solve"]
+    assert hist_err(np.array(nb["config"]["residual_history"]), np.array(one["config"]["residual_history"])) < 1e-10
+
+
+@pytest.mark.gpu
 def test_bench_two_ranks_control_flow_on_one_gpu():
     """bench.py --gpus 2 under torch.distributed.run with both ranks pinned to the box's only GPU:
     RCCL refuses two ranks on one device, every rank agrees (over gloo) to switch to the staged
