@@ -39,9 +39,11 @@ struct SelfComm final : SpmvAmdComm {
 struct RcclComm final : SpmvAmdComm {
     ncclComm_t p2p = nullptr;   // halo rows
     ncclComm_t coll = nullptr;  // all-reduce, gather
+    double* d_barrier = nullptr;  // one zero, summed over the ranks by barrier()
     ~RcclComm() override {
         if (p2p) ncclCommDestroy(p2p);
         if (coll) ncclCommDestroy(coll);
+        if (d_barrier) (void)hipFree(d_barrier);
     }
     void halo_exchange(const double* d_send_prev, const double* d_send_next, double* d_recv_prev,
                        double* d_recv_next, int count, hipStream_t stream) override {
@@ -90,11 +92,13 @@ struct RcclComm final : SpmvAmdComm {
         }
     }
     void barrier() override {
-        double* d = device_alloc<double>(1);
-        HIP_CHECK(hipMemset(d, 0, sizeof(double)));
-        RCCL_CHECK(ncclAllReduce(d, d, 1, ncclDouble, ncclSum, coll, nullptr));
+        // the solver calls this before every timed region: no allocation, one 8-byte all-reduce of zeros
+        if (d_barrier == nullptr) {
+            d_barrier = device_alloc<double>(1);
+            HIP_CHECK(hipMemset(d_barrier, 0, sizeof(double)));
+        }
+        RCCL_CHECK(ncclAllReduce(d_barrier, d_barrier, 1, ncclDouble, ncclSum, coll, nullptr));
         HIP_CHECK(hipStreamSynchronize(nullptr));
-        device_release(d);
     }
     const char* transport() const override { return "rccl"; }
 };
