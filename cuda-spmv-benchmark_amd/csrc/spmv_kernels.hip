@@ -662,13 +662,13 @@ __global__ __launch_bounds__(kBlock) void csr_row_scalar_kernel(SlabCsr m, const
 // thread-per-row loop instead. This is the shape of the "stream" half of CSR-adaptive
 // (Greathouse & Daga, SC'14), without a preprocessing pass: the row count per block is fixed per
 // matrix from its mean row length.
-constexpr int kCsrStreamPerThread = 4;                         // entries each thread fetches in phase 1
-constexpr int kCsrStreamCap = kBlock * kCsrStreamPerThread;    // 1024 entries: 16 KiB of LDS, 8 blocks per CU
-
-template <bool kNtLoad, bool kNtStore>
-__global__ __launch_bounds__(kBlock) void csr_stream_kernel(SlabCsr m, const double* __restrict__ x,
-                                                            double* __restrict__ y, double alpha,
-                                                            int rows_per_block) {
+// kThreads threads fetch kPerThread entries each in phase 1 (LDS: 16 B per entry).
+template <int kThreads, int kPerThread>
+__global__ __launch_bounds__(kThreads) void csr_stream_kernel(SlabCsr m, const double* __restrict__ x,
+                                                              double* __restrict__ y, double alpha,
+                                                              int rows_per_block) {
+    constexpr int kCsrStreamCap = kThreads * kPerThread;
+    constexpr int kCsrStreamPerThread = kPerThread;
     __shared__ double sv[kCsrStreamCap];
     __shared__ double sx[kCsrStreamCap];
     const int lo = -m.halo_before, hi = m.n_local + m.halo_after;
@@ -688,25 +688,25 @@ __global__ __launch_bounds__(kBlock) void csr_stream_kernel(SlabCsr m, const dou
         double v[kCsrStreamPerThread], xv[kCsrStreamPerThread];
 #pragma unroll
         for (int u = 0; u < kCsrStreamPerThread; ++u) {
-            const int e = kb + (int)threadIdx.x + u * kBlock;
+            const int e = kb + (int)threadIdx.x + u * kThreads;
             const bool live = e < ke;
-            // the span is read once per SpMV, fully coalesced: nontemporal
-            c[u] = !live ? m.row_offset : kNtLoad ? __builtin_nontemporal_load(m.col_idx + e) : m.col_idx[e];
-            v[u] = !live ? 0.0 : kNtLoad ? __builtin_nontemporal_load(m.values + e) : m.values[e];
+            // plain loads: nontemporal ones measured 9 % slower here (block spans are not line-aligned and
+            // neighbouring blocks share their edge lines; profiles/r01_csr_ell_nt_ab.txt)
+            c[u] = live ? m.col_idx[e] : m.row_offset;
+            v[u] = live ? m.values[e] : 0.0;
         }
 #pragma unroll
         for (int u = 0; u < kCsrStreamPerThread; ++u) xv[u] = x_at(x, (long long)c[u] - m.row_offset, lo, hi);
 #pragma unroll
         for (int u = 0; u < kCsrStreamPerThread; ++u) {
-            sv[threadIdx.x + u * kBlock] = v[u];
-            sx[threadIdx.x + u * kBlock] = xv[u];
+            sv[threadIdx.x + u * kThreads] = v[u];
+            sx[threadIdx.x + u * kThreads] = xv[u];
         }
         __syncthreads();
         if (has_row) {
             double sum = 0.0;
             for (int k = k0 - kb; k < k1 - kb; ++k) sum = fma(sv[k], sx[k], sum);
-            if (kNtStore) __builtin_nontemporal_store(alpha * sum, y + row);
-            else y[row] = alpha * sum;
+            y[row] = alpha * sum;
         }
     } else if (has_row) {
         double sum = 0.0;
@@ -1193,22 +1193,22 @@ void launch_csr_spmv(const SlabCsr& m, const double* x, double* y, double alpha,
     const long long rows = m.n_local;
     switch (variant) {
         case CsrVariant::Stream: {
-            // rows per block: the mean span should fill about 80 % of the LDS strip, at most one row per thread
+            // rows per block: the mean span should fill about 90 % of the LDS strip, at most one row per thread
             const double avg = rows > 0 ? (double)m.nnz_local / rows : 1.0;
-            int per_block = (int)(0.9 * kCsrStreamCap / (avg > 1.0 ? avg : 1.0));
-            per_block = per_block > kBlock ? kBlock : (per_block < 16 ? 16 : per_block & ~15);
+            const int shape = env_int("SPMV_AMD_CSR_STREAM_SHAPE", 0);  // 0: 256 x 4, 1: 64 x 6, 2: 64 x 8, 3: 128 x 5
+            const int threads = shape == 0 ? 256 : (shape == 3 ? 128 : 64);
+            const int cap = shape == 0 ? 1024 : (shape == 1 ? 384 : (shape == 2 ? 512 : 640));
+            int per_block = (int)(0.9 * cap / (avg > 1.0 ? avg : 1.0));
+            per_block = per_block > threads ? threads : (per_block < 16 ? 16 : per_block & ~15);
             per_block = env_int("SPMV_AMD_CSR_STREAM_ROWS", per_block);
+            if (per_block > threads) per_block = threads;
             const dim3 grid((unsigned)((rows + per_block - 1) / per_block));
-            // bit 0: nontemporal span loads, bit 1: nontemporal y store. Measured on MI355X (10 000^2 / 15 000^2):
-            // plain 1.40 / 3.11 ms, nt loads 1.53 / 3.52, nt store 1.41 / 3.20, both 1.53 / 3.44 -> plain.
-            // (Block spans are not line-aligned and neighbouring blocks share their edge lines.)
-            const int nt = env_int("SPMV_AMD_CSR_NT", 0);
-#define SPMV_AMD_CSR_STREAM(L, S) \
-    hipLaunchKernelGGL((csr_stream_kernel<L, S>), grid, dim3(kBlock), 0, stream, m, x, y, alpha, per_block)
-            if ((nt & 3) == 3) SPMV_AMD_CSR_STREAM(true, true);
-            else if (nt & 1) SPMV_AMD_CSR_STREAM(true, false);
-            else if (nt & 2) SPMV_AMD_CSR_STREAM(false, true);
-            else SPMV_AMD_CSR_STREAM(false, false);
+#define SPMV_AMD_CSR_STREAM(T, P) \
+    hipLaunchKernelGGL((csr_stream_kernel<T, P>), grid, dim3(T), 0, stream, m, x, y, alpha, per_block)
+            if (shape == 1) SPMV_AMD_CSR_STREAM(64, 6);
+            else if (shape == 2) SPMV_AMD_CSR_STREAM(64, 8);
+            else if (shape == 3) SPMV_AMD_CSR_STREAM(128, 5);
+            else SPMV_AMD_CSR_STREAM(256, 4);
 #undef SPMV_AMD_CSR_STREAM
             break;
         }
