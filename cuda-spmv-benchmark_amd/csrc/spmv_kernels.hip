@@ -1195,6 +1195,9 @@ void launch_csr_spmv(const SlabCsr& m, const double* x, double* y, double alpha,
         case CsrVariant::Stream: {
             // rows per block: the mean span should fill about 90 % of the LDS strip, at most one row per thread
             const double avg = rows > 0 ? (double)m.nnz_local / rows : 1.0;
+            // threads x entries per thread; measured on MI355X at 10 000^2 / 15 000^2: 256 x 4 1.43 / 3.13 ms,
+            // 64 x 6 1.42 / 3.23-3.40, 64 x 8 1.55 / 3.30, 128 x 5 1.44 / 3.20 -> unlike the dense streams, the
+            // one-wave shapes do not pay here (fewer rows per block = more shared edge lines)
             const int shape = env_int("SPMV_AMD_CSR_STREAM_SHAPE", 0);  // 0: 256 x 4, 1: 64 x 6, 2: 64 x 8, 3: 128 x 5
             const int threads = shape == 0 ? 256 : (shape == 3 ? 128 : 64);
             const int cap = shape == 0 ? 1024 : (shape == 1 ? 384 : (shape == 2 ? 512 : 640));
