@@ -416,8 +416,29 @@ __global__ __launch_bounds__(kStream) void cg_update_p_ring_kernel(size_t n, con
     if ((n & 1) && block == 0 && threadIdx.x == 0) p_out[n - 1] = fma(1.0, r[n - 1], beta * p_in[n - 1]);
 }
 
+// K directions of the ring window for one 16-byte pair: all K loads first, then the fmas in iteration order.
+template <int K>
+__device__ __forceinline__ void flush_chunk(d2& xv, const RingSlots& ring, const double* __restrict__ alphas, int slots,
+                                            int& slot, size_t i) {
+    d2 pv[K];
+    double a[K];
+#pragma unroll
+    for (int u = 0; u < K; ++u) {
+        const int sl = (slot + u) % slots;
+        pv[u] = load_once(ring.p[sl], i);
+        a[u] = alphas[sl];
+    }
+#pragma unroll
+    for (int u = 0; u < K; ++u) {
+        xv.x = fma(a[u], pv[u].x, xv.x);
+        xv.y = fma(a[u], pv[u].y, xv.y);
+    }
+    slot = (slot + K) % slots;
+}
+
 // x = x_in + sum of alpha_j p_j over the ring window, one fma per term in iteration order: the chain
-// x <- fma(alpha_j, p_j, x) the per-iteration x updates evaluate (axpy_kernel, mgpu :598), read in one pass.
+// x <- fma(alpha_j, p_j, x) the per-iteration x updates evaluate (axpy_kernel, mgpu :598), read in one pass
+// with up to eight directions in flight per lane.
 __global__ __launch_bounds__(kStream) void cg_flush_x_kernel(size_t n, const double* __restrict__ alphas, RingSlots ring,
                                                              int slots, int first_slot, int count,
                                                              const double* x_in, double* x) {
@@ -426,41 +447,11 @@ __global__ __launch_bounds__(kStream) void cg_flush_x_kernel(size_t n, const dou
     if (i < pairs) {
         d2 xv = load_once(x_in, i);
         int slot = first_slot;
-        int j = 0;
-        constexpr int kInFlight = 8;  // directions in flight per lane
-        for (; j + kInFlight <= count; j += kInFlight) {
-            d2 pv[kInFlight];
-            double a[kInFlight];
-#pragma unroll
-            for (int u = 0; u < kInFlight; ++u) {
-                const int sl = (slot + u) % slots;
-                pv[u] = load_once(ring.p[sl], i);
-                a[u] = alphas[sl];
-            }
-#pragma unroll
-            for (int u = 0; u < kInFlight; ++u) {
-                xv.x = fma(a[u], pv[u].x, xv.x);
-                xv.y = fma(a[u], pv[u].y, xv.y);
-            }
-            slot = (slot + kInFlight) % slots;
-        }
-        for (; j + 2 <= count; j += 2) {
-            const int s1 = (slot + 1) % slots;
-            const d2 p0 = load_once(ring.p[slot], i), p1 = load_once(ring.p[s1], i);
-            const double a0 = alphas[slot], a1 = alphas[s1];
-            xv.x = fma(a0, p0.x, xv.x);
-            xv.y = fma(a0, p0.y, xv.y);
-            xv.x = fma(a1, p1.x, xv.x);
-            xv.y = fma(a1, p1.y, xv.y);
-            slot = (slot + 2) % slots;
-        }
-        for (; j < count; ++j) {
-            const d2 pv = load_once(ring.p[slot], i);
-            const double a = alphas[slot];
-            xv.x = fma(a, pv.x, xv.x);
-            xv.y = fma(a, pv.y, xv.y);
-            slot = (slot + 1) % slots;
-        }
+        int left = count;
+        for (; left >= 8; left -= 8) flush_chunk<8>(xv, ring, alphas, slots, slot, i);
+        if (left >= 4) { flush_chunk<4>(xv, ring, alphas, slots, slot, i); left -= 4; }
+        if (left >= 2) { flush_chunk<2>(xv, ring, alphas, slots, slot, i); left -= 2; }
+        if (left >= 1) flush_chunk<1>(xv, ring, alphas, slots, slot, i);
         store_once(x, i, xv);
     }
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
