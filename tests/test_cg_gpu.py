@@ -116,6 +116,39 @@ def test_direction_ring_is_bit_identical_to_in_place_updates(B, O, fresh_host_ma
         assert it1 == ro.iterations and hist_err(h1, ho) < TOL and np.max(np.abs(x1 - xo)) <= TOL * np.max(np.abs(xo))
 
 
+@pytest.mark.parametrize("n", [130, 640])
+def test_sweep_direction_alternation_changes_nothing(B, O, fresh_host_matrices, monkeypatch, n):
+    """SPMV_AMD_PINGPONG: consecutive kernels walk the vectors in opposite directions. Tiles, arithmetic and
+    partial slots are the same either way, so x and the history are bit-identical with and without it."""
+    rng = np.random.default_rng(7 * n)
+    e = O.stencil5_coo(n)
+    b, x0 = rng.standard_normal(n * n), 0.1 * rng.standard_normal(n * n)
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("SPMV_AMD_PINGPONG", mode)
+        B.lib().spmv_amd_reset_host_matrices()
+        slab = B.CgSlab.from_matrix(B.HostMatrix(e, n * n, n * n, n))
+        slab.set_vectors(b, x0)
+        st = slab.solve()
+        out[mode] = (st.iterations, slab.history().copy(), slab.gather().copy())
+        slab.destroy()
+    assert out["0"][0] == out["1"][0] and np.array_equal(out["0"][1], out["1"][1]) and np.array_equal(out["0"][2], out["1"][2])
+
+
+def test_one_launch_reduction_gives_the_same_bits():
+    """SPMV_AMD_REDUCE_ONE_LAUNCH=1 (last-block reduction + scalar step in one launch; measured slower, kept
+    selectable) sums in the same order as the two-launch default: identical residual history."""
+    import json, subprocess, sys
+    from conftest import ROOT
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--grid", "1024", "--no-cpu-baseline", "--no-spmv"]
+    runs = []
+    for env_extra in ({}, {"SPMV_AMD_REDUCE_ONE_LAUNCH": "1"}):
+        out = subprocess.run(cmd, env=dict(os.environ, **env_extra), capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stdout + out.stderr
+        runs.append(json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])["config"])
+    assert runs[0]["residual_history"] == runs[1]["residual_history"] and runs[0]["iterations_per_solve"] == runs[1]["iterations_per_solve"]
+
+
 def test_reference_entry_point_cg_solve_mgpu_partitioned(B, O, fresh_host_matrices):
     import ctypes as C
     n = 100
