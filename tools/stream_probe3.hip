@@ -5,6 +5,9 @@
 //   lds8    : coefficients fetched as five fully coalesced 8-byte loads per lane (optionally nontemporal),
 //             transposed through a wave-private LDS strip
 //   ldsdma  : coefficients of 128 rows per wave by five 16-byte-per-lane LDS-DMA instructions
+// Every kernel of the runs logged in profiles/r01_stream_probe3.txt is in this file; main() holds the first block
+// (argv[1] = passes, default 0) and the LAST experiment only -- the earlier ones were successive edits of main(),
+// their launch macros (LG, LGP, LGR, LF, FG, LP ...) are quoted in the log headers.
 //   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off tools/stream_probe3.hip -o tools/bin/stream_probe3
 #include <hip/hip_runtime.h>
 #include <stdio.h>
