@@ -424,6 +424,51 @@ __global__ __launch_bounds__(64) void lds_grid_pol(const double* __restrict__ v,
         if (f[h]) __builtin_nontemporal_store(row5(q[0], q[1], q[2], q[3], q[4], xw[h], xc[h], xe[h], xn[h], xs[h]), y + (long long)gi * n + j0 + lane + 64 * h);
     }
 }
+// grid tiles of 128 columns, coefficient run fetched as five 16-byte nontemporal loads per lane from the 16-byte
+// aligned address at or just below the run (sh = 0 / 1 doubles of lead-in), one extra pair by lane 0 when sh = 1
+typedef double dbl2 __attribute__((ext_vector_type(2)));
+template <int G>
+__global__ __launch_bounds__(64) void lds_grid16(const double* __restrict__ v, const double* __restrict__ x,
+                                                 double* __restrict__ y, int n, int tiles) {
+    __shared__ __attribute__((aligned(16))) double lds[656];
+    const int lane = threadIdx.x;
+    unsigned b = blockIdx.x;
+    if (G > 1) b = (b / (8 * G)) * (8 * G) + (b & 7) * G + ((b >> 3) % G);
+    const int gi = 1 + b / tiles;
+    if (gi > n - 2) return;
+    const int tile = b - (gi - 1) * tiles;
+    const int j0 = tile * 128;
+    const long long base = (4LL * n - 2) + (long long)(gi - 1) * (5LL * n - 2);
+    const long long s0 = base + 5LL * j0 - 1;
+    const int sh = (int)(s0 & 1);
+    const long long hi2 = (5LL * n * n - 4LL * n) / 2 - 1;  // last whole pair of the array
+    const dbl2* src = reinterpret_cast<const dbl2*>(v) + (s0 - sh) / 2;
+    dbl2 c[5], extra = {0.0, 0.0};
+#pragma unroll
+    for (int k = 0; k < 5; ++k) { long long idx = (s0 - sh) / 2 + lane + 64 * k; idx = idx > hi2 ? hi2 : idx; c[k] = __builtin_nontemporal_load(reinterpret_cast<const dbl2*>(v) + idx); }
+    if (sh && lane == 0) { long long idx = (s0 - sh) / 2 + 320; idx = idx > hi2 ? hi2 : idx; extra = __builtin_nontemporal_load(reinterpret_cast<const dbl2*>(v) + idx); }
+    (void)src;
+    double xc[2], xw[2], xe[2], xn[2], xs[2];
+    bool f[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int j = j0 + lane + 64 * h;
+        f[h] = j > 0 && j < n - 1;
+        if (f[h]) { const double* xl = x + (long long)gi * n + j; xc[h] = xl[0], xw[h] = xl[-1], xe[h] = xl[1], xn[h] = xl[-n], xs[h] = xl[n]; }
+    }
+    dbl2* l2 = reinterpret_cast<dbl2*>(lds);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) l2[64 * k + lane] = c[k];
+    if (sh && lane == 0) l2[320] = extra;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const double* q = lds + sh + 5 * (lane + 64 * h);
+        if (f[h]) __builtin_nontemporal_store(row5(q[0], q[1], q[2], q[3], q[4], xw[h], xc[h], xe[h], xn[h], xs[h]), y + (long long)gi * n + j0 + lane + 64 * h);
+    }
+}
 __global__ void fill_pattern(double* p, size_t count, int mode) {
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= count) return;
@@ -493,20 +538,13 @@ int main(int argc, char** argv) {
 #define LG(COLS, AL, PR, label) do { const int tl = (n + COLS - 1) / COLS; const unsigned nb = ((unsigned)tl * (n - 2) + 31) & ~31u; RUN(label, hipLaunchKernelGGL((lds_grid<COLS, AL, PR>), dim3(nb), dim3(64), 0, 0, v, x, y, n, tl)); } while (0)
         if (data == 1) {
 #define LF(COLS, G, label) do { const long long nt_ = ((long long)n * (n - 2)) / COLS; const unsigned nb = (unsigned)((nt_ + 8 * G - 1) / (8 * G) * (8 * G)); RUN(label, hipLaunchKernelGGL((lds_flat<COLS, G>), dim3(nb), dim3(64), 0, 0, v, x, y, n, nt_)); } while (0)
-            {
-            // does the relative placement of the three arrays matter? x and y shifted inside larger allocations
-            double *xb, *yb;
-            const size_t slack = 64u << 20;
-            CK(hipMalloc(&xb, rows * 8 + slack)); CK(hipMalloc(&yb, rows * 8 + slack));
-            const int tl = (n + 127) / 128; const unsigned nb = ((unsigned)tl * (n - 2) + 31) & ~31u;
-            for (size_t xoff : {(size_t)0, (size_t)256, (size_t)1024, (size_t)4096, (size_t)16384, (size_t)65536, (size_t)(1u << 20), (size_t)(2u << 20), (size_t)(16u << 20)})
-                for (size_t yoff : {(size_t)0, (size_t)1024, (size_t)65536, (size_t)(1u << 20)}) {
-                    double* xs = xb + xoff / 8; double* ys = yb + yoff / 8;
-                    hipLaunchKernelGGL(fill_pattern, dim3(blocks_for(rows, 256)), dim3(256), 0, 0, xs, rows, 2);
-                    CK(hipDeviceSynchronize());
-                    double ms = time_ms([&] { hipLaunchKernelGGL((lds_grid<128, false, 4>), dim3(nb), dim3(64), 0, 0, v, xs, ys, n, tl); });
-                    printf("x offset %9zu B, y offset %8zu B : %7.3f ms\n", xoff, yoff, ms); fflush(stdout);
-                }
+#define LG16(G, label) do { const int tl = (n + 127) / 128; const unsigned nb = ((unsigned)tl * (n - 2) + 8 * G - 1) / (8 * G) * (8 * G); RUN(label, hipLaunchKernelGGL((lds_grid16<G>), dim3(nb), dim3(64), 0, 0, v, x, y, n, tl)); } while (0)
+            for (int rep = 0; rep < 2; ++rep) {
+                LG(128, false, 4, "grid 128 cols G=4, ten 8-byte coefficient loads per lane");
+                LG16(1, "grid 128 cols G=1, five 16-byte coefficient loads per lane");
+                LG16(2, "grid 128 cols G=2, five 16-byte coefficient loads per lane");
+                LG16(4, "grid 128 cols G=4, five 16-byte coefficient loads per lane");
+                LG16(8, "grid 128 cols G=8, five 16-byte coefficient loads per lane");
             }
         }
     }
