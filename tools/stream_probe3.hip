@@ -538,13 +538,21 @@ int main(int argc, char** argv) {
 #define LG(COLS, AL, PR, label) do { const int tl = (n + COLS - 1) / COLS; const unsigned nb = ((unsigned)tl * (n - 2) + 31) & ~31u; RUN(label, hipLaunchKernelGGL((lds_grid<COLS, AL, PR>), dim3(nb), dim3(64), 0, 0, v, x, y, n, tl)); } while (0)
         if (data == 1) {
 #define LF(COLS, G, label) do { const long long nt_ = ((long long)n * (n - 2)) / COLS; const unsigned nb = (unsigned)((nt_ + 8 * G - 1) / (8 * G) * (8 * G)); RUN(label, hipLaunchKernelGGL((lds_flat<COLS, G>), dim3(nb), dim3(64), 0, 0, v, x, y, n, nt_)); } while (0)
-#define LG16(G, label) do { const int tl = (n + 127) / 128; const unsigned nb = ((unsigned)tl * (n - 2) + 8 * G - 1) / (8 * G) * (8 * G); RUN(label, hipLaunchKernelGGL((lds_grid16<G>), dim3(nb), dim3(64), 0, 0, v, x, y, n, tl)); } while (0)
-            for (int rep = 0; rep < 2; ++rep) {
-                LG(128, false, 4, "grid 128 cols G=4, ten 8-byte coefficient loads per lane");
-                LG16(1, "grid 128 cols G=1, five 16-byte coefficient loads per lane");
-                LG16(2, "grid 128 cols G=2, five 16-byte coefficient loads per lane");
-                LG16(4, "grid 128 cols G=4, five 16-byte coefficient loads per lane");
-                LG16(8, "grid 128 cols G=8, five 16-byte coefficient loads per lane");
+            {
+            // coefficients in an UNCACHED / fine-grained allocation instead of the default one
+            for (unsigned flag : {hipDeviceMallocUncached, hipDeviceMallocFinegrained}) {
+                double* vu = nullptr;
+                if (hipExtMallocWithFlags((void**)&vu, rows * 40 + 64, flag) != hipSuccess) { printf("allocation with flag %u failed\n", flag); continue; }
+                CK(hipMemcpy(vu, v, rows * 40 + 64, hipMemcpyDeviceToDevice));
+                const int tl = (n + 127) / 128; const unsigned nb = ((unsigned)tl * (n - 2) + 31) & ~31u;
+                for (int rep = 0; rep < 2; ++rep) {
+                    double ms = time_ms([&] { hipLaunchKernelGGL((lds_grid<128, false, 4>), dim3(nb), dim3(64), 0, 0, v, x, y, n, tl); });
+                    printf("coefficients in the default allocation      : %7.3f ms\n", ms);
+                    ms = time_ms([&] { hipLaunchKernelGGL((lds_grid<128, false, 4>), dim3(nb), dim3(64), 0, 0, vu, x, y, n, tl); });
+                    printf("coefficients in allocation with flag 0x%x : %7.3f ms\n", flag, ms); fflush(stdout);
+                }
+                CK(hipFree(vu));
+            }
             }
         }
     }
