@@ -20,6 +20,9 @@ configuration of reference docs/PROBLEM_SIZE_SCALING_RESULTS.md:40-47, on N row 
   spmv      (N = 1 only) the reference's other headline: stencil5-csr operator, x = 1, 5 warm-ups
             + 10 timed launches, >2 sigma outliers dropped, median -> "effective" GB/s by both of
             the reference's byte formulas (spmv_metrics.cu:85-101 and the published 12*nnz+16*rows).
+  scaling_probe  (N = 1 only) per-rank slab sizes of 2 / 4 / 8 GPUs solved on this GPU, plainly and through the full
+            RCCL pipeline with the rank as its own neighbour, and the strong-scaling efficiency that projects for an
+            assumed 20 us per inter-device all-reduce (evidence for DESIGN.md section 5; not part of `value`).
   cpu_baseline  (N = 1, rank 0) the serial C oracle's CG (oracle/spmv_oracle.c, 1 core) on a
             bounded sample (10 000 x 10 000 = 1/4 of the rows, ~10 s), scaled by rows to the 400 M-unknown problem.
 
@@ -114,6 +117,57 @@ def cpu_baseline(sample_grid, full_rows):
     }
 
 
+def scaling_probe(B, torch, grid, full_ms, full_iterations, steps=6):
+    """What this one GPU can say about strong scaling (N = 1 only): for P = 2, 4, 8 a square grid with the row count
+    of one rank's slab is solved plainly and through the complete multi-rank pipeline over RCCL with the rank as its
+    own neighbour (SPMV_AMD_SELF_NEIGHBOUR: halo send/recv on the side stream under the interior SpMV, split SpMV
+    launches, both all-reduces issued). Everything but the latency of an all-reduce BETWEEN
+    devices is measured; the projection adds 2 per iteration at an assumed 20 us."""
+    import math
+
+    out = {"method": "per-rank slab sizes solved on one GPU, plain vs full RCCL pipeline with the rank as its own neighbour; "
+                     "projection = pipeline time per iteration x iterations of the full problem + 2 all-reduces per iteration at the assumed latency",
+           "assumed_allreduce_latency_us": 20.0, "slabs": []}
+
+    def run(n, comm):
+        slab = B.CgSlab.stencil5(n, comm)
+        for _ in range(2):
+            st = slab.solve()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            st = slab.solve()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        it = st.iterations
+        slab.destroy()
+        return ms, it
+
+    for P in (2, 4, 8):
+        n = int(round(math.sqrt(grid * grid / P)))
+        plain_ms, it = run(n, None)
+        saved = {k: os.environ.get(k) for k in ("SPMV_AMD_SELF_NEIGHBOUR", "SPMV_AMD_FORCE_COLLECTIVES")}
+        os.environ["SPMV_AMD_SELF_NEIGHBOUR"] = os.environ["SPMV_AMD_FORCE_COLLECTIVES"] = "1"
+        try:
+            comm = B.Comm.rccl(0, 1, B.Comm.unique_id())
+        finally:
+            for k, v in saved.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        if comm is None:
+            out["slabs"].append({"gpus": P, "error": "RCCL communicator could not be created"})
+            continue
+        pipe_ms, it2 = run(n, comm)
+        comm.destroy()
+        projected = pipe_ms / it2 * full_iterations + 2 * full_iterations * out["assumed_allreduce_latency_us"] / 1e3
+        out["slabs"].append({"gpus": P, "slab_proxy_grid": n, "iterations": it, "plain_ms_per_solve": plain_ms, "pipeline_ms_per_solve": pipe_ms,
+                             "pipeline_overhead_us_per_iteration": (pipe_ms / it2 - plain_ms / it) * 1e3,
+                             "projected_ms_per_solve": projected, "projected_strong_scaling_efficiency": full_ms / (P * projected)})
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -123,6 +177,7 @@ def main():
     ap.add_argument("--cpu-sample-grid", type=int, default=10000, help="grid of the CPU-baseline sample (10000: ~10 s on one core)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-spmv", action="store_true", help="skip the N=1 SpMV headline leg")
+    ap.add_argument("--no-scaling-probe", action="store_true", help="skip the N=1 one-GPU strong-scaling probe")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -256,6 +311,11 @@ def main():
     if comm is not None:
         comm.destroy()
 
+    if rank == 0 and world == 1 and not multi and not args.no_scaling_probe and n >= 8192:
+        try:
+            out["scaling_probe"] = scaling_probe(B, torch, n, out["ms_per_step"], iterations)
+        except Exception as e:  # evidence only: never let it take the benchmark line down
+            out["scaling_probe"] = {"error": repr(e)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.cpu_sample_grid, rows)
     if rank == 0:
