@@ -178,7 +178,29 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-spmv", action="store_true", help="skip the N=1 SpMV headline leg")
     ap.add_argument("--no-scaling-probe", action="store_true", help="skip the N=1 one-GPU strong-scaling probe")
+    ap.add_argument("--scaling-probe-only", nargs=2, metavar=("FULL_MS", "FULL_ITERATIONS"), default=None,
+                    help="(internal) run only the scaling probe and print its JSON object")
     args = ap.parse_args()
+
+    # The library prints progress lines the way the reference harness does ("[stencil5-csr] Cleaning up", ...):
+    # send everything written to fd 1 from here on to stderr and keep the real stdout for the one JSON line.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(obj):
+        os.write(json_fd, (json.dumps(obj) + "\n").encode())
+
+    if args.scaling_probe_only is not None:
+        import torch
+
+        B = load_binding()
+        B.lib()
+        B.require_gpu()
+        torch.cuda.set_device(0)
+        B.lib().spmv_amd_set_device(0)
+        emit(scaling_probe(B, torch, args.grid, float(args.scaling_probe_only[0]), int(args.scaling_probe_only[1])))
+        return
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -312,14 +334,20 @@ def main():
         comm.destroy()
 
     if rank == 0 and world == 1 and not multi and not args.no_scaling_probe and n >= 8192:
+        # evidence only, in a child process: whatever happens to it, the benchmark line above is printed
+        import subprocess
         try:
-            out["scaling_probe"] = scaling_probe(B, torch, n, out["ms_per_step"], iterations)
-        except Exception as e:  # evidence only: never let it take the benchmark line down
+            child = subprocess.run([sys.executable, os.path.abspath(__file__), "--grid", str(n), "--scaling-probe-only",
+                                    repr(out["ms_per_step"]), str(iterations)], capture_output=True, text=True, timeout=600)
+            lines = [l for l in child.stdout.splitlines() if l.startswith("{")]
+            out["scaling_probe"] = json.loads(lines[-1]) if child.returncode == 0 and lines else {
+                "error": f"probe exited with {child.returncode}", "stderr_tail": child.stderr[-400:]}
+        except Exception as e:
             out["scaling_probe"] = {"error": repr(e)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.cpu_sample_grid, rows)
     if rank == 0:
-        print(json.dumps(out))
+        emit(out)
     if multi:
         dist.barrier()
         dist.destroy_process_group()
