@@ -16,12 +16,15 @@ dst = os.path.join(ROOT, "profiles")
 
 
 def newest(pattern):
-    # rocprofv3 writes one directory per process: the one holding our kernels is the python process
-    best, best_rows = None, -1
+    # gpurun merges every collection into the same local directory (one file set per process id): take the most
+    # recently written file that holds our kernels
+    best, best_time = None, -1.0
     for f in glob.glob(pattern):
-        rows = sum(1 for line in open(f) if "spmv_amd" in line)
-        if rows > best_rows:
-            best, best_rows = f, rows
+        if not any("spmv_amd" in line for line in open(f)):
+            continue
+        t = os.path.getmtime(f)
+        if t > best_time:
+            best, best_time = f, t
     return best
 
 
