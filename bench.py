@@ -24,7 +24,8 @@ configuration of reference docs/PROBLEM_SIZE_SCALING_RESULTS.md:40-47, on N row 
             RCCL pipeline with the rank as its own neighbour, and the strong-scaling efficiency that projects for an
             assumed 20 us per inter-device all-reduce (evidence for DESIGN.md section 5; not part of `value`).
   cpu_baseline  (N = 1, rank 0) the serial C oracle's CG (oracle/spmv_oracle.c, 1 core) on a
-            bounded sample (10 000 x 10 000 = 1/4 of the rows, ~10 s), scaled by rows to the 400 M-unknown problem.
+            bounded sample (10 000 x 10 000 = 1/4 of the rows, ~10 s), scaled by rows to the 400 M-unknown problem;
+            `all_cores` = the same loops under OpenMP on up to 16 threads (~1-2 s).
 
 Multi-GPU: launched by torch.distributed.run with one rank per GPU. torch.distributed (gloo) is
 used only for rendezvous, the unique-id broadcast, barriers and the max-over-ranks; the data path
@@ -110,11 +111,22 @@ def cpu_baseline(sample_grid, full_rows):
                 break
     except OSError:
         pass
-    return {
+    rec = {
         "value": res.iterations / dt * rows / full_rows, "unit": "CG iterations/s (scaled to 400M unknowns)", "cores": 1, "kind": "port",
         "sample": f"oracle_cg on the {sample_grid}x{sample_grid} stencil ({rows} rows = 1/{full_rows // rows} of the workload), "
                   f"{res.iterations} iterations in {dt:.2f} s on 1 core of {os.cpu_count()} ({cpu})",
     }
+    # the same loops spread over the cores this job may use (a one-GPU box's CPU share is 16), BASELINE.md section 3
+    try:
+        threads = max(1, min(16, os.cpu_count() or 1))
+        t0 = time.perf_counter()
+        x2, hist2, res2 = O.cg_all_cores(rp, ci, va, sample_grid, np.ones(rows), np.zeros(rows), threads)
+        dt2 = time.perf_counter() - t0
+        rec["all_cores"] = {"value": res2.iterations / dt2 * rows / full_rows, "cores": threads, "kind": "port (OpenMP over the oracle's loops)",
+                            "sample": f"same sample, {res2.iterations} iterations in {dt2:.2f} s on {threads} threads"}
+    except Exception as e:  # optional figure
+        rec["all_cores"] = {"error": repr(e)}
+    return rec
 
 
 def scaling_probe(B, torch, grid, full_ms, full_iterations, steps=6):

@@ -12,6 +12,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "liboracle.so")
+OMP_LIB_PATH = os.path.join(HERE, "liboracle_omp.so")  # threaded build: bench.py's all-cores baseline only
 REF_IO_PATH = os.path.join(HERE, "_ref", "libref_io.so")
 REF_GEN_PATH = os.path.join(HERE, "_ref", "generate_matrix")
 
@@ -47,7 +48,7 @@ def build(force=False):
     if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < os.path.getmtime(
         os.path.join(HERE, "spmv_oracle.c")
     ):
-        subprocess.check_call(["make", "-C", HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-C", HERE, "liboracle.so", "liboracle_omp.so"], stdout=subprocess.DEVNULL)
     if not os.path.exists(REF_IO_PATH):
         subprocess.call(["make", "-C", HERE, "ref"], stdout=subprocess.DEVNULL)
 
@@ -187,6 +188,23 @@ def cg(rp, ci, va, grid_size, b, x0, max_iters=1000, tol=1e-6, device_form=True)
     hist = np.zeros(max_iters + 1, dtype=np.float64)
     res = CGResult()
     rc = lib().oracle_cg(n, _ip(rp), _ip(ci), _dp(va), int(grid_size), _dp(b), _dp(x), max_iters, C.c_double(tol), int(bool(device_form)), _dp(hist), len(hist), C.byref(res))
+    assert rc == 0
+    return x, hist[: res.iterations + 1].copy(), res
+
+
+def cg_all_cores(rp, ci, va, grid_size, b, x0, threads, max_iters=1000, tol=1e-6):
+    """oracle_cg (device form) from the threaded build, for timing the all-cores CPU baseline. Its dot products are
+    summed per thread, so compare it with the serial oracle at 1e-10, never bit for bit."""
+    if not os.path.exists(OMP_LIB_PATH):
+        subprocess.check_call(["make", "-C", HERE, "liboracle_omp.so"], stdout=subprocess.DEVNULL)
+    L = C.CDLL(OMP_LIB_PATH)
+    C.CDLL("libgomp.so.1").omp_set_num_threads(int(threads))
+    n = len(rp) - 1
+    b = _f64(b)
+    x = _f64(x0).copy()
+    hist = np.zeros(max_iters + 1, dtype=np.float64)
+    res = CGResult()
+    rc = L.oracle_cg(n, _ip(rp), _ip(ci), _dp(va), int(grid_size), _dp(b), _dp(x), max_iters, C.c_double(tol), 1, _dp(hist), len(hist), C.byref(res))
     assert rc == 0
     return x, hist[: res.iterations + 1].copy(), res
 

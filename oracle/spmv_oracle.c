@@ -14,6 +14,16 @@
 /* stencil generation (io.cu:322-399)                                  */
 /* ------------------------------------------------------------------ */
 
+/* liboracle_omp.so (-fopenmp -DORACLE_OMP) is this same file with the row / element loops of the solver spread
+ * over threads, for the all-cores CPU baseline of bench.py ONLY: per-element arithmetic is unchanged, dot products
+ * are summed per thread and then combined, so its rounding differs from the serial oracle in the last bits.
+ * Parity is always checked against the serial build (liboracle.so), where these pragmas do not exist. */
+#ifdef ORACLE_OMP
+#define ORACLE_PARALLEL_FOR _Pragma("omp parallel for schedule(static)")
+#else
+#define ORACLE_PARALLEL_FOR
+#endif
+
 long long oracle_stencil5_nnz(int n) { return 5LL * n * n - 4LL * n; }
 
 long long oracle_stencil5_coo(int n, double center, double off, OracleEntry* out) {
@@ -114,6 +124,7 @@ void oracle_spmv_csr(int rows, const int* row_ptr, const int* col_idx, const dou
 
 void oracle_spmv_stencil5(int rows, const int* row_ptr, const int* col_idx, const double* values,
                           const double* x, double* y, int grid_size, double alpha) {
+    ORACLE_PARALLEL_FOR
     for (int row = 0; row < rows; row++) {
         /* C division of a non-negative row by grid_size == -1 gives i = -row, so the
          * interior test fails for every row, exactly as on the GPU. */
@@ -255,6 +266,12 @@ double oracle_dot_host(int n, const double* x, const double* y) {
 
 double oracle_dot_device(int n, const double* x, const double* y) {
     int blocks = (n + ORACLE_BLOCK - 1) / ORACLE_BLOCK;
+#ifdef ORACLE_OMP
+    double total = 0.0;
+#pragma omp parallel for schedule(static) reduction(+ : total)
+    for (int b = 0; b < blocks; b++) total += block_partial(n, x, y, b);
+    return total;
+#endif
     double s[ORACLE_BLOCK];
     for (int t = 0; t < ORACLE_BLOCK; t++) s[t] = 0.0;
     /* thread t accumulates partials t, t+256, ... in that order */
@@ -289,6 +306,7 @@ int oracle_cg(int n, const int* row_ptr, const int* col_idx, const double* value
 
     oracle_spmv_stencil5(n, row_ptr, col_idx, values, x, Ap, grid_size, 1.0);
     /* axpby_kernel(n, 1.0, b, -1.0, Ap, r): z = alpha*x + beta*y */
+    ORACLE_PARALLEL_FOR
     for (int i = 0; i < n; i++) r[i] = fma(1.0, b[i], -1.0 * Ap[i]);
     memcpy(p, r, (size_t)n * sizeof(double));
     double rr_old = dot(n, r, r);
@@ -302,7 +320,9 @@ int oracle_cg(int n, const int* row_ptr, const int* col_idx, const double* value
         oracle_spmv_stencil5(n, row_ptr, col_idx, values, p, Ap, grid_size, 1.0);
         double pAp = dot(n, Ap, p);
         double alpha = rr_old / pAp;
+        ORACLE_PARALLEL_FOR
         for (int i = 0; i < n; i++) x[i] = fma(alpha, p[i], x[i]);
+        ORACLE_PARALLEL_FOR
         for (int i = 0; i < n; i++) r[i] = fma(-alpha, Ap[i], r[i]);
         double rr_new = dot(n, r, r);
         double res = sqrt(rr_new);
@@ -316,8 +336,10 @@ int oracle_cg(int n, const int* row_ptr, const int* col_idx, const double* value
         }
         double beta = rr_new / rr_old;
         if (device_form) {
+            ORACLE_PARALLEL_FOR
             for (int i = 0; i < n; i++) p[i] = fma(beta, p[i], r[i]); /* update_p_kernel */
         } else {
+            ORACLE_PARALLEL_FOR
             for (int i = 0; i < n; i++) p[i] = fma(1.0, r[i], beta * p[i]); /* axpby_kernel */
         }
         rr_old = rr_new;

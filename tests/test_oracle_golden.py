@@ -143,3 +143,14 @@ def test_integer_formulas(O):
     assert O.interior_csr_offset(19998 * 20000 + 19998, 20000) == 1999839993  # SURVEY 8 a1 maximum
     assert O.partition_rows(400000000, 8, 3) == (150000000, 50000000)
     assert O.partition_rows(10, 3, 2) == (6, 4)
+
+
+def test_threaded_oracle_build_agrees_with_the_serial_one(O):
+    """liboracle_omp.so (bench.py's all-cores CPU baseline) runs the serial oracle's loops under OpenMP: same
+    iteration count, residual history within 1e-12 (its dot products are summed per thread)."""
+    n = 130
+    rp, ci, va = O.stencil5_csr(n)
+    b, x0 = np.ones(n * n), np.zeros(n * n)
+    x, h, r = O.cg(rp, ci, va, n, b, x0)
+    x2, h2, r2 = O.cg_all_cores(rp, ci, va, n, b, x0, threads=4)
+    assert r.iterations == r2.iterations and np.max(np.abs(h - h2) / h) < 1e-12 and np.max(np.abs(x - x2)) < 1e-12
