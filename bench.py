@@ -17,24 +17,43 @@ configuration of reference docs/PROBLEM_SIZE_SCALING_RESULTS.md:40-47, on N row 
             p.Ap partials): algorithmic bytes of one launch (8*nnz + 8*cols + 8*rows of the slab,
             SURVEY.md 8d) / its average duration, from HIP events recorded on the solver's stream
             around every in-loop launch of the timed steps. Peak 8 TB/s (MI355X_MICROARCH.md).
+            ceiling_measured / frac_of_ceiling: the same byte mix (48 B read : 8 B written per row) streamed
+            with ideal accesses on this GPU in this run (csrc/stream_ceiling.hip), so the line carries the
+            fraction of the data-sheet peak AND of what the part sustains. traffic: fabric bytes per launch
+            from profiles/hbm_traffic.json, only while that file's hash of csrc/spmv_kernels.hip matches.
   spmv      (N = 1 only) the reference's other headline: stencil5-csr operator, x = 1, 5 warm-ups
             + 10 timed launches, >2 sigma outliers dropped, median -> "effective" GB/s by both of
             the reference's byte formulas (spmv_metrics.cu:85-101 and the published 12*nnz+16*rows).
-  scaling_probe  (N = 1 only) per-rank slab sizes of 2 / 4 / 8 GPUs solved on this GPU, plainly and through the full
-            RCCL pipeline with the rank as its own neighbour, and the strong-scaling efficiency that projects for an
-            assumed 20 us per inter-device all-reduce (evidence for DESIGN.md section 5; not part of `value`).
-  cpu_baseline  (N = 1, rank 0) the serial C oracle's CG (oracle/spmv_oracle.c, 1 core) on a
-            bounded sample (10 000 x 10 000 = 1/4 of the rows, ~10 s), scaled by rows to the 400 M-unknown problem;
-            `all_cores` = the same loops under OpenMP on up to 16 threads (~1-2 s).
+  scaling_probe  (N = 1 only; a PROJECTION, never part of `value`) the real per-rank slabs of a 2 / 4 / 8-GPU
+            run of this problem (rows [r*N/P, (r+1)*N/P), 160 KB halos), edge rank and a two-neighbour rank,
+            each solved for the full iteration count on this GPU through the complete RCCL pipeline with the
+            rank as its own neighbour. The latency of an all-reduce BETWEEN devices cannot be measured on one
+            GPU: the efficiency is given for a range of latencies.
+  cpu_baseline  (N = 1, rank 0) the serial C oracle (oracle/spmv_oracle.c, 1 core) on a bounded sample
+            (10 000 x 10 000 = 1/4 of the rows): its CG, scaled by rows to the 400 M-unknown problem
+            (~10 s), and `spmv` = its STENCIL5 and CSR SpMV (1 warm-up + 3 runs, median) in the reference's
+            effective-GB/s formula and in algorithmic GB/s; `all_cores` = the same loops under OpenMP.
 
-Multi-GPU: launched by torch.distributed.run with one rank per GPU. torch.distributed (gloo) is
-used only for rendezvous, the unique-id broadcast, barriers and the max-over-ranks; the data path
-(halo send/recv + all-reduce) is RCCL inside libspmv_amd.so.
+Multi-GPU: one process per GPU. Either the driver starts the ranks (`python -m torch.distributed.run
+--nproc-per-node N bench.py --gpus N ...`, RANK / WORLD_SIZE in the environment) or `python bench.py --gpus N`
+starts them itself: the parent process touches neither torch nor the GPU, spawns N children of this file with
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, relays rank 0's JSON line and exits with the worst
+child status. torch.distributed (gloo) is used only for rendezvous, the unique-id broadcast, barriers and the
+max-over-ranks; the data path (halo send/recv + all-reduce) is RCCL inside libspmv_amd.so.
+
+No silent degradation: if RCCL cannot be created or fails its self-test on any rank, if fewer GPUs are visible
+than ranks, or if RCCL spans fewer ranks than asked, every rank stops, rank 0 prints a line with "value": null and
+"unmeasured": "<reason>", and the exit status is 3. The host-staged transport (the reference's own D2H -> host
+exchange -> H2D scheme) is taken only when SPMV_AMD_BENCH_ALLOW_STAGED=1 asks for it (tests on a 1-GPU box),
+and then the line says "degraded" and carries no vs_baseline.
 """
 import argparse
+import hashlib
 import importlib.util
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -47,6 +66,8 @@ sys.path.insert(0, ROOT)
 A100_CG_ITERS_PER_S = {1: 14 / 0.5314, 2: 14 / 0.2693, 4: 14 / 0.1363, 8: 14 / 0.0710}
 A100_SPMV_EFFECTIVE_GBS_PUBLISHED_FORMULA = 2364.16
 HBM_PEAK_GBS = 8000.0
+EXIT_UNMEASURED = 3
+KERNEL_SOURCE = os.path.join(ROOT, "cuda-spmv-benchmark_amd", "csrc", "spmv_kernels.hip")
 
 
 def load_binding():
@@ -63,6 +84,11 @@ def reference_stats(times_ms):
     return float(np.median(keep)), int(len(t) - len(keep))
 
 
+def spmv_byte_formulas(rows, nnz):
+    """(reference's effective bytes today, its published formula, algorithmic bytes) of one SpMV."""
+    return (8 * nnz + 4 * nnz + 4 * (rows + 1) + 8 * rows + 8 * rows, 12 * nnz + 16 * rows, 8 * nnz + 8 * rows + 8 * rows)
+
+
 def spmv_headline(B, n, warmup=5, runs=10):
     """The reference's SpMV benchmark (src/main/main.cu:136-187) on the stencil5-csr operator."""
     rows, nnz = n * n, 5 * n * n - 4 * n
@@ -73,7 +99,6 @@ def spmv_headline(B, n, warmup=5, runs=10):
     op.time_device(dx, dy, warmup)
     ms = op.time_device(dx, dy, runs)
     median_ms, dropped = reference_stats(ms)
-    # checksum without pulling 3.2 GB to the host: sum(y) through a dot with ones on the device
     y_sum = None
     if rows <= 50_000_000:
         y = dy.to_host()
@@ -81,9 +106,7 @@ def spmv_headline(B, n, warmup=5, runs=10):
     variant = op.variant()
     dx.free(), dy.free(), op.free()
     secs = median_ms / 1e3
-    bytes_today = 8 * nnz + 4 * nnz + 4 * (rows + 1) + 8 * rows + 8 * rows
-    bytes_published = 12 * nnz + 16 * rows
-    bytes_algorithmic = 8 * nnz + 8 * rows + 8 * rows
+    bytes_today, bytes_published, bytes_algorithmic = spmv_byte_formulas(rows, nnz)
     return {
         "operator": "stencil5-csr", "variant": variant, "grid": n, "median_ms": median_ms, "outliers_removed": dropped,
         "all_ms": [round(float(v), 4) for v in ms], "gflops": 2.0 * nnz / secs / 1e9,
@@ -93,9 +116,59 @@ def spmv_headline(B, n, warmup=5, runs=10):
     }
 
 
+def stream_ceiling(B, rows=200_000_000, reps=20):
+    """The 48:8 read:write stream probe on the benchmark's data (csrc/stream_ceiling.hip), ~50 ms of GPU time."""
+    ms, nbytes = B.stream_ceiling(rows, warmup=3, reps=reps)
+    med, _ = reference_stats(ms)
+    return {"gbs": nbytes / (med / 1e3) / 1e9, "median_ms": med, "rows": rows, "bytes_per_launch": nbytes, "launches": reps,
+            "what": "48 B read : 8 B written per row, coalesced 8-byte nontemporal accesses, one-wave workgroups, "
+                    "coefficients [-1 -1 5 -1 -1] and x = 1 (non-zero data), no neighbour reads"}
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_spmv_baseline(O, rp, ci, va, n, threads):
+    """Serial oracle SpMV, stencil5 path (spmv_stencil_csr_direct.cu:76-123) and CSR path
+    (cg_solver_mgpu_partitioned.cu:40-56): 1 warm-up + 3 runs, median; then the threaded build."""
+    rows, nnz = n * n, len(va)
+    x, y = np.ones(rows), np.empty(rows)
+    eff, published, alg_stencil = spmv_byte_formulas(rows, nnz)
+    alg = {"stencil5": alg_stencil, "csr": eff}  # the CSR kernel really reads col_idx and row_ptr (SURVEY 8d)
+
+    def timed(kind, L):
+        g = n if kind == "stencil5" else None
+        O.spmv_into(rp, ci, va, x, y, g, L)  # warm-up
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            O.spmv_into(rp, ci, va, x, y, g, L)
+            ts.append(time.perf_counter() - t0)
+        s = float(np.median(ts))
+        return {"median_ms": s * 1e3, "runs_ms": [round(t * 1e3, 2) for t in ts], "gflops": 2.0 * nnz / s / 1e9,
+                "effective_gbs": eff / s / 1e9, "effective_gbs_published_formula": published / s / 1e9,
+                "algorithmic_gbs": alg[kind] / s / 1e9, "sum_y": float(y.sum())}
+
+    rec = {"grid": n, "rows": rows, "nnz": nnz, "rule": "x = 1, 1 warm-up + 3 runs, median (BASELINE.md section 3)", "cores": 1,
+           "stencil5": timed("stencil5", None), "csr": timed("csr", None)}
+    try:
+        L = O.omp_lib(threads)
+        rec["all_cores"] = {"cores": threads, "stencil5": timed("stencil5", L), "csr": timed("csr", L)}
+    except Exception as e:  # optional figure
+        rec["all_cores"] = {"error": repr(e)}
+    return rec
+
+
 def cpu_baseline(sample_grid, full_rows):
     """Oracle CG (serial C, 1 core) on a sample grid; cost is linear in rows, so iterations/s at the
-    full size = iterations/s on the sample * sample_rows / full_rows."""
+    full size = iterations/s on the sample * sample_rows / full_rows. Plus the oracle's SpMV on the same sample."""
     from oracle import oracle as O
 
     rp, ci, va = O.stencil5_csr(sample_grid)
@@ -103,22 +176,15 @@ def cpu_baseline(sample_grid, full_rows):
     t0 = time.perf_counter()
     x, hist, res = O.cg(rp, ci, va, sample_grid, np.ones(rows), np.zeros(rows), device_form=True)
     dt = time.perf_counter() - t0
-    cpu = "unknown"
-    try:
-        for line in open("/proc/cpuinfo"):
-            if line.startswith("model name"):
-                cpu = line.split(":", 1)[1].strip()
-                break
-    except OSError:
-        pass
+    cpu = cpu_model()
     rec = {
         "value": res.iterations / dt * rows / full_rows, "unit": "CG iterations/s (scaled to 400M unknowns)", "cores": 1, "kind": "port",
         "sample": f"oracle_cg on the {sample_grid}x{sample_grid} stencil ({rows} rows = 1/{full_rows // rows} of the workload), "
                   f"{res.iterations} iterations in {dt:.2f} s on 1 core of {os.cpu_count()} ({cpu})",
     }
     # the same loops spread over the cores this job may use (a one-GPU box's CPU share is 16), BASELINE.md section 3
+    threads = max(1, min(16, os.cpu_count() or 1))
     try:
-        threads = max(1, min(16, os.cpu_count() or 1))
         t0 = time.perf_counter()
         x2, hist2, res2 = O.cg_all_cores(rp, ci, va, sample_grid, np.ones(rows), np.zeros(rows), threads)
         dt2 = time.perf_counter() - t0
@@ -126,58 +192,117 @@ def cpu_baseline(sample_grid, full_rows):
                             "sample": f"same sample, {res2.iterations} iterations in {dt2:.2f} s on {threads} threads"}
     except Exception as e:  # optional figure
         rec["all_cores"] = {"error": repr(e)}
+    try:
+        rec["spmv"] = cpu_spmv_baseline(O, rp, ci, va, sample_grid, threads)
+    except Exception as e:
+        rec["spmv"] = {"error": repr(e)}
     return rec
 
 
-def scaling_probe(B, torch, grid, full_ms, full_iterations, steps=6):
-    """What this one GPU can say about strong scaling (N = 1 only): for P = 2, 4, 8 a square grid with the row count
-    of one rank's slab is solved plainly and through the complete multi-rank pipeline over RCCL with the rank as its
-    own neighbour (SPMV_AMD_SELF_NEIGHBOUR: halo send/recv on the side stream under the interior SpMV, split SpMV
-    launches, both all-reduces issued). Everything but the latency of an all-reduce BETWEEN
-    devices is measured; the projection adds 2 per iteration at an assumed 20 us."""
-    import math
+def scaling_probe(B, torch, grid, full_ms, full_iterations, steps=5):
+    """What ONE GPU can say about strong scaling (N = 1 only; a projection). For P = 2, 4, 8 the real slab of the
+    edge rank (one neighbour) and of a middle rank (two neighbours) of this grid -- rows [r*N/P, (r+1)*N/P), same CSR
+    bytes, `grid`-double halos -- is solved for exactly `full_iterations` iterations through the complete multi-rank
+    pipeline over RCCL with the rank as its own neighbour (halo ncclSend / ncclRecv on the side stream under the
+    interior SpMV, split SpMV launches, both ncclAllReduce calls issued with one rank). The slab's neighbours being
+    its own grid rows, the system solved is a periodic strip, not the global one: only the time is used.
+    Not measured: the latency of a send/recv and of an all-reduce BETWEEN devices."""
+    out = {"method": "real per-rank slabs of the headline grid on one GPU: full RCCL pipeline with the rank as its own neighbour, "
+                     f"{full_iterations} iterations per solve (tolerance 0), {steps} timed solves after 2 warm-ups",
+           "projection": True, "measured_between_devices": False, "grid": grid, "full_problem_ms_per_solve": full_ms,
+           "allreduces_per_solve": 2 * full_iterations + 1, "slabs": []}
+    saved = {k: os.environ.get(k) for k in ("SPMV_AMD_SELF_NEIGHBOUR", "SPMV_AMD_FORCE_COLLECTIVES")}
+    os.environ["SPMV_AMD_SELF_NEIGHBOUR"] = os.environ["SPMV_AMD_FORCE_COLLECTIVES"] = "1"
+    try:
+        comm = B.Comm.rccl(0, 1, B.Comm.unique_id())
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    if comm is None:
+        out["error"] = "RCCL communicator could not be created"
+        return out
 
-    out = {"method": "per-rank slab sizes solved on one GPU, plain vs full RCCL pipeline with the rank as its own neighbour; "
-                     "projection = pipeline time per iteration x iterations of the full problem + 2 all-reduces per iteration at the assumed latency",
-           "assumed_allreduce_latency_us": 20.0, "slabs": []}
-
-    def run(n, comm):
-        slab = B.CgSlab.stencil5(n, comm)
+    def run(P, r):
+        slab = B.CgSlab.stencil5_as(grid, r, P, comm)
         for _ in range(2):
-            st = slab.solve()
+            st = slab.solve(max_iters=full_iterations, tol=0.0)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
+        spmv_ms = 0.0
         for _ in range(steps):
-            st = slab.solve()
+            st = slab.solve(max_iters=full_iterations, tol=0.0)
+            spmv_ms += st.time_spmv_ms
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / steps * 1e3
-        it = st.iterations
+        rec = {"as_rank": r, "neighbours": (1 if r > 0 else 0) + (1 if r < P - 1 else 0), "row_offset": slab.row_offset, "rows": slab.n_local,
+               "halo_doubles": grid, "iterations": st.iterations, "ms_per_solve": ms, "us_per_iteration": ms / max(st.iterations, 1) * 1e3,
+               "spmv_us_per_launch": spmv_ms / steps / max(st.iterations, 1) * 1e3}
         slab.destroy()
-        return ms, it
+        return rec
 
     for P in (2, 4, 8):
-        n = int(round(math.sqrt(grid * grid / P)))
-        plain_ms, it = run(n, None)
-        saved = {k: os.environ.get(k) for k in ("SPMV_AMD_SELF_NEIGHBOUR", "SPMV_AMD_FORCE_COLLECTIVES")}
-        os.environ["SPMV_AMD_SELF_NEIGHBOUR"] = os.environ["SPMV_AMD_FORCE_COLLECTIVES"] = "1"
-        try:
-            comm = B.Comm.rccl(0, 1, B.Comm.unique_id())
-        finally:
-            for k, v in saved.items():
-                if v is None:
-                    os.environ.pop(k, None)
-                else:
-                    os.environ[k] = v
-        if comm is None:
-            out["slabs"].append({"gpus": P, "error": "RCCL communicator could not be created"})
-            continue
-        pipe_ms, it2 = run(n, comm)
-        comm.destroy()
-        projected = pipe_ms / it2 * full_iterations + 2 * full_iterations * out["assumed_allreduce_latency_us"] / 1e3
-        out["slabs"].append({"gpus": P, "slab_proxy_grid": n, "iterations": it, "plain_ms_per_solve": plain_ms, "pipeline_ms_per_solve": pipe_ms,
-                             "pipeline_overhead_us_per_iteration": (pipe_ms / it2 - plain_ms / it) * 1e3,
-                             "projected_ms_per_solve": projected, "projected_strong_scaling_efficiency": full_ms / (P * projected)})
+        ranks = sorted({0, min(P - 1, max(1, P // 2 - 1))})  # edge rank and (P > 2) one with two neighbours: 1 of 4, 3 of 8
+        roles = [run(P, r) for r in ranks]
+        slowest = max(v["ms_per_solve"] for v in roles)
+        eff = {f"{lat}us": full_ms / (P * (slowest + out["allreduces_per_solve"] * lat / 1e3)) for lat in (0, 10, 25, 50)}
+        out["slabs"].append({"gpus": P, "roles": roles, "slowest_role_ms_per_solve": slowest,
+                             "ideal_ms_per_solve": full_ms / P, "projected_efficiency_by_allreduce_latency": eff})
+    comm.destroy()
     return out
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with no RANK / WORLD_SIZE around: start the N ranks ourselves. Nothing in this
+    process imports torch or touches the GPU (a process that has initialised the GPU must not be replaced by or
+    turned into a launcher on this pool); the ranks are ordinary children, never an exec."""
+    n = args.gpus
+    port = free_port()
+    argv = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    procs = []
+    for rank in range(n):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SPMV_AMD_BENCH_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL's intra-node transport needs it on this host driver
+        env.setdefault("OMP_NUM_THREADS", "4")
+        # rank 0's stdout carries the JSON line; the other ranks have nothing to say there
+        procs.append(subprocess.Popen(argv, env=env, stdout=subprocess.PIPE if rank == 0 else sys.stderr.fileno()))
+    deadline = time.monotonic() + args.launch_timeout
+    failed_at = None
+    while any(p.poll() is None for p in procs):
+        time.sleep(0.2)
+        now = time.monotonic()
+        if failed_at is None and any(p.poll() not in (None, 0) for p in procs):
+            failed_at = now  # the other ranks notice through gloo / the solver's watchdog; give them a moment to report
+        if (failed_at is not None and now - failed_at > 90) or now > deadline:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()  # exactly the children started above
+            break
+    out0 = procs[0].stdout.read().decode(errors="replace") if procs[0].stdout else ""
+    codes = [p.wait() for p in procs]
+    lines = [l for l in out0.splitlines() if l.startswith("{")]
+    worst = max(codes, key=abs) if codes else 1
+    if lines:
+        sys.stdout.write(lines[-1] + "\n")
+    else:
+        reason = f"ranks exited with {codes} and rank 0 printed no result line" + (" (launcher deadline reached)" if time.monotonic() > deadline else "")
+        sys.stdout.write(json.dumps({"metric": "cg_iterations_per_second", "value": None, "unit": "CG iterations/s", "n_gpus": n,
+                                     "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": "strong",
+                                     "unmeasured": reason}) + "\n")
+        worst = worst or EXIT_UNMEASURED
+    sys.stdout.flush()
+    return worst
 
 
 def main():
@@ -190,9 +315,14 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-spmv", action="store_true", help="skip the N=1 SpMV headline leg")
     ap.add_argument("--no-scaling-probe", action="store_true", help="skip the N=1 one-GPU strong-scaling probe")
+    ap.add_argument("--no-ceiling", action="store_true", help="skip the in-run stream-ceiling probe")
+    ap.add_argument("--launch-timeout", type=float, default=1500.0, help="self-launch only: seconds before the parent ends the ranks")
     ap.add_argument("--scaling-probe-only", nargs=2, metavar=("FULL_MS", "FULL_ITERATIONS"), default=None,
                     help="(internal) run only the scaling probe and print its JSON object")
     args = ap.parse_args()
+
+    if args.scaling_probe_only is None and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args))
 
     # The library prints progress lines the way the reference harness does ("[stencil5-csr] Cleaning up", ...):
     # send everything written to fd 1 from here on to stderr and keep the real stdout for the one JSON line.
@@ -218,9 +348,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: running {world} rank(s)", file=sys.stderr)
         args.gpus = world
+
+    import datetime
 
     import torch  # first: libspmv_amd then shares the HIP runtime torch has loaded
     import torch.distributed as dist
@@ -234,51 +365,85 @@ def main():
     multi = world > 1 or os.environ.get("SPMV_AMD_BENCH_FORCE_DIST") == "1"
     if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=600))
         dist.barrier()
     L = B.lib()
-    B.require_gpu()
-    # SPMV_AMD_BENCH_DEVICE (test hook): put every rank on one device, so a 1-GPU box can walk the
-    # N > 1 control flow (RCCL refuses two ranks on one device -> the staged transport takes over)
-    device = int(os.environ.get("SPMV_AMD_BENCH_DEVICE", local_rank))
+
+    n = args.grid
+    rows, nnz = n * n, 5 * n * n - 4 * n
+    base = {"metric": "cg_iterations_per_second", "unit": "CG iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "higher_is_better": True, "scaling": "strong", "dtype": "f64", "data": "synthetic"}
+
+    def agree(ok, reason):
+        """All ranks learn whether every rank is fine; returns the first failing rank's reason, or None."""
+        if not multi:
+            return None if ok else reason
+        box = [None] * world
+        dist.all_gather_object(box, None if ok else f"rank {rank}: {reason}")
+        bad = [b for b in box if b is not None]
+        return "; ".join(bad) if bad else None
+
+    def give_up(reason):
+        """No measurement: say so on the one line the driver reads and leave with a non-zero status."""
+        if rank == 0:
+            print(f"bench.py: UNMEASURED -- {reason}", file=sys.stderr)
+            emit(dict(base, value=None, ms_per_step=None, vs_baseline=None, unmeasured=reason,
+                      config={"workload": f"CG on the {n}x{n} 5-point stencil, b=1, x0=0, tol 1e-6", "grid": n, "partition": f"{world} row slab(s)"}))
+        if multi:
+            try:
+                dist.barrier()
+                dist.destroy_process_group()
+            except Exception:
+                pass
+        sys.exit(EXIT_UNMEASURED)
+
+    # SPMV_AMD_BENCH_DEVICE (test hook): put every rank on one device, so a 1-GPU box can walk the N > 1 control flow
+    forced_device = os.environ.get("SPMV_AMD_BENCH_DEVICE")
+    device = int(forced_device) if forced_device is not None else local_rank
+    visible = L.spmv_amd_device_count()
+    why = agree(visible > device, f"device {device} wanted, {visible} HIP device(s) visible")
+    if why:
+        give_up(why)
     torch.cuda.set_device(device)
     L.spmv_amd_set_device(device)
+    dev_index, pci = B.current_device()
 
     def barrier():
         if multi:
             dist.barrier()
 
-    n = args.grid
-    rows, nnz = n * n, 5 * n * n - 4 * n
-
     spmv = None
     if world == 1 and not args.no_spmv:
         spmv = spmv_headline(B, n)
 
-    comm, transport = None, "single rank (no communicator)"
+    allow_staged = os.environ.get("SPMV_AMD_BENCH_ALLOW_STAGED") == "1"
+    comm, transport, degraded = None, "single rank (no communicator)", None
     if multi:
         box = [B.Comm.unique_id() if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
         comm = B.Comm.rccl(rank, world, box[0])
-        # every rank must have its RCCL communicators and pass the collective self-test (all-reduce,
-        # neighbour send/recv, barrier); otherwise all ranks switch together to the staged transport
-        ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32)
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if int(ok[0]) == 1:
-            ok = torch.tensor([1 if comm.selftest() == 0 else 0], dtype=torch.int32)
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if int(ok[0]) == 1:
+        # every rank must have its RCCL communicators, see all `world` ranks in them and pass the collective
+        # self-test (all-reduce, neighbour send/recv, loopback on a side stream, barrier)
+        why = agree(comm is not None, "RCCL communicator creation failed (see the [comm/rccl] line on stderr)")
+        if why is None:
+            got = comm.transport_ranks()
+            why = agree(got == world, f"RCCL communicators span {got} rank(s), {world} wanted")
+        if why is None:
+            why = agree(comm.selftest() == 0, "RCCL self-test (all-reduce / neighbour send-recv / barrier) returned wrong data")
+        if why is None:
             transport = "rccl"
-        else:
+        elif allow_staged:
             if comm is not None:
                 comm.destroy()
             comm = B.Comm.staged_over_torch(rank, world, dist)
-            transport = "staged over torch.distributed/gloo (RCCL unavailable on this node)"
+            transport = "staged over torch.distributed/gloo"
+            degraded = f"host-staged transport instead of RCCL (SPMV_AMD_BENCH_ALLOW_STAGED=1): {why}"
             if rank == 0:
-                print("bench.py: RCCL communicator unusable, using the host-staged transport", file=sys.stderr)
+                print(f"bench.py: {degraded}", file=sys.stderr)
+        else:
+            give_up(f"RCCL unusable, and the host-staged transport is not a substitute for the headline number: {why}")
     slab = B.CgSlab.stencil5(n, comm)
 
-    iterations = None
     for _ in range(args.warmup):
         st = slab.solve()
     barrier()
@@ -298,8 +463,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t[0])
     hist = slab.history()
-    kernel_name = {"stencil5/row-lds": "stencil5_rowlds_kernel<true>", "stencil5/row-direct": "stencil5_rowdirect_kernel<1, true>"}.get(
-        slab.variant(), slab.variant()) + " (SpMV + p.Ap partials)"
+    kernel_symbol = {"stencil5/row-lds": "stencil5_rowlds_kernel<true>", "stencil5/row-direct": "stencil5_rowdirect_kernel<1, true>"}.get(
+        slab.variant(), slab.variant())
 
     # dominant kernel: STENCIL5 SpMV of this rank's slab, average over the launches of the timed steps
     local_rows, local_nnz = slab.n_local, slab.local_nnz if slab.local_nnz > 0 else None
@@ -308,37 +473,60 @@ def main():
     alg_bytes = 8 * local_nnz + 8 * local_rows + 8 * local_rows
     avg_spmv_ms = spmv_ms / max(spmv_launches, 1)
     achieved = alg_bytes / (avg_spmv_ms / 1e3) / 1e9 if avg_spmv_ms > 0 else 0.0
-    traffic = None
+    # fabric bytes per launch from the committed PMC passes -- only if they were taken on THIS kernel source
+    traffic, traffic_note = None, None
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    if os.path.exists(tpath):
-        try:
-            rec = json.load(open(tpath))
-            if rec.get("grid") == n and rec.get("n_gpus") == world:
-                traffic = rec.get("bytes_per_launch")  # measured with rocprofv3 --pmc, see the file's "source"
-        except (OSError, ValueError):
-            pass
+    try:
+        rec = json.load(open(tpath))
+        source_hash = hashlib.sha256(open(KERNEL_SOURCE, "rb").read()).hexdigest()
+        if rec.get("grid") != n or rec.get("n_gpus") != world or rec.get("kernel") != kernel_symbol:
+            traffic_note = "profiles/hbm_traffic.json holds another configuration or kernel: traffic not reported"
+        elif rec.get("kernel_source_sha256") != source_hash:
+            traffic_note = "profiles/hbm_traffic.json is stale (csrc/spmv_kernels.hip changed since the PMC passes): traffic not reported"
+        else:
+            traffic = rec.get("bytes_per_launch")
+            traffic_note = ("L2-to-fabric bytes per launch from separate rocprofv3 --pmc passes (profiles/hbm_traffic.json, taken on this "
+                            "kernel source); Infinity-Cache hits included")
+    except (OSError, ValueError):
+        traffic_note = "no profiles/hbm_traffic.json"
     roofline = {
-        "bound": "hbm", "kernel": kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS,
+        "bound": "hbm", "kernel": kernel_symbol + " (SpMV + p.Ap partials)", "achieved": achieved, "peak": HBM_PEAK_GBS,
         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
-        "avg_launch_ms": avg_spmv_ms, "launches_timed": spmv_launches,
-        "traffic_note": "L2-to-fabric bytes per launch from separate rocprofv3 --pmc passes (profiles/hbm_traffic.json); Infinity-Cache hits included" if traffic else None,
+        "avg_launch_ms": avg_spmv_ms, "launches_timed": spmv_launches, "traffic_note": traffic_note,
     }
+    if rank == 0 and not args.no_ceiling and local_rows >= 1_000_000:
+        try:
+            ceil = stream_ceiling(B, rows=min(200_000_000, local_rows))
+            roofline["ceiling_measured"] = ceil["gbs"]
+            roofline["frac_of_ceiling"] = achieved / ceil["gbs"]
+            roofline["ceiling_probe"] = ceil
+        except Exception as e:
+            roofline["ceiling_probe"] = {"error": repr(e)}
+
+    devices = [{"rank": rank, "device": dev_index, "pci_bus_id": pci}]
+    if multi:
+        box = [None] * world
+        dist.all_gather_object(box, devices[0])
+        devices = box
+    rccl_ranks = comm.transport_ranks() if (comm is not None and transport == "rccl") else 0
 
     out = None
     if rank == 0:
         value = args.steps * iterations / dt
-        out = {
-            "metric": "cg_iterations_per_second", "value": value, "unit": "CG iterations/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": value / A100_CG_ITERS_PER_S[world] if world in A100_CG_ITERS_PER_S and n == 20000 else None,
-            "baseline_note": "reference's published CG iters/s on the same problem at the same GPU count, A100-SXM4-80GB (BASELINE.md); no MI355X number is published",
-            "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"CG on the {n}x{n} 5-point stencil ({rows} unknowns, {nnz} nnz), b=1, x0=0, tol 1e-6",
-                       "grid": n, "unknowns": rows, "nnz": nnz, "partition": f"{world} row slab(s)", "transport": transport,
-                       "iterations_per_solve": iterations, "converged": bool(st.converged), "final_residual": st.residual_norm,
-                       "residual_history": [float(v) for v in hist]},
-            "roofline": roofline,
-        }
+        headline = world in A100_CG_ITERS_PER_S and n == 20000 and degraded is None
+        out = dict(base, value=value, ms_per_step=dt / args.steps * 1e3,
+                   vs_baseline=value / A100_CG_ITERS_PER_S[world] if headline else None,
+                   baseline_note="reference's published CG iters/s on the same problem at the same GPU count, A100-SXM4-80GB (BASELINE.md); no MI355X number is published",
+                   config={"workload": f"CG on the {n}x{n} 5-point stencil ({rows} unknowns, {nnz} nnz), b=1, x0=0, tol 1e-6",
+                           "grid": n, "unknowns": rows, "nnz": nnz, "partition": f"{world} row slab(s)", "transport": transport,
+                           "iterations_per_solve": iterations, "converged": bool(st.converged), "final_residual": st.residual_norm,
+                           "residual_history": [float(v) for v in hist]},
+                   transport=transport, rccl_ranks=rccl_ranks, devices=devices,
+                   launched_by="bench.py (self-launched ranks)" if os.environ.get("SPMV_AMD_BENCH_SELF_LAUNCHED") == "1" else
+                   ("external launcher (RANK/WORLD_SIZE in the environment)" if "RANK" in os.environ else "single process"),
+                   roofline=roofline)
+        if degraded:
+            out["degraded"] = degraded
         if spmv is not None:
             out["spmv"] = spmv
     slab.destroy()
@@ -347,7 +535,6 @@ def main():
 
     if rank == 0 and world == 1 and not multi and not args.no_scaling_probe and n >= 8192:
         # evidence only, in a child process: whatever happens to it, the benchmark line above is printed
-        import subprocess
         try:
             child = subprocess.run([sys.executable, os.path.abspath(__file__), "--grid", str(n), "--scaling-probe-only",
                                     repr(out["ms_per_step"]), str(iterations)], capture_output=True, text=True, timeout=600)

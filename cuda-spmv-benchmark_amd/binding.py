@@ -83,12 +83,13 @@ DECLARED_SYMBOLS = [
     "cg_benchmark_with_stats_mgpu_partitioned", "export_cg_json", "export_cg_mgpu_json", "export_cg_csv",
     "spmv_amd_build_csr_struct", "spmv_amd_build_ellpack_from_csr_struct", "spmv_amd_cg_solve", "spmv_amd_cg_solve_device",
     "spmv_amd_cg_solve_mgpu_partitioned", "spmv_amd_reset_host_matrices", "spmv_amd_interior_csr_offset",
-    "spmv_amd_partition_rows", "spmv_amd_device_count", "spmv_amd_set_device", "spmv_amd_device_alloc", "spmv_amd_device_free",
+    "spmv_amd_partition_rows", "spmv_amd_device_count", "spmv_amd_set_device", "spmv_amd_current_device", "spmv_amd_stream_ceiling", "spmv_amd_device_alloc", "spmv_amd_device_free",
     "spmv_amd_copy_to_device", "spmv_amd_copy_to_host", "spmv_amd_device_fill_f64", "spmv_amd_device_synchronize",
     "spmv_amd_init_stencil5_synthetic", "spmv_amd_ellpack_run_device_scaled", "spmv_amd_download_device_csr", "spmv_amd_time_run_device", "spmv_amd_operator_variant",
     "spmv_amd_operator_select_variant", "spmv_amd_cg_last_history", "spmv_amd_comm_unique_id", "spmv_amd_comm_create_rccl",
     "spmv_amd_comm_create_staged", "spmv_amd_comm_destroy", "spmv_amd_comm_set_world", "spmv_amd_comm_rank", "spmv_amd_comm_size", "spmv_amd_comm_selftest",
-    "spmv_amd_cg_slab_create", "spmv_amd_cg_slab_create_stencil5", "spmv_amd_cg_slab_set_vectors", "spmv_amd_cg_slab_solve",
+    "spmv_amd_comm_barrier", "spmv_amd_comm_transport", "spmv_amd_comm_transport_ranks",
+    "spmv_amd_cg_slab_create", "spmv_amd_cg_slab_create_stencil5", "spmv_amd_cg_slab_create_stencil5_as", "spmv_amd_cg_slab_set_vectors", "spmv_amd_cg_slab_solve",
     "spmv_amd_cg_slab_gather", "spmv_amd_cg_slab_history", "spmv_amd_cg_slab_spmv", "spmv_amd_cg_slab_info",
     "spmv_amd_cg_slab_time_spmv", "spmv_amd_cg_slab_variant", "spmv_amd_cg_slab_destroy", "spmv_amd_version", "spmv_amd_write_stencil5_values",
 ]
@@ -107,7 +108,9 @@ def build(force=False):
     """Compiles libspmv_amd.so for gfx950 with hipcc (cross-compiles without a GPU)."""
     if force:
         subprocess.check_call(["make", "-C", PKG_DIR, "clean"], stdout=subprocess.DEVNULL)
-    subprocess.check_call(["make", "-C", PKG_DIR, "-j8"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    done = subprocess.run(["make", "-C", PKG_DIR, "-j8"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if done.returncode != 0:
+        raise RuntimeError(f"building libspmv_amd.so failed (make exit {done.returncode}); compiler output:\n{done.stdout[-8000:]}")
     if not os.path.exists(LIB_PATH):
         raise RuntimeError("libspmv_amd.so was not produced by the build")
 
@@ -132,6 +135,9 @@ def lib():
     L.spmv_amd_device_alloc.restype = C.c_void_p
     L.spmv_amd_device_alloc.argtypes = [C.c_size_t]
     L.spmv_amd_device_free.argtypes = [C.c_void_p]
+    L.spmv_amd_current_device.argtypes = [C.c_char_p, C.c_int]
+    L.spmv_amd_stream_ceiling.restype = C.c_double
+    L.spmv_amd_stream_ceiling.argtypes = [C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_float)]
     L.spmv_amd_copy_to_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     L.spmv_amd_copy_to_host.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     L.spmv_amd_device_fill_f64.argtypes = [C.c_void_p, C.c_size_t, C.c_double]
@@ -153,6 +159,12 @@ def lib():
     L.spmv_amd_comm_rank.argtypes = [C.c_void_p]
     L.spmv_amd_comm_size.argtypes = [C.c_void_p]
     L.spmv_amd_comm_selftest.argtypes = [C.c_void_p]
+    L.spmv_amd_comm_barrier.argtypes = [C.c_void_p]
+    L.spmv_amd_comm_transport.restype = C.c_char_p
+    L.spmv_amd_comm_transport.argtypes = [C.c_void_p]
+    L.spmv_amd_comm_transport_ranks.argtypes = [C.c_void_p]
+    L.spmv_amd_cg_slab_create_stencil5_as.restype = C.c_void_p
+    L.spmv_amd_cg_slab_create_stencil5_as.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p]
     L.spmv_amd_cg_slab_create.restype = C.c_void_p
     L.spmv_amd_cg_slab_create.argtypes = [C.POINTER(MatrixData), C.c_void_p]
     L.spmv_amd_cg_slab_create_stencil5.restype = C.c_void_p
@@ -180,6 +192,23 @@ def lib():
 def require_gpu():
     if lib().spmv_amd_device_count() < 1:
         raise RuntimeError("no HIP device visible: libspmv_amd has no CPU path")
+
+
+def current_device():
+    """(device index, PCI bus id) of the calling thread's current HIP device."""
+    buf = C.create_string_buffer(64)
+    dev = lib().spmv_amd_current_device(buf, 64)
+    return dev, buf.value.decode()
+
+
+def stream_ceiling(rows, warmup=3, reps=20):
+    """Per-launch milliseconds and bytes of the 48:8 stream probe (csrc/stream_ceiling.hip)."""
+    require_gpu()
+    ms = (C.c_float * reps)()
+    nbytes = lib().spmv_amd_stream_ceiling(int(rows), int(warmup), int(reps), ms)
+    if nbytes <= 0:
+        raise RuntimeError("spmv_amd_stream_ceiling failed")
+    return np.array(ms[:], dtype=np.float64), nbytes
 
 
 def csr_mat():
@@ -410,6 +439,16 @@ class Comm:
     def selftest(self):
         return lib().spmv_amd_comm_selftest(self.handle)
 
+    def barrier(self):
+        return lib().spmv_amd_comm_barrier(self.handle)
+
+    def transport(self):
+        return lib().spmv_amd_comm_transport(self.handle).decode()
+
+    def transport_ranks(self):
+        """Ranks the device transport itself reports (ncclCommCount); 0 for staged / self."""
+        return lib().spmv_amd_comm_transport_ranks(self.handle)
+
     @classmethod
     def staged(cls, rank, world, halo, allreduce, gather=None, barrier=None):
         cbs = (HALO_FN(halo), ALLREDUCE_FN(allreduce), GATHER_FN(gather) if gather else GATHER_FN(), BARRIER_FN(barrier) if barrier else BARRIER_FN())
@@ -451,6 +490,12 @@ class CgSlab:
     def stencil5(cls, n, comm=None):
         require_gpu()
         return cls(lib().spmv_amd_cg_slab_create_stencil5(int(n), comm.handle if comm else None), n * n)
+
+    @classmethod
+    def stencil5_as(cls, n, as_rank, as_world, comm):
+        """The slab rank `as_rank` of an `as_world`-GPU run would own, on a single self-neighbour rank (timing only)."""
+        require_gpu()
+        return cls(lib().spmv_amd_cg_slab_create_stencil5_as(int(n), int(as_rank), int(as_world), comm.handle), n * n)
 
     def set_vectors(self, b=None, x0=None):
         b = None if b is None else np.ascontiguousarray(b, dtype=np.float64)

@@ -136,9 +136,12 @@ __global__ __launch_bounds__(kStream) void dot_partials_kernel(size_t n, const d
 }
 
 // Single block: thread t sums partials t, t+256, ... then a 256-wide tree in LDS.
+// host_progress (may be null): an int in host-coherent pinned memory that receives progress_value once the sum
+// is stored -- the solver's watchdog reads it to say how far the GPU got when a rank stops making progress.
 __global__ __launch_bounds__(kBlock) void reduce_partials_kernel(const double* __restrict__ partials,
                                                                  int count, double* __restrict__ out,
-                                                                 const int* __restrict__ skip_flag) {
+                                                                 const int* __restrict__ skip_flag,
+                                                                 int* host_progress, int progress_value) {
     __shared__ double s[kBlock];
     if (skip_flag != nullptr && *skip_flag != 0) return;
     double acc = 0.0;
@@ -149,7 +152,11 @@ __global__ __launch_bounds__(kBlock) void reduce_partials_kernel(const double* _
         if ((int)threadIdx.x < stride) s[threadIdx.x] += s[threadIdx.x + stride];
         __syncthreads();
     }
-    if (threadIdx.x == 0) *out = s[0];
+    if (threadIdx.x == 0) {
+        *out = s[0];
+        if (host_progress != nullptr)
+            __hip_atomic_store(host_progress, progress_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // Stage one of a wide reduction: block b sums the contiguous slice [b*slice, (b+1)*slice) of the
@@ -554,7 +561,7 @@ static bool reduce_in_two_launches() {
 }
 
 void launch_reduce_partials(const double* partials, int count, double* d_out, const int* d_skip_flag,
-                            hipStream_t stream, double* stage) {
+                            hipStream_t stream, double* stage, int* host_progress, int progress_value) {
     // One block walking tens of thousands of partials is latency-bound (0.3 ms for 200k on MI355X);
     // with a stage buffer the sum is split over kReduceStageBlocks blocks first, in one launch whose
     // last-finishing block adds the stage values. Both shapes are fixed.
@@ -565,7 +572,7 @@ void launch_reduce_partials(const double* partials, int count, double* d_out, co
             hipLaunchKernelGGL(reduce_slices_kernel, dim3(blocks), dim3(kBlock), 0, stream, partials, count, slice,
                                stage, d_skip_flag);
             hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(kBlock), 0, stream, stage, blocks, d_out,
-                               d_skip_flag);
+                               d_skip_flag, host_progress, progress_value);
             return;
         }
         hipLaunchKernelGGL(reduce_fused_kernel, dim3(blocks), dim3(kBlock), 0, stream, partials, count, slice, stage,
@@ -574,7 +581,7 @@ void launch_reduce_partials(const double* partials, int count, double* d_out, co
         return;
     }
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(kBlock), 0, stream, partials, count, d_out,
-                       d_skip_flag);
+                       d_skip_flag, host_progress, progress_value);
 }
 
 void launch_reduce_partials_and_step(const double* partials, int count, double* d_out, const int* d_skip_flag,

@@ -31,6 +31,7 @@
 #include "comm.hpp"
 #include "device_runtime.hpp"
 #include "stencil_geometry.hpp"
+#include "watchdog.hpp"
 
 using namespace spmv_amd;
 
@@ -40,6 +41,10 @@ std::vector<double>& last_cg_history();
 
 struct SpmvAmdCgSlab {
     SpmvAmdComm* comm = nullptr;
+    // Which slab of how many this is. Equal to the communicator's rank / world, except for a stand-in slab
+    // (spmv_amd_cg_slab_create_stencil5_as): one self-neighbour rank carrying the slab of rank `part_rank` of a
+    // `part_world`-GPU job, so that one GPU can time the real per-rank slab shapes.
+    int part_rank = 0, part_world = 1;
     int n = 0, grid = -1, row_offset = 0, n_local = 0, halo = 0;
     bool has_prev = false, has_next = false;
     DeviceCsr A;
@@ -63,7 +68,13 @@ struct SpmvAmdCgSlab {
     CgScalars* d_s = nullptr;
     double* d_hist = nullptr;
     int hist_cap = 0;
-    struct Poll { int sequence; int converged; int iterations; int pad; }* h_poll = nullptr;  // pinned, host-coherent
+    // pinned, host-coherent. progress = 4 * sequence + k, written by the last block of the local reductions of the
+    // iteration that will publish `sequence`: k = 1 local p.Ap summed, k = 2 local r.r summed (watchdog report only)
+    struct Poll { int sequence; int converged; int iterations; int progress; }* h_poll = nullptr;
+    int* spmv_progress = nullptr;  // where the p.Ap reduction of the SpMV being enqueued reports (in-loop SpMVs only)
+    int spmv_progress_value = 0;
+    const char* enqueued_stage = "";  // the last piece of work the host put on the streams
+    int enqueued_iteration = -1;
     hipStream_t compute = nullptr, side = nullptr;
     hipEvent_t ev_p_ready = nullptr, ev_halo_done = nullptr;
     LaunchShape shape;
@@ -94,8 +105,12 @@ namespace {
 
 void make_common(SpmvAmdCgSlab* s) {
     const size_t nl = (size_t)s->n_local;
-    s->has_prev = s->comm->rank > 0 || s->comm->self_neighbour;
-    s->has_next = s->comm->rank < s->comm->world - 1 || s->comm->self_neighbour;
+    // A self-neighbour rank that owns the WHOLE grid (part_world == 1) keeps halos on both sides: the rows that would
+    // read them are the first and last grid row of the global grid, which have no north / south entry, so the
+    // full pipeline runs and the solve must still reproduce the plain one (tests/test_distributed.py).
+    const bool whole_grid_probe = s->comm->self_neighbour && s->part_world == 1;
+    s->has_prev = s->comm->exchanges_halos() && (s->part_rank > 0 || whole_grid_probe);
+    s->has_next = s->comm->exchanges_halos() && (s->part_rank < s->part_world - 1 || whole_grid_probe);
     s->halo = s->comm->exchanges_halos() ? s->grid : 0;
     s->A.view.halo_before = s->has_prev ? s->halo : 0;
     s->A.view.halo_after = s->has_next ? s->halo : 0;
@@ -262,19 +277,51 @@ void slab_spmv(SpmvAmdCgSlab* s, bool with_dot, bool overlap, const int* skip,
     if (spmv_done) HIP_CHECK(hipEventRecord(spmv_done, s->compute));
     if (with_dot) {
         if (part)
-            launch_reduce_partials(part, used, &s->d_s->pAp, skip, s->compute, s->reduce_stage);
+            launch_reduce_partials(part, used, &s->d_s->pAp, skip, s->compute, s->reduce_stage, s->spmv_progress,
+                                   s->spmv_progress_value);
         else
             launch_dot((size_t)s->n_local, s->p, s->Ap, s->partials_blas, &s->d_s->pAp, s->compute);
     }
 }
 
-// Blocks the host until the scalar step of the iteration just enqueued has published its record.
+const char* query_name(hipError_t e) {
+    return e == hipSuccess ? "idle (all work done)" : e == hipErrorNotReady ? "busy (work pending)" : hipGetErrorString(e);
+}
+
+// What the watchdog prints about a slab whose rank stopped making progress. Runs on the watchdog's thread;
+// queries only.
+void report_slab_state(void* user, FILE* out) {
+    const SpmvAmdCgSlab* s = static_cast<const SpmvAmdCgSlab*>(user);
+    const int seq = __atomic_load_n(&s->h_poll->sequence, __ATOMIC_ACQUIRE);
+    const int prog = __atomic_load_n(&s->h_poll->progress, __ATOMIC_ACQUIRE);
+    fprintf(out, "[cg-slab] rank %d (slab %d of %d, rows [%d, %d)): last work enqueued by the host: %s of iteration %d\n",
+            s->comm->rank, s->part_rank, s->part_world, s->row_offset, s->row_offset + s->n_local, s->enqueued_stage,
+            s->enqueued_iteration);
+    fprintf(out, "[cg-slab] status records: waiting for #%d, GPU has published #%d (iterations counted %d, converged %d)\n",
+            s->poll_sequence, seq, s->h_poll->iterations, s->h_poll->converged);
+    const char* where = "before the local p.Ap sum: in the SpMV, or waiting for the halo rows (see the events below)";
+    if (prog == 4 * s->poll_sequence + 1)
+        where = "local p.Ap summed: in the all-reduce of p.Ap, the r update or the local r.r sum";
+    else if (prog == 4 * s->poll_sequence + 2)
+        where = "local r.r summed: in the all-reduce of r.r or the scalar step";
+    if (seq != s->poll_sequence) fprintf(out, "[cg-slab] GPU progress inside that iteration: %s\n", where);
+    fprintf(out, "[cg-slab] compute stream: %s; side (halo) stream: %s\n", query_name(hipStreamQuery(s->compute)),
+            query_name(hipStreamQuery(s->side)));
+    fprintf(out, "[cg-slab] event 'direction vector ready for the halo exchange': %s; event 'halo rows received': %s\n",
+            query_name(hipEventQuery(s->ev_p_ready)), query_name(hipEventQuery(s->ev_halo_done)));
+    s->comm->describe(out);
+}
+
+// Blocks the host until the scalar step of the iteration just enqueued has published its record. Bounded by
+// the watchdog (SPMV_AMD_WATCHDOG_S): a rank whose peers never answer ends with a report, not a hang.
 void wait_for_status(SpmvAmdCgSlab* s) {
+    WatchdogScope guard("waiting for the iteration's status record", s->comm->rank, s->enqueued_iteration,
+                        report_slab_state, s);
     volatile int* seq = &s->h_poll->sequence;
     long spins = 0;
     while (__atomic_load_n(seq, __ATOMIC_ACQUIRE) != s->poll_sequence) {
         if (++spins % (1L << 22) == 0) {
-            // nothing should take this long: surface a faulted or wedged stream instead of spinning for ever
+            // surface a faulted stream at once instead of waiting for the watchdog
             const hipError_t e = hipStreamQuery(s->compute);
             if (e != hipSuccess && e != hipErrorNotReady) HIP_CHECK(e);
             if (e == hipSuccess && __atomic_load_n(seq, __ATOMIC_ACQUIRE) != s->poll_sequence) {
@@ -289,7 +336,15 @@ void wait_for_status(SpmvAmdCgSlab* s) {
 // into [v - halo, v) and [v + n_local, v + n_local + halo).
 void exchange_halo(SpmvAmdCgSlab* s, double* v, hipStream_t stream) {
     if (!s->comm->exchanges_halos()) return;
-    s->comm->halo_exchange(v, v + (s->n_local - s->halo), v - s->halo, v + s->n_local, s->halo, stream);
+    // a staged transport blocks in here on its host exchange, RCCL may block while it connects peers
+    WatchdogScope guard("halo exchange (send/recv of the first and last grid row)", s->comm->rank, s->enqueued_iteration,
+                        report_slab_state, s);
+    s->comm->halo_exchange(s->has_prev ? v : nullptr, s->has_next ? v + (s->n_local - s->halo) : nullptr,
+                           s->has_prev ? v - s->halo : nullptr, s->has_next ? v + s->n_local : nullptr, s->halo, stream);
+}
+void allreduce_scalar(SpmvAmdCgSlab* s, double* d_value, const char* stage) {
+    WatchdogScope guard(stage, s->comm->rank, s->enqueued_iteration, report_slab_state, s);
+    s->comm->allreduce_sum(d_value, 1, s->compute);
 }
 void exchange_p_halo(SpmvAmdCgSlab* s, hipStream_t stream) { exchange_halo(s, s->p, stream); }
 
@@ -308,6 +363,8 @@ extern "C" SpmvAmdCgSlab* spmv_amd_cg_slab_create(MatrixData* mat, SpmvAmdComm* 
     if (build_csr_struct(mat) != EXIT_SUCCESS) return nullptr;
     SpmvAmdCgSlab* s = new SpmvAmdCgSlab();
     s->comm = comm;
+    s->part_rank = comm->rank;
+    s->part_world = comm->world;
     s->n = mat->rows;
     s->grid = mat->grid_size;
     s->row_offset = row_offset;
@@ -317,17 +374,19 @@ extern "C" SpmvAmdCgSlab* spmv_amd_cg_slab_create(MatrixData* mat, SpmvAmdComm* 
     return s;
 }
 
-extern "C" SpmvAmdCgSlab* spmv_amd_cg_slab_create_stencil5(int n, SpmvAmdComm* comm) {
-    if (comm == nullptr) comm = self_comm();
+namespace {
+SpmvAmdCgSlab* create_stencil5_slab(int n, int part_rank, int part_world, SpmvAmdComm* comm) {
     if (n < 2 || (long long)n * n > 0x7fffffffLL || 5LL * n * n - 4LL * n > 0x7fffffffLL) {
         fprintf(stderr, "[cg-slab] grid %d does not fit 32-bit CSR indices\n", n);
         return nullptr;
     }
     int row_offset = 0, n_local = 0;
-    spmv_amd_partition_rows(n * n, comm->world, comm->rank, &row_offset, &n_local);
+    spmv_amd_partition_rows(n * n, part_world, part_rank, &row_offset, &n_local);
     if (!partition_ok(comm, n * n, n, n_local)) return nullptr;
     SpmvAmdCgSlab* s = new SpmvAmdCgSlab();
     s->comm = comm;
+    s->part_rank = part_rank;
+    s->part_world = part_world;
     s->n = n * n;
     s->grid = n;
     s->row_offset = row_offset;
@@ -336,6 +395,26 @@ extern "C" SpmvAmdCgSlab* spmv_amd_cg_slab_create_stencil5(int n, SpmvAmdComm* c
     HIP_CHECK(hipStreamSynchronize(nullptr));
     make_common(s);
     return s;
+}
+}  // namespace
+
+extern "C" SpmvAmdCgSlab* spmv_amd_cg_slab_create_stencil5(int n, SpmvAmdComm* comm) {
+    if (comm == nullptr) comm = self_comm();
+    return create_stencil5_slab(n, comm->rank, comm->world, comm);
+}
+
+// Stand-in slab for measurements on one GPU: the slab rank `as_rank` of an `as_world`-GPU job would own (same
+// rows, same CSR bytes, same halo length, neighbours on the same sides), carried by a single-rank communicator
+// created under SPMV_AMD_SELF_NEIGHBOUR=1, which exchanges the halo rows with itself through the transport's own
+// send / recv path. The numbers it produces are those of a slab whose north / south neighbours are its own last /
+// first grid row (a periodic strip): a different linear system with the same work per iteration. Timing only.
+extern "C" SpmvAmdCgSlab* spmv_amd_cg_slab_create_stencil5_as(int n, int as_rank, int as_world, SpmvAmdComm* comm) {
+    if (comm == nullptr || comm->world != 1 || (as_world > 1 && !comm->self_neighbour)) {
+        fprintf(stderr, "[cg-slab] a stand-in slab needs a single-rank self-neighbour communicator\n");
+        return nullptr;
+    }
+    if (as_world < 1 || as_rank < 0 || as_rank >= as_world) return nullptr;
+    return create_stencil5_slab(n, as_rank, as_world, comm);
 }
 
 extern "C" int spmv_amd_cg_slab_set_vectors(SpmvAmdCgSlab* s, const double* b_full,
@@ -381,6 +460,8 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
         part.begin(s->compute);
         work();
         part.end(s->compute);
+        WatchdogScope guard("detailed timers: waiting for the stage just enqueued", comm->rank, s->enqueued_iteration,
+                            report_slab_state, s);
         const double ms = part.elapsed_ms();
         if (bucket) *bucket += ms;
         if (bucket2) *bucket2 += ms;
@@ -392,7 +473,12 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
     for (int k = 0; k < kMaxRingSlots; ++k) ring_view.p[k] = s->ring[(size_t)k % s->ring.size()];
     int window_start = 0;  // first iteration whose alpha_k p_k is not in x yet (ring mode)
 
-    comm->barrier();
+    s->enqueued_stage = "barrier before the timed region";
+    s->enqueued_iteration = -1;
+    {
+        WatchdogScope guard("barrier before the timed region", comm->rank, -1, report_slab_state, s);
+        comm->barrier(s->compute);
+    }
     total.begin(s->compute);
 
     // ---- r0 = b - A x0 ; p0 = r0 ; rr0 ----
@@ -405,7 +491,8 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
     timed(&stats->time_dot_rs_initial_ms, nullptr, [&] {
         launch_reduce_partials(s->partials_blas, cg_partial_count(nl), &s->d_s->rr_new, nullptr, s->compute, s->reduce_stage);
     });
-    if (reduce) comm->allreduce_sum(&s->d_s->rr_new, 1, s->compute);
+    s->enqueued_stage = "initial residual";
+    if (reduce) allreduce_scalar(s, &s->d_s->rr_new, "all-reduce of the initial r.r");
     launch_cg_scalars_init(s->d_s, s->d_hist, s->compute);
     bool halo_in_flight = false;
     auto start_p_halo = [&] {  // halo rows of the new p: side stream, under the interior SpMV
@@ -434,6 +521,10 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
         // direction flips every iteration, so every kernel starts where the previous one ended
         const bool backward = s->pingpong && (enqueued & 1) == 0;  // iteration 0 follows the forward initial-residual pass
         s->shape.reverse = backward;
+        s->enqueued_iteration = enqueued;
+        s->enqueued_stage = "SpMV";
+        s->spmv_progress = &s->h_poll->progress;
+        s->spmv_progress_value = 4 * (s->poll_sequence + 1) + 1;
         if (detail) {
             timed(&stats->time_spmv_ms, nullptr, [&] { slab_spmv(s, true, halo_in_flight, skip); });
         } else {
@@ -452,7 +543,10 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
                 slab_spmv(s, true, halo_in_flight, skip);
             }
         }
-        if (reduce) timed(&stats->time_allreduce_ms, nullptr, [&] { comm->allreduce_sum(&s->d_s->pAp, 1, s->compute); });
+        s->spmv_progress = nullptr;
+        s->enqueued_stage = "all-reduce of p.Ap";
+        if (reduce) timed(&stats->time_allreduce_ms, nullptr, [&] { allreduce_scalar(s, &s->d_s->pAp, "all-reduce of p.Ap"); });
+        s->enqueued_stage = "r update";
         timed(&stats->time_blas1_ms, &stats->time_axpy_update_r_ms, [&] {
             launch_cg_update_r(nl, s->d_s, s->Ap, s->r, s->partials_blas, s->compute, s->pingpong && !backward);
         });
@@ -462,9 +556,11 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
         ++s->poll_sequence;
         if (reduce) {
             timed(&stats->time_reductions_ms, &stats->time_dot_rs_new_ms, [&] {
-                launch_reduce_partials(s->partials_blas, cg_partial_count(nl), &s->d_s->rr_new, skip, s->compute, s->reduce_stage);
+                launch_reduce_partials(s->partials_blas, cg_partial_count(nl), &s->d_s->rr_new, skip, s->compute, s->reduce_stage,
+                                       &s->h_poll->progress, 4 * s->poll_sequence + 2);
             });
-            timed(&stats->time_allreduce_ms, nullptr, [&] { comm->allreduce_sum(&s->d_s->rr_new, 1, s->compute); });
+            s->enqueued_stage = "all-reduce of r.r";
+            timed(&stats->time_allreduce_ms, nullptr, [&] { allreduce_scalar(s, &s->d_s->rr_new, "all-reduce of r.r"); });
             launch_cg_scalars_step(s->d_s, config->tolerance, s->d_hist, &s->h_poll->sequence, s->poll_sequence,
                                    s->compute, s->d_alpha_ring, slots);
         } else {
@@ -498,6 +594,7 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
             });
             s->p = p_next;
         }
+        s->enqueued_stage = "direction update and halo exchange";
         start_p_halo();
         wait_for_status(s);
         if (s->h_poll->converged) done = true;
@@ -518,8 +615,12 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
     if (enqueued == 0)  // no iteration ran (max_iters == 0): the solution is the initial guess
         HIP_CHECK(hipMemcpyAsync(s->x, s->x0, vbytes, hipMemcpyDeviceToDevice, s->compute));
     total.end(s->compute);
-    const float total_ms = total.elapsed_ms();
-    HIP_CHECK(hipStreamSynchronize(s->side));
+    float total_ms = 0.f;
+    {
+        WatchdogScope guard("draining the streams after the loop", comm->rank, enqueued, report_slab_state, s);
+        total_ms = total.elapsed_ms();
+        HIP_CHECK(hipStreamSynchronize(s->side));
+    }
     HIP_CHECK(hipGetLastError());
 
     CgScalars fin;
@@ -563,6 +664,7 @@ extern "C" int spmv_amd_cg_slab_gather(SpmvAmdCgSlab* s, double* x_full) {
     HIP_CHECK(hipStreamSynchronize(s->compute));
     if (s->comm->rank != 0)  // non-root ranks keep their own slab in place, like the reference (:831-833)
         download(x_full + s->row_offset, s->x, (size_t)s->n_local);
+    WatchdogScope guard("gathering the solution on rank 0", s->comm->rank, -1, report_slab_state, s);
     s->comm->gather_to_root(s->x, s->n_local, x_full, counts.data(), displs.data());
     return 0;
 }
@@ -674,8 +776,11 @@ int cg_solve_mgpu_partitioned(SpmvOperator* spmv_op, MatrixData* mat, const doub
         memcpy(&slots[(size_t)rank * 6], mine, sizeof mine);
         double* d_slots = device_alloc<double>(slots.size());
         upload(d_slots, slots.data(), slots.size());
-        comm->allreduce_sum(d_slots, (int)slots.size(), s->compute);
-        HIP_CHECK(hipStreamSynchronize(s->compute));
+        {
+            WatchdogScope guard("all-reduce of the ranks' timers", rank, -1, report_slab_state, s);
+            comm->allreduce_sum(d_slots, (int)slots.size(), s->compute);
+            HIP_CHECK(hipStreamSynchronize(s->compute));
+        }
         download(slots.data(), d_slots, slots.size());
         device_release(d_slots);
         if (rank == 0) {

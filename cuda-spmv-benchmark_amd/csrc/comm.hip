@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "device_runtime.hpp"
+#include "watchdog.hpp"
 
 #define RCCL_CHECK(call)                                                                         \
     do {                                                                                         \
@@ -32,7 +33,7 @@ struct SelfComm final : SpmvAmdComm {
         HIP_CHECK(hipMemcpy(h_full + (displs ? displs[0] : 0), d_local,
                             (size_t)n_local * sizeof(double), hipMemcpyDeviceToHost));
     }
-    void barrier() override {}
+    void barrier(hipStream_t) override {}
     const char* transport() const override { return "self"; }
 };
 
@@ -40,7 +41,9 @@ struct RcclComm final : SpmvAmdComm {
     ncclComm_t p2p = nullptr;   // halo rows
     ncclComm_t coll = nullptr;  // all-reduce, gather
     double* d_barrier = nullptr;  // one zero, summed over the ranks by barrier()
+    hipStream_t gather_s = nullptr;
     ~RcclComm() override {
+        if (gather_s) (void)hipStreamDestroy(gather_s);
         if (p2p) ncclCommDestroy(p2p);
         if (coll) ncclCommDestroy(coll);
         if (d_barrier) (void)hipFree(d_barrier);
@@ -49,12 +52,19 @@ struct RcclComm final : SpmvAmdComm {
                        double* d_recv_next, int count, hipStream_t stream) override {
         if (!exchanges_halos()) return;
         const int prev = self_neighbour ? rank : rank - 1, next = self_neighbour ? rank : rank + 1;
+        const bool to_prev = d_send_prev != nullptr && d_recv_prev != nullptr;
+        const bool to_next = d_send_next != nullptr && d_recv_next != nullptr;
+        if ((to_prev && (prev < 0 || prev >= world)) || (to_next && (next < 0 || next >= world))) {
+            fprintf(stderr, "[comm/rccl] rank %d of %d asked to exchange with a rank that does not exist\n", rank, world);
+            exit(EXIT_FAILURE);
+        }
+        // one group: with the rank as its own neighbour the two send/recv pairs to the same peer match in order
         RCCL_CHECK(ncclGroupStart());
-        if (self_neighbour || rank > 0) {
+        if (to_prev) {
             RCCL_CHECK(ncclSend(d_send_prev, (size_t)count, ncclDouble, prev, p2p, stream));
             RCCL_CHECK(ncclRecv(d_recv_prev, (size_t)count, ncclDouble, prev, p2p, stream));
         }
-        if (self_neighbour || rank < world - 1) {
+        if (to_next) {
             RCCL_CHECK(ncclSend(d_send_next, (size_t)count, ncclDouble, next, p2p, stream));
             RCCL_CHECK(ncclRecv(d_recv_next, (size_t)count, ncclDouble, next, p2p, stream));
         }
@@ -72,7 +82,9 @@ struct RcclComm final : SpmvAmdComm {
     }
     void gather_to_root(const double* d_local, int n_local, double* h_full, const int* counts,
                         const int* displs) override {
-        hipStream_t s = nullptr;
+        // outside every timed region (reference: MPI_Gatherv after the solve, :846); own stream so that the
+        // collective communicator is never driven from the null stream
+        hipStream_t s = gather_stream();
         if (rank == 0) {
             HIP_CHECK(hipMemcpy(h_full + displs[0], d_local, (size_t)n_local * sizeof(double),
                                 hipMemcpyDeviceToHost));
@@ -91,14 +103,31 @@ struct RcclComm final : SpmvAmdComm {
             HIP_CHECK(hipStreamSynchronize(s));
         }
     }
-    void barrier() override {
-        // the solver calls this before every timed region: no allocation, one 8-byte all-reduce of zeros
+    void barrier(hipStream_t stream) override {
+        // the solver calls this before every timed region: no allocation, one 8-byte all-reduce of zeros on
+        // the caller's stream (the stream every other use of `coll` is ordered on), then drain that stream
         if (d_barrier == nullptr) {
             d_barrier = device_alloc<double>(1);
             HIP_CHECK(hipMemset(d_barrier, 0, sizeof(double)));
         }
-        RCCL_CHECK(ncclAllReduce(d_barrier, d_barrier, 1, ncclDouble, ncclSum, coll, nullptr));
-        HIP_CHECK(hipStreamSynchronize(nullptr));
+        RCCL_CHECK(ncclAllReduce(d_barrier, d_barrier, 1, ncclDouble, ncclSum, coll, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+    }
+    int transport_ranks() const override {
+        int a = 0, b = 0;
+        if (ncclCommCount(p2p, &a) != ncclSuccess || ncclCommCount(coll, &b) != ncclSuccess) return 0;
+        return a == b ? a : 0;
+    }
+    void describe(FILE* out) const override {
+        ncclResult_t ea = ncclSuccess, eb = ncclSuccess;
+        const ncclResult_t qa = ncclCommGetAsyncError(p2p, &ea), qb = ncclCommGetAsyncError(coll, &eb);
+        fprintf(out, "[comm/rccl] rank %d of %d: async error state p2p=%s, collectives=%s\n", rank, world,
+                qa == ncclSuccess ? ncclGetErrorString(ea) : "(query failed)",
+                qb == ncclSuccess ? ncclGetErrorString(eb) : "(query failed)");
+    }
+    hipStream_t gather_stream() {
+        if (gather_s == nullptr) HIP_CHECK(hipStreamCreateWithFlags(&gather_s, hipStreamNonBlocking));
+        return gather_s;
     }
     const char* transport() const override { return "rccl"; }
 };
@@ -130,7 +159,8 @@ struct StagedComm final : SpmvAmdComm {
         double* sn = pinned + pinned_count;
         double* rp = pinned + 2 * pinned_count;
         double* rn = pinned + 3 * pinned_count;
-        const bool prev = rank > 0, next = rank < world - 1;
+        const bool prev = d_send_prev != nullptr && d_recv_prev != nullptr;
+        const bool next = d_send_next != nullptr && d_recv_next != nullptr;
         if (prev) HIP_CHECK(hipMemcpyAsync(sp, d_send_prev, bytes, hipMemcpyDeviceToHost, stream));
         if (next) HIP_CHECK(hipMemcpyAsync(sn, d_send_next, bytes, hipMemcpyDeviceToHost, stream));
         HIP_CHECK(hipStreamSynchronize(stream));
@@ -170,7 +200,7 @@ struct StagedComm final : SpmvAmdComm {
             exit(EXIT_FAILURE);
         }
     }
-    void barrier() override {
+    void barrier(hipStream_t) override {
         if (world > 1 && barrier_fn) barrier_fn(user);
     }
     const char* transport() const override { return "staged"; }
@@ -249,17 +279,40 @@ extern "C" void spmv_amd_comm_set_world(SpmvAmdComm* comm) { g_world = comm; }
 extern "C" int spmv_amd_comm_rank(const SpmvAmdComm* comm) { return comm ? comm->rank : 0; }
 extern "C" int spmv_amd_comm_size(const SpmvAmdComm* comm) { return comm ? comm->world : 1; }
 
+extern "C" int spmv_amd_comm_transport_ranks(const SpmvAmdComm* comm) { return comm ? comm->transport_ranks() : 0; }
+extern "C" const char* spmv_amd_comm_transport(const SpmvAmdComm* comm) { return comm ? comm->transport() : "self"; }
+
+extern "C" int spmv_amd_comm_barrier(SpmvAmdComm* comm) {
+    if (comm == nullptr) comm = &g_self;
+    spmv_amd::WatchdogScope guard("barrier", comm->rank);
+    comm->barrier(nullptr);
+    return 0;
+}
+
+namespace {
+void describe_comm(void* user, FILE* out) { static_cast<const SpmvAmdComm*>(user)->describe(out); }
+}  // namespace
+
 extern "C" int spmv_amd_comm_selftest(SpmvAmdComm* comm) {
     if (comm == nullptr) comm = &g_self;
+    using spmv_amd::WatchdogScope;
+    // everything the test sends travels on one stream of its own, drained before the function returns
+    hipStream_t st = nullptr;
+    HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     // all-reduce: value rank+1 on every rank
     double mine = (double)(comm->rank + 1), got = 0.0;
     double* d = device_alloc<double>(1);
     HIP_CHECK(hipMemcpy(d, &mine, sizeof mine, hipMemcpyHostToDevice));
-    comm->allreduce_sum(d, 1, nullptr);
-    HIP_CHECK(hipStreamSynchronize(nullptr));
+    {
+        WatchdogScope guard("self-test: all-reduce of one double", comm->rank, -1, describe_comm, comm);
+        comm->allreduce_sum(d, 1, st);
+        HIP_CHECK(hipStreamSynchronize(st));
+    }
     HIP_CHECK(hipMemcpy(&got, d, sizeof got, hipMemcpyDeviceToHost));
     device_release(d);
     int bad = got != 0.5 * comm->world * (comm->world + 1);
+    if (bad) fprintf(stderr, "[comm/%s] rank %d: self-test all-reduce returned %.17g, expected %.17g\n", comm->transport(),
+                     comm->rank, got, 0.5 * comm->world * (comm->world + 1));
     // neighbour exchange: every rank sends 64 doubles carrying its rank both ways
     if (comm->world > 1) {
         const int count = 64;
@@ -267,17 +320,23 @@ extern "C" int spmv_amd_comm_selftest(SpmvAmdComm* comm) {
         for (int i = 0; i < 2 * count; ++i) h[i] = (double)comm->rank;
         double* buf = device_alloc<double>(4 * count);  // [send_prev | send_next | recv_prev | recv_next]
         HIP_CHECK(hipMemcpy(buf, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice));
-        comm->halo_exchange(buf, buf + count, buf + 2 * count, buf + 3 * count, count, nullptr);
-        HIP_CHECK(hipStreamSynchronize(nullptr));
+        const bool prev = comm->rank > 0, next = comm->rank < comm->world - 1;
+        {
+            WatchdogScope guard("self-test: neighbour send/recv", comm->rank, -1, describe_comm, comm);
+            comm->halo_exchange(prev ? buf : nullptr, next ? buf + count : nullptr, prev ? buf + 2 * count : nullptr,
+                                next ? buf + 3 * count : nullptr, count, st);
+            HIP_CHECK(hipStreamSynchronize(st));
+        }
         HIP_CHECK(hipMemcpy(h.data(), buf, h.size() * sizeof(double), hipMemcpyDeviceToHost));
         device_release(buf);
         for (int i = 0; i < count; ++i) {
-            if (comm->rank > 0 && h[2 * count + i] != (double)(comm->rank - 1)) bad = 1;
-            if (comm->rank < comm->world - 1 && h[3 * count + i] != (double)(comm->rank + 1)) bad = 1;
+            if (prev && h[2 * count + i] != (double)(comm->rank - 1)) bad = 1;
+            if (next && h[3 * count + i] != (double)(comm->rank + 1)) bad = 1;
         }
+        if (bad) fprintf(stderr, "[comm/%s] rank %d: self-test neighbour exchange delivered wrong data\n", comm->transport(), comm->rank);
     }
-    // the transport's point-to-point calls with this rank as its own peer, on a non-default stream while the
-    // default stream is busy: what a one-GPU box can run of the halo exchange's RCCL path
+    // the transport's point-to-point calls with this rank as its own peer, on a second stream while the
+    // first one is idle: what a one-GPU box can run of the halo exchange's RCCL path
     {
         const int count = 20000;  // one halo row of the headline problem
         std::vector<double> h((size_t)count);
@@ -288,6 +347,7 @@ extern "C" int spmv_amd_comm_selftest(SpmvAmdComm* comm) {
         HIP_CHECK(hipMemset(b, 0, h.size() * sizeof(double)));
         hipStream_t side = nullptr;
         HIP_CHECK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+        WatchdogScope guard("self-test: send/recv loopback on a side stream", comm->rank, -1, describe_comm, comm);
         if (comm->loopback(a, b, count, side)) {
             HIP_CHECK(hipStreamSynchronize(side));
             std::vector<double> back((size_t)count);
@@ -299,6 +359,10 @@ extern "C" int spmv_amd_comm_selftest(SpmvAmdComm* comm) {
         device_release(a);
         device_release(b);
     }
-    comm->barrier();
+    {
+        WatchdogScope guard("self-test: barrier", comm->rank, -1, describe_comm, comm);
+        comm->barrier(st);
+    }
+    HIP_CHECK(hipStreamDestroy(st));
     return bad;
 }

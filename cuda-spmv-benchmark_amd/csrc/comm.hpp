@@ -14,6 +14,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <stdio.h>
 
 #include "spmv_amd.h"
 
@@ -33,7 +34,8 @@ struct SpmvAmdComm {
     bool exchanges_halos() const { return world > 1 || self_neighbour; }
     virtual ~SpmvAmdComm() {}
     // Exchanges `count` doubles with rank-1 (send_prev/recv_prev) and rank+1 (send_next/recv_next);
-    // pointers are device pointers, NULL where there is no neighbour. Ordered on `stream`.
+    // pointers are device pointers, NULL where the slab has no neighbour on that side (the pointers, not the
+    // rank, decide: a self-neighbour probe can stand in for any rank of a larger job). Ordered on `stream`.
     virtual void halo_exchange(const double* d_send_prev, const double* d_send_next,
                                double* d_recv_prev, double* d_recv_next, int count,
                                hipStream_t stream) = 0;
@@ -42,8 +44,16 @@ struct SpmvAmdComm {
     // Every rank contributes n_local device doubles; rank 0 receives them in h_full at displs[r].
     virtual void gather_to_root(const double* d_local, int n_local, double* h_full,
                                 const int* counts, const int* displs) = 0;
-    virtual void barrier() = 0;
+    // All ranks meet here. `stream` is the stream the caller's device work is ordered on (the solver's compute
+    // stream): a device-side transport enqueues its barrier there, so that each RCCL communicator is only ever
+    // driven from one stream, and returns once that stream has drained.
+    virtual void barrier(hipStream_t stream) = 0;
     virtual const char* transport() const = 0;
+    // Ranks the device transport itself reports (ncclCommCount of both communicators, 0 if they disagree or the
+    // transport has no such notion): lets a benchmark line prove how many devices RCCL really spans.
+    virtual int transport_ranks() const { return 0; }
+    // One or two lines for the watchdog report (e.g. ncclCommGetAsyncError of each communicator). Must not block.
+    virtual void describe(FILE*) const {}
     // Self-test aid: moves `count` device doubles from d_send to d_recv through the transport's own
     // point-to-point path with this rank as its own peer (RCCL: ncclSend + ncclRecv to self in one group),
     // so a one-GPU box runs the send / recv calls the halo exchange is made of. False = not supported.

@@ -29,6 +29,16 @@ extern "C" int spmv_amd_set_device(int device) {
     return 0;
 }
 
+extern "C" int spmv_amd_current_device(char* pci_bus_id, int cap) {
+    int dev = -1;
+    HIP_CHECK(hipGetDevice(&dev));
+    if (pci_bus_id != nullptr && cap > 0) {
+        pci_bus_id[0] = '\0';
+        (void)hipDeviceGetPCIBusId(pci_bus_id, cap, dev);
+    }
+    return dev;
+}
+
 extern "C" void* spmv_amd_device_alloc(size_t bytes) { return device_alloc<char>(bytes); }
 
 extern "C" void spmv_amd_device_free(void* d_ptr) {

@@ -154,8 +154,11 @@ int cg_partial_count(size_t n);  // partial slots written by the two reducing ke
 // may be null; its LAST slot is a ticket counter and must be zero before the first use) lets
 // large counts be summed by many blocks first, in the same launch.
 int reduce_stage_doubles();
+// host_progress (may be null): int in host-coherent pinned memory, set to progress_value once the sum is stored
+// (two-launch and single-block forms only); read by the solver's watchdog report.
 void launch_reduce_partials(const double* partials, int count, double* d_out,
-                            const int* d_skip_flag, hipStream_t stream, double* stage = nullptr);
+                            const int* d_skip_flag, hipStream_t stream, double* stage = nullptr,
+                            int* host_progress = nullptr, int progress_value = 0);
 // The same reduction followed by launch_cg_scalars_step(), in one launch when the wide path is taken
 // (only valid when no all-reduce has to happen between the sum and the step).
 void launch_reduce_partials_and_step(const double* partials, int count, double* d_out, const int* d_skip_flag,

@@ -160,12 +160,20 @@ void spmv_amd_partition_rows(int n, int world, int rank, int* row_offset, int* n
 /* ---- device plumbing for callers that have no HIP binding of their own ---- */
 int spmv_amd_device_count(void);
 int spmv_amd_set_device(int device);
+/* The calling thread's current device; pci_bus_id (may be NULL) receives "0000:c1:00.0"-style text. */
+int spmv_amd_current_device(char* pci_bus_id, int cap);
 void* spmv_amd_device_alloc(size_t bytes);
 void spmv_amd_device_free(void* d_ptr);
 int spmv_amd_copy_to_device(void* d_dst, const void* h_src, size_t bytes);
 int spmv_amd_copy_to_host(void* h_dst, const void* d_src, size_t bytes);
 int spmv_amd_device_fill_f64(double* d_ptr, size_t count, double value);
 int spmv_amd_device_synchronize(void);
+
+/* Measurement aid: the rate this GPU sustains for the byte mix of one STENCIL5 row (48 B read : 8 B written,
+ * SURVEY.md 8d) with ideal accesses -- coalesced 8-byte nontemporal loads / stores, no neighbours, no row
+ * structure -- on the benchmark's own data. `warmup` untimed launches over `rows` rows, then `reps` launches
+ * timed one by one with HIP events on the launch stream (ms_each[reps]). Returns bytes moved per launch. */
+double spmv_amd_stream_ceiling(size_t rows, int warmup, int reps, float* ms_each);
 
 /* ---- operators on synthetic, device-generated matrices ---- */
 
@@ -245,6 +253,14 @@ int spmv_amd_comm_size(const SpmvAmdComm* comm);
  * (64 doubles carrying the sender's rank, both ways) and one barrier through the communicator and
  * checks what arrived; 0 on success. Collective: every rank must call it. */
 int spmv_amd_comm_selftest(SpmvAmdComm* comm);
+/* All ranks meet (reference: MPI_Barrier, cg_solver_mgpu_partitioned.cu:405). Like every wait on another
+ * rank in this library it is bounded by the watchdog: after SPMV_AMD_WATCHDOG_S seconds (default 60,
+ * 0 = unbounded) without progress the rank reports where it is stuck and exits with EXIT_FAILURE. */
+int spmv_amd_comm_barrier(SpmvAmdComm* comm);
+/* "rccl", "staged" or "self"; and the number of ranks the device transport itself reports
+ * (ncclCommCount of both RCCL communicators; 0 for transports without such a notion). */
+const char* spmv_amd_comm_transport(const SpmvAmdComm* comm);
+int spmv_amd_comm_transport_ranks(const SpmvAmdComm* comm);
 
 /* ---- resident multi-GPU CG (what cg_solve_mgpu_partitioned is built from) ---- */
 typedef struct SpmvAmdCgSlab SpmvAmdCgSlab;
@@ -253,6 +269,11 @@ typedef struct SpmvAmdCgSlab SpmvAmdCgSlab;
 SpmvAmdCgSlab* spmv_amd_cg_slab_create(MatrixData* mat, SpmvAmdComm* comm);
 /* Slab of the synthetic n x n stencil, generated in HBM; b = 1, x0 = 0. */
 SpmvAmdCgSlab* spmv_amd_cg_slab_create_stencil5(int n, SpmvAmdComm* comm);
+/* Measurement aid: the slab rank `as_rank` of an `as_world`-GPU run would own (same rows, CSR bytes, halo
+ * length and neighbour sides; reference partition, cg_solver_mgpu_partitioned.cu:259-268,306-331), carried by ONE
+ * rank whose communicator was created with SPMV_AMD_SELF_NEIGHBOUR=1 and exchanges the halo rows with itself
+ * through the transport's own send / recv path. Solves a periodic strip, not the global system: timing only. */
+SpmvAmdCgSlab* spmv_amd_cg_slab_create_stencil5_as(int n, int as_rank, int as_world, SpmvAmdComm* comm);
 /* Full-length host vectors as in the reference (each rank uploads its slab);
  * NULL keeps b = 1 / x0 = 0. */
 int spmv_amd_cg_slab_set_vectors(SpmvAmdCgSlab* s, const double* b_full, const double* x0_full);

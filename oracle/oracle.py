@@ -209,6 +209,27 @@ def cg_all_cores(rp, ci, va, grid_size, b, x0, threads, max_iters=1000, tol=1e-6
     return x, hist[: res.iterations + 1].copy(), res
 
 
+def omp_lib(threads):
+    """The threaded build (liboracle_omp.so): timing of the all-cores CPU baseline only."""
+    if not os.path.exists(OMP_LIB_PATH):
+        subprocess.check_call(["make", "-C", HERE, "liboracle_omp.so"], stdout=subprocess.DEVNULL)
+    L = C.CDLL(OMP_LIB_PATH)
+    C.CDLL("libgomp.so.1").omp_set_num_threads(int(threads))
+    return L
+
+
+def spmv_into(rp, ci, va, x, y, grid_size=None, L=None):
+    """oracle_spmv_stencil5 (grid_size given) or oracle_spmv_csr into a caller-owned y, without allocating: the form
+    bench.py times. L = another build of the oracle (omp_lib) or None for the serial one. Rows are independent,
+    so the threaded build's SpMV results are bit-identical to the serial ones."""
+    L = L or lib()
+    if grid_size is None:
+        L.oracle_spmv_csr(len(rp) - 1, _ip(rp), _ip(ci), _dp(va), _dp(x), _dp(y))
+    else:
+        L.oracle_spmv_stencil5(len(rp) - 1, _ip(rp), _ip(ci), _dp(va), _dp(x), _dp(y), int(grid_size), C.c_double(1.0))
+    return y
+
+
 def cg_partitioned(rp, ci, va, grid_size, b, x0, world, max_iters=1000, tol=1e-6):
     n = len(rp) - 1
     b = _f64(b)

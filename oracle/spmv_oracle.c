@@ -119,6 +119,7 @@ static inline double csr_row_sum(const int* col_idx, const double* values, const
 
 void oracle_spmv_csr(int rows, const int* row_ptr, const int* col_idx, const double* values,
                      const double* x, double* y) {
+    ORACLE_PARALLEL_FOR
     for (int r = 0; r < rows; r++) y[r] = csr_row_sum(col_idx, values, x, row_ptr[r], row_ptr[r + 1]);
 }
 

@@ -1,10 +1,13 @@
-"""World-size > 1 paths. CPU: the partitioned algorithm over real gloo messages (oracle kernels).
+"""World-size > 1 paths. CPU: the partitioned algorithm over real gloo messages (oracle kernels); bench.py's
+self-launch and fail-loudly path; the watchdog.
 GPU: libspmv_amd's slab solver with 2 and 3 ranks sharing the box's GPU over the staged/gloo
 communicator, and the RCCL communicator with one rank (a 1-GPU box cannot host two RCCL ranks)."""
+import json
 import os
 import socket
 import subprocess
 import sys
+import time
 
 import numpy as np
 import pytest
@@ -122,24 +125,153 @@ def test_multi_rank_pipeline_over_rccl_with_the_rank_as_its_own_neighbour(grid):
     assert hist_err(np.array(nb["config"]["residual_history"]), np.array(one["config"]["residual_history"])) < 1e-10
 
 
+def _json_lines(text):
+    return [json.loads(l) for l in text.splitlines() if l.startswith("{")]
+
+
+def test_bench_self_launches_its_ranks_and_fails_loudly_without_gpus():
+    """`python bench.py --gpus 2`, the way the driver invokes it, with no GPU in sight: the parent starts two ranks
+    (no torch, no GPU call in the parent), they rendezvous over gloo, agree that nothing can be measured, rank 0 prints
+    ONE line with value null and the reason of every rank, and the exit status is non-zero."""
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
+    env.pop("RANK", None), env.pop("WORLD_SIZE", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--grid", "256"],
+                         env=env, capture_output=True, text=True, timeout=600)
+    lines = _json_lines(out.stdout)
+    assert out.returncode == 3, out.stdout + out.stderr
+    assert len(lines) == 1 and lines[0]["value"] is None and lines[0]["n_gpus"] == 2
+    assert "rank 0:" in lines[0]["unmeasured"] and "rank 1:" in lines[0]["unmeasured"]
+    assert "UNMEASURED" in out.stderr
+
+
+def test_watchdog_turns_a_wedged_barrier_into_a_diagnosable_exit(tmp_path):
+    """A staged communicator whose barrier callback never returns (a peer that died): the watchdog names the rank and
+    the stage and ends the process with a non-zero status after SPMV_AMD_WATCHDOG_S seconds. No GPU involved."""
+    script = tmp_path / "wedged_barrier.py"
+    script.write_text(
+        "import sys, time\n"
+        f"sys.path.insert(0, {os.path.join(ROOT, 'tests')!r})\n"
+        "from conftest import load_binding\n"
+        "B = load_binding(); B.lib()\n"
+        "def never(user):\n"
+        "    time.sleep(3600)\n"
+        "    return 0\n"
+        "c = B.Comm.staged(1, 2, lambda *a: 0, lambda *a: 0, None, never)\n"
+        "print('transport', c.transport(), flush=True)\n"
+        "c.barrier()\n"
+        "print('unreachable', flush=True)\n")
+    t0 = time.monotonic()
+    out = subprocess.run([sys.executable, str(script)], env=dict(os.environ, SPMV_AMD_WATCHDOG_S="1"), capture_output=True, text=True, timeout=120)
+    assert out.returncode == 1 and time.monotonic() - t0 < 60, out.stdout + out.stderr
+    assert "transport staged" in out.stdout and "unreachable" not in out.stdout
+    assert "[spmv_amd watchdog] rank 1: no progress" in out.stderr and "stage 'barrier'" in out.stderr
+
+
+@pytest.mark.gpu
+def test_watchdog_names_the_stage_of_a_wedged_all_reduce(tmp_path):
+    """Two-rank staged communicator whose all-reduce callback stops answering in the third call (= the p.Ap
+    all-reduce of iteration 0, after the initial r.r and ... ): the solve ends with the watchdog's report naming
+    the all-reduce and the iteration, with the state of both streams, instead of hanging."""
+    script = tmp_path / "wedged_allreduce.py"
+    script.write_text(
+        "import sys, time\n"
+        f"sys.path.insert(0, {os.path.join(ROOT, 'tests')!r})\n"
+        "from conftest import load_binding\n"
+        "B = load_binding(); B.lib()\n"
+        "calls = [0]\n"
+        "def allreduce(user, buf, count):\n"
+        "    calls[0] += 1\n"
+        "    if calls[0] >= 3:\n"
+        "        time.sleep(3600)\n"
+        "    return 0\n"
+        "c = B.Comm.staged(0, 2, lambda *a: 0, allreduce)\n"
+        "slab = B.CgSlab.stencil5(256, c)\n"
+        "print('solving', flush=True)\n"
+        "slab.solve()\n"
+        "print('unreachable', flush=True)\n")
+    out = subprocess.run([sys.executable, str(script)], env=dict(os.environ, SPMV_AMD_WATCHDOG_S="2"), capture_output=True, text=True, timeout=300)
+    assert out.returncode == 1, out.stdout + out.stderr
+    assert "solving" in out.stdout and "unreachable" not in out.stdout
+    assert "[spmv_amd watchdog] rank 0: no progress" in out.stderr and "all-reduce of" in out.stderr
+    assert "compute stream:" in out.stderr and "side (halo) stream:" in out.stderr
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_one_gpu_refuses_to_publish_a_staged_number():
+    """`python bench.py --gpus 2` (self-launched) with both ranks pinned to the box's only GPU: RCCL cannot span two
+    ranks on one device. Without SPMV_AMD_BENCH_ALLOW_STAGED the run must NOT fall back: one line with value null, the
+    reason, exit status 3."""
+    env = dict(os.environ, SPMV_AMD_BENCH_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("SPMV_AMD_BENCH_ALLOW_STAGED", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--grid", "1024"],
+                         env=env, capture_output=True, text=True, timeout=600)
+    lines = _json_lines(out.stdout)
+    assert out.returncode == 3, out.stdout + out.stderr
+    assert len(lines) == 1 and lines[0]["value"] is None and "RCCL" in lines[0]["unmeasured"] and lines[0]["n_gpus"] == 2
+
+
 @pytest.mark.gpu
 def test_bench_two_ranks_control_flow_on_one_gpu():
-    """bench.py --gpus 2 under torch.distributed.run with both ranks pinned to the box's only GPU:
-    RCCL refuses two ranks on one device, every rank agrees (over gloo) to switch to the staged
-    transport, and the run completes with the same residual history as one rank."""
-    import json
-    env = dict(os.environ, SPMV_AMD_BENCH_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    """`python bench.py --gpus 2`, self-launched, both ranks pinned to the box's only GPU and the staged transport
+    explicitly allowed: the ranks agree (over gloo) to switch, the run completes with the same residual history as one
+    rank, and the line is marked degraded and carries no vs_baseline."""
+    env = dict(os.environ, SPMV_AMD_BENCH_DEVICE="0", SPMV_AMD_BENCH_ALLOW_STAGED="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--grid", "1024"],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = _json_lines(out.stdout)
+    assert len(lines) == 1
+    two = lines[0]
+    assert two["n_gpus"] == 2 and two["scaling"] == "strong" and "staged" in two["transport"] and "degraded" in two
+    assert two["vs_baseline"] is None and two["rccl_ranks"] == 0 and "self-launched" in two["launched_by"]
+    assert [d["rank"] for d in two["devices"]] == [0, 1] and all(d["device"] == 0 for d in two["devices"])
+    assert "cpu_baseline" not in two and "spmv" not in two  # N = 1 only legs
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--grid", "1024",
+                          "--no-cpu-baseline", "--no-spmv"], capture_output=True, text=True, timeout=600)
+    one = _json_lines(one.stdout)[-1]
+    assert two["config"]["iterations_per_solve"] == one["config"]["iterations_per_solve"]
+    h2, h1 = np.array(two["config"]["residual_history"]), np.array(one["config"]["residual_history"])
+    assert hist_err(h2, h1) < 1e-10
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_under_an_external_launcher_on_one_gpu():
+    """The contract's other launch form: torch.distributed.run starts the ranks (RANK / WORLD_SIZE in the environment),
+    bench.py must not start any itself."""
+    env = dict(os.environ, SPMV_AMD_BENCH_DEVICE="0", SPMV_AMD_BENCH_ALLOW_STAGED="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
            "--grid", "1024"]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
-    two = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
-    assert two["n_gpus"] == 2 and two["scaling"] == "strong" and "staged" in two["config"]["transport"]
-    assert "cpu_baseline" not in two and "spmv" not in two  # N = 1 only legs
-    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--grid", "1024",
-                          "--no-cpu-baseline", "--no-spmv"], capture_output=True, text=True, timeout=600)
-    one = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
-    assert two["config"]["iterations_per_solve"] == one["config"]["iterations_per_solve"]
-    h2, h1 = np.array(two["config"]["residual_history"]), np.array(one["config"]["residual_history"])
-    assert hist_err(h2, h1) < 1e-10
+    two = _json_lines(out.stdout)[-1]
+    assert two["n_gpus"] == 2 and "external launcher" in two["launched_by"] and two["config"]["converged"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,as_rank,as_world", [(640, 0, 2), (640, 1, 4), (640, 3, 4), (1024, 3, 8)])
+def test_stand_in_slab_is_the_real_slab_of_that_rank(B, O, fresh_host_matrices, monkeypatch, n, as_rank, as_world):
+    """spmv_amd_cg_slab_create_stencil5_as (the scaling probe's slab): rank r-of-P's rows, CSR bytes and halo sides on a
+    single self-neighbour RCCL rank. Its slab SpMV on caller data (halos filled from the full vector, no exchange) must
+    be bit-identical to the oracle's halo kernel for that rank; a solve with tolerance 0 runs exactly max_iters
+    iterations through the send/recv + all-reduce pipeline."""
+    monkeypatch.setenv("SPMV_AMD_SELF_NEIGHBOUR", "1")
+    monkeypatch.setenv("SPMV_AMD_FORCE_COLLECTIVES", "1")
+    comm = B.Comm.rccl(0, 1, B.Comm.unique_id())
+    assert comm is not None and comm.transport() == "rccl" and comm.transport_ranks() == 1
+    slab = B.CgSlab.stencil5_as(n, as_rank, as_world, comm)
+    off, nl = O.partition_rows(n * n, as_world, as_rank)
+    assert (slab.row_offset, slab.n_local) == (off, nl)
+    rp, ci, va = O.stencil5_csr(n)
+    x = np.random.default_rng(5).standard_normal(n * n)
+    base = rp[off]
+    lrp = (rp[off:off + nl + 1] - base).astype(np.int32)
+    hp = x[off - n:off] if as_rank > 0 else None
+    hn = x[off + nl:off + nl + n] if as_rank < as_world - 1 else None
+    want = O.spmv_halo(lrp, ci[base:], va[base:], x[off:off + nl], hp, hn, off, n * n, n)
+    assert np.array_equal(slab.spmv(x), want)
+    st = slab.solve(max_iters=6, tol=0.0)
+    assert st.iterations == 6 and st.converged == 0 and np.all(np.isfinite(slab.history()))
+    assert slab.history()[-1] < slab.history()[0]  # the periodic strip is SPD too: CG makes progress
+    slab.destroy()
+    comm.destroy()
