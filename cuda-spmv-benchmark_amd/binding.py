@@ -92,6 +92,8 @@ DECLARED_SYMBOLS = [
     "spmv_amd_cg_slab_create", "spmv_amd_cg_slab_create_stencil5", "spmv_amd_cg_slab_create_stencil5_as", "spmv_amd_cg_slab_set_vectors", "spmv_amd_cg_slab_solve",
     "spmv_amd_cg_slab_gather", "spmv_amd_cg_slab_history", "spmv_amd_cg_slab_spmv", "spmv_amd_cg_slab_info",
     "spmv_amd_cg_slab_time_spmv", "spmv_amd_cg_slab_variant", "spmv_amd_cg_slab_destroy", "spmv_amd_version", "spmv_amd_write_stencil5_values",
+    "spmv_amd_blas1_axpy", "spmv_amd_blas1_axpby", "spmv_amd_blas1_axpy_dev", "spmv_amd_blas1_update_p_dev", "spmv_amd_blas1_dot",
+    "spmv_amd_cg_fused_step",
 ]
 # C++-linkage entry points kept under the reference's own names (Itanium-mangled).
 DECLARED_CXX_SYMBOLS = [
@@ -135,6 +137,12 @@ def lib():
     L.spmv_amd_device_alloc.restype = C.c_void_p
     L.spmv_amd_device_alloc.argtypes = [C.c_size_t]
     L.spmv_amd_device_free.argtypes = [C.c_void_p]
+    L.spmv_amd_blas1_axpy.argtypes = [C.c_size_t, C.c_double, C.c_void_p, C.c_void_p]
+    L.spmv_amd_blas1_axpby.argtypes = [C.c_size_t, C.c_double, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]
+    L.spmv_amd_blas1_axpy_dev.argtypes = [C.c_size_t, C.c_double, C.c_void_p, C.c_void_p, C.c_int]
+    L.spmv_amd_blas1_update_p_dev.argtypes = [C.c_size_t, C.c_void_p, C.c_double, C.c_void_p]
+    L.spmv_amd_blas1_dot.argtypes = [C.c_size_t, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
+    L.spmv_amd_cg_fused_step.argtypes = [C.c_int, C.c_size_t, C.POINTER(C.c_double), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_double)]
     L.spmv_amd_current_device.argtypes = [C.c_char_p, C.c_int]
     L.spmv_amd_stream_ceiling.restype = C.c_double
     L.spmv_amd_stream_ceiling.argtypes = [C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_float)]
@@ -240,6 +248,25 @@ def load_matrix_market(path):
     e = np.ctypeslib.as_array((C.c_byte * (16 * m.nnz)).from_address(m.entries)).view(ENTRY_DTYPE).copy()
     C.CDLL(None).free(C.c_void_p(m.entries))
     return HostMatrix(e, m.rows, m.cols, m.grid_size)
+
+
+def read_matrix_symtogen(path):
+    """read_matrix_symtogen with every output requested: (rows, cols, stored nnz, expanded nnz, row_ptr, col_idx,
+    values, expanded entries). The CSR arrays are the reference reader's (columns in a row in file order)."""
+    m = MatrixData()
+    rows, cols, nnz, full = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    rp, ci, va = C.POINTER(C.c_int)(), C.POINTER(C.c_int)(), C.POINTER(C.c_double)()
+    lib().read_matrix_symtogen(C.byref(m), os.fsencode(path), C.byref(rows), C.byref(cols), C.byref(nnz), C.byref(rp), C.byref(ci),
+                               C.byref(va), C.byref(full))
+    if not m.entries:
+        raise IOError(f"read_matrix_symtogen({path}) failed")
+    out = (rows.value, cols.value, nnz.value, full.value, np.ctypeslib.as_array(rp, shape=(rows.value + 1,)).copy(),
+           np.ctypeslib.as_array(ci, shape=(full.value,)).copy(), np.ctypeslib.as_array(va, shape=(full.value,)).copy(),
+           np.ctypeslib.as_array((C.c_byte * (16 * m.nnz)).from_address(m.entries)).view(ENTRY_DTYPE).copy())
+    libc = C.CDLL(None)
+    for ptr in (rp, ci, va, C.c_void_p(m.entries)):
+        libc.free(ptr)
+    return out
 
 
 def host_csr_arrays():

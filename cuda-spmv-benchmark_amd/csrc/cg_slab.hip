@@ -31,6 +31,7 @@
 #include "comm.hpp"
 #include "device_runtime.hpp"
 #include "stencil_geometry.hpp"
+#include "trace_ranges.hpp"
 #include "watchdog.hpp"
 
 using namespace spmv_amd;
@@ -78,6 +79,8 @@ struct SpmvAmdCgSlab {
     hipStream_t compute = nullptr, side = nullptr;
     hipEvent_t ev_p_ready = nullptr, ev_halo_done = nullptr;
     LaunchShape shape;
+    // launch plans, made once at creation: the whole slab, the rows that need no halo, the first / last grid row
+    Stencil5Plan plan_whole, plan_interior, plan_head, plan_tail;
     int partials_cap = 0;
     const char* variant_name = "";
     bool fused_dot = false;
@@ -96,6 +99,8 @@ struct SpmvAmdCgSlab {
     // stores / consumers' loads plain instead of nontemporal did not raise the hit share (SPMV_AMD_PINGPONG=0
     // switches the alternation off).
     bool pingpong = true;
+    bool roctx_always = false;  // SPMV_AMD_ROCTX=1: roctx ranges even without detailed timers
+    bool no_overlap = false;  // SPMV_AMD_NO_OVERLAP=1: halo exchange on the compute stream, for A/B runs of the overlap
     int poll_sequence = 0;
     double last_spmv_ms = 0.0;
     int last_spmv_launches = 0;
@@ -179,6 +184,8 @@ void make_common(SpmvAmdCgSlab* s) {
     s->shape = current_launch_shape();
     if (const char* v = getenv("SPMV_AMD_SPMV_EVENT_STRIDE")) s->spmv_event_stride = atoi(v);
     if (const char* v = getenv("SPMV_AMD_PINGPONG")) s->pingpong = v[0] == '1';
+    if (const char* v = getenv("SPMV_AMD_NO_OVERLAP")) s->no_overlap = v[0] == '1';
+    if (const char* v = getenv("SPMV_AMD_ROCTX")) s->roctx_always = v[0] == '1';
     s->partials_blas = device_alloc<double>(dot_scratch_doubles(nl));
     s->reduce_stage = device_alloc<double>((size_t)reduce_stage_doubles());
     // both end in the ticket counter of the one-launch reduction, which starts at zero
@@ -194,18 +201,20 @@ void make_common(SpmvAmdCgSlab* s) {
         // slab and the row range, so size for the larger of the two ways a SpMV is issued
         const SlabCsr& A = s->A.view;
         const int lo = s->has_prev ? s->halo : 0, hi = s->n_local - (s->has_next ? s->halo : 0);
-        const auto need = [&](int a, int b) {
-            return b > a ? stencil5_partials_needed(A, a, b, Stencil5Variant::Auto, s->shape) : 0;
-        };
-        const int whole = need(0, s->n_local);
-        const int split = need(lo, hi) + need(0, lo) + need(hi, s->n_local);
+        const auto plan = [&](int a, int b) { return plan_stencil5(A, a, b > a ? b : a, Stencil5Variant::Auto, s->shape); };
+        s->plan_whole = plan(0, s->n_local);
+        s->plan_interior = plan(lo, hi);
+        s->plan_head = plan(0, lo);
+        s->plan_tail = plan(hi, s->n_local);
+        const int whole = s->plan_whole.partials;
+        const int split = (hi > lo ? s->plan_interior.partials : 0) + (lo > 0 ? s->plan_head.partials : 0) +
+                          (hi < s->n_local ? s->plan_tail.partials : 0);
         s->partials_cap = whole > split ? whole : split;
         s->partials_spmv = device_alloc<double>((size_t)s->partials_cap);
         HIP_CHECK(hipMemset(s->partials_spmv, 0, (size_t)s->partials_cap * sizeof(double)));
-        const char* name = stencil5_variant_name(A, 0, s->n_local, Stencil5Variant::Auto, s->shape);
-        s->variant_name = name;
+        s->variant_name = s->plan_whole.name;
         // unverified / unaligned slabs run the row-generic kernel and use the plain dot kernel
-        s->fused_dot = strstr(name, "row-generic") == nullptr;
+        s->fused_dot = strstr(s->variant_name, "row-generic") == nullptr;
     }
     launch_fill(s->b, nl, 1.0, s->compute);   // default right-hand side b = 1
     launch_fill(s->x0, nl, 0.0, s->compute);  // default initial guess x0 = 0
@@ -234,17 +243,15 @@ int slab_boundary_spmv(SpmvAmdCgSlab* s, double* part, const int* skip, hipStrea
     const int hi = s->n_local - (s->has_next ? s->halo : 0);
     LaunchShape forward = s->shape;
     forward.reverse = false;
-    double* at = part ? part + stencil5_partials_needed(A, lo, hi, Stencil5Variant::Auto, forward) : nullptr;
+    double* at = part ? part + (hi > lo ? s->plan_interior.partials : 0) : nullptr;
     int used = 0;
     if (lo > 0 && hi < s->n_local && lo == A.grid_size && s->n_local - hi == A.grid_size) {
         // a rank with two neighbours: its first and last grid row in one launch
-        used += launch_stencil5_spmv_first_and_last_gridrow(A, s->p, s->Ap, 1.0, at, skip, forward, stream);
+        used += launch_stencil5_spmv_first_and_last_gridrow(A, s->plan_head, s->p, s->Ap, 1.0, at, skip, forward, stream);
     } else {
-        if (lo > 0)
-            used += launch_stencil5_spmv(A, s->p, s->Ap, 1.0, 0, lo, at, skip, Stencil5Variant::Auto, forward, stream);
+        if (lo > 0) used += launch_stencil5_spmv(A, s->plan_head, s->p, s->Ap, 1.0, at, skip, false, stream);
         if (hi < s->n_local)
-            used += launch_stencil5_spmv(A, s->p, s->Ap, 1.0, hi, s->n_local, at ? at + used : nullptr, skip,
-                                         Stencil5Variant::Auto, forward, stream);
+            used += launch_stencil5_spmv(A, s->plan_tail, s->p, s->Ap, 1.0, at ? at + used : nullptr, skip, false, stream);
     }
     return part ? used : 0;
 }
@@ -262,15 +269,13 @@ void slab_spmv(SpmvAmdCgSlab* s, bool with_dot, bool overlap, const int* skip,
     int used = 0;
     if (!overlap || hi <= lo || (lo == 0 && hi == s->n_local)) {
         if (overlap) HIP_CHECK(hipStreamWaitEvent(s->compute, s->ev_halo_done, 0));
-        used = launch_stencil5_spmv(A, in, s->Ap, 1.0, 0, s->n_local, part, skip, Stencil5Variant::Auto,
-                                    s->shape, s->compute);
+        used = launch_stencil5_spmv(A, s->plan_whole, in, s->Ap, 1.0, part, skip, s->shape.reverse, s->compute);
     } else {
         // rows whose north and south neighbours are local run under the halo exchange; the first / last grid
         // row of the slab once the halo rows have landed. (Launching those two rows behind the exchange on the
         // side stream instead, so that this stream only waits for an event, measured slower: 15.77 vs 15.59 ms
         // per solve at 50 M rows with the rank as its own neighbour.)
-        used = launch_stencil5_spmv(A, s->p, s->Ap, 1.0, lo, hi, part, skip, Stencil5Variant::Auto,
-                                    s->shape, s->compute);
+        used = launch_stencil5_spmv(A, s->plan_interior, s->p, s->Ap, 1.0, part, skip, s->shape.reverse, s->compute);
         HIP_CHECK(hipStreamWaitEvent(s->compute, s->ev_halo_done, 0));
         used += slab_boundary_spmv(s, part, skip, s->compute);
     }
@@ -451,6 +456,9 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
     // x update computes x = x0 + alpha p.
     HIP_CHECK(hipStreamSynchronize(s->compute));
 
+    // the reference's NVTX ranges (:540-717) as roctx ranges, when detailed timers (or SPMV_AMD_ROCTX=1) ask for them
+    const TraceRanges trace(detail || s->roctx_always);
+    TraceScope solver_range(trace, "CG_Solver");
     EventTimer total, part;
     auto timed = [&](double* bucket, double* bucket2, auto&& work) {
         if (!detail) {
@@ -498,8 +506,7 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
     auto start_p_halo = [&] {  // halo rows of the new p: side stream, under the interior SpMV
         if (!multi) return;
         // SPMV_AMD_NO_OVERLAP=1: exchange on the compute stream, for A/B runs of the overlap
-        static const bool no_overlap = [] { const char* v = getenv("SPMV_AMD_NO_OVERLAP"); return v && v[0] == '1'; }();
-        if (detail || no_overlap) {
+        if (detail || s->no_overlap) {
             timed(&stats->time_allgather_ms, nullptr, [&] { exchange_p_halo(s, s->compute); });
             halo_in_flight = false;
             return;
@@ -521,8 +528,10 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
         // direction flips every iteration, so every kernel starts where the previous one ended
         const bool backward = s->pingpong && (enqueued & 1) == 0;  // iteration 0 follows the forward initial-residual pass
         s->shape.reverse = backward;
+        TraceScope iteration_range(trace, "CG_Iteration");
         s->enqueued_iteration = enqueued;
         s->enqueued_stage = "SpMV";
+        trace.push("SpMV");
         s->spmv_progress = &s->h_poll->progress;
         s->spmv_progress_value = 4 * (s->poll_sequence + 1) + 1;
         if (detail) {
@@ -543,24 +552,34 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
                 slab_spmv(s, true, halo_in_flight, skip);
             }
         }
+        trace.pop();
         s->spmv_progress = nullptr;
         s->enqueued_stage = "all-reduce of p.Ap";
-        if (reduce) timed(&stats->time_allreduce_ms, nullptr, [&] { allreduce_scalar(s, &s->d_s->pAp, "all-reduce of p.Ap"); });
+        if (reduce) {
+            TraceScope r(trace, "AllReduce");
+            timed(&stats->time_allreduce_ms, nullptr, [&] { allreduce_scalar(s, &s->d_s->pAp, "all-reduce of p.Ap"); });
+        }
         s->enqueued_stage = "r update";
+        trace.push("BLAS_AXPY");
         timed(&stats->time_blas1_ms, &stats->time_axpy_update_r_ms, [&] {
             launch_cg_update_r(nl, s->d_s, s->Ap, s->r, s->partials_blas, s->compute, s->pingpong && !backward);
         });
+        trace.pop();
         // the scalar step publishes {sequence, converged, iterations} straight into host-coherent pinned
         // memory: no copy command sits between it and the p update on the stream. Without an all-reduce
         // between the sum and the step, the step runs in the tail of the reduction's launch.
         ++s->poll_sequence;
+        trace.push("Dot_Product");
         if (reduce) {
             timed(&stats->time_reductions_ms, &stats->time_dot_rs_new_ms, [&] {
                 launch_reduce_partials(s->partials_blas, cg_partial_count(nl), &s->d_s->rr_new, skip, s->compute, s->reduce_stage,
                                        &s->h_poll->progress, 4 * s->poll_sequence + 2);
             });
             s->enqueued_stage = "all-reduce of r.r";
-            timed(&stats->time_allreduce_ms, nullptr, [&] { allreduce_scalar(s, &s->d_s->rr_new, "all-reduce of r.r"); });
+            {
+                TraceScope r(trace, "AllReduce");
+                timed(&stats->time_allreduce_ms, nullptr, [&] { allreduce_scalar(s, &s->d_s->rr_new, "all-reduce of r.r"); });
+            }
             launch_cg_scalars_step(s->d_s, config->tolerance, s->d_hist, &s->h_poll->sequence, s->poll_sequence,
                                    s->compute, s->d_alpha_ring, slots);
         } else {
@@ -570,7 +589,9 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
                                                 &s->h_poll->sequence, s->poll_sequence, s->d_alpha_ring, slots);
             });
         }
+        trace.pop();
         ++enqueued;
+        trace.push("BLAS_AXPBY");
 
         // p <- r + beta p, its halo exchange, and (when overlapping) nothing else before the host
         // looks at the status: the GPU works on these while the host waits for the record.
@@ -594,8 +615,12 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
             });
             s->p = p_next;
         }
+        trace.pop();
         s->enqueued_stage = "direction update and halo exchange";
-        start_p_halo();
+        {
+            TraceScope r(trace, "Halo_Exchange");
+            start_p_halo();
+        }
         wait_for_status(s);
         if (s->h_poll->converged) done = true;
         if (config->verbose >= 2 && comm->rank == 0) {
@@ -702,9 +727,8 @@ extern "C" int spmv_amd_cg_slab_time_spmv(SpmvAmdCgSlab* s, int reps, float* ms_
     EventTimer t;
     for (int i = 0; i < reps; ++i) {
         t.begin(s->compute);
-        (void)launch_stencil5_spmv(s->A.view, s->p, s->Ap, 1.0, 0, s->n_local,
-                                   s->fused_dot ? s->partials_spmv : nullptr, nullptr,
-                                   Stencil5Variant::Auto, s->shape, s->compute);
+        (void)launch_stencil5_spmv(s->A.view, s->plan_whole, s->p, s->Ap, 1.0, s->fused_dot ? s->partials_spmv : nullptr,
+                                   nullptr, false, s->compute);
         t.end(s->compute);
         ms_each[i] = t.elapsed_ms();
     }

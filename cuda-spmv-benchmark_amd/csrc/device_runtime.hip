@@ -1,11 +1,39 @@
 // device_runtime.hip -- see device_runtime.hpp.
 #include "device_runtime.hpp"
 
+#include <stdlib.h>
+
 #include <vector>
 
 #include "stencil_geometry.hpp"
 
 namespace spmv_amd {
+
+namespace {
+int env_int(const char* name, int fallback) {
+    const char* v = getenv(name);
+    return (v && *v) ? atoi(v) : fallback;
+}
+
+// The SPMV_AMD_* measurement switches of the launch paths (tools/README.md), out-of-range values replaced by the
+// defaults. Called when an operator is initialised or a solver slab is created, never per launch.
+Tunables read_tunables() {
+    Tunables k;
+    k.rowlds_min_grid = env_int("SPMV_AMD_ROWLDS_MIN_GRID", k.rowlds_min_grid);
+    k.rowlds_group = env_int("SPMV_AMD_ROWLDS_GROUP", k.rowlds_group);
+    if (k.rowlds_group < 1 || k.rowlds_group > 64) k.rowlds_group = 4;
+    k.direct_rows = env_int("SPMV_AMD_DIRECT_ROWS", k.direct_rows);
+    if (k.direct_rows != 2 && k.direct_rows != 4) k.direct_rows = 1;
+    k.wavetile_oneshot = env_int("SPMV_AMD_WAVETILE_ONESHOT", k.wavetile_oneshot);
+    k.march_blocks_per_cu = env_int("SPMV_AMD_MARCH_BLOCKS_PER_CU", k.march_blocks_per_cu);
+    k.march_max_rows = env_int("SPMV_AMD_MARCH_MAX_ROWS", k.march_max_rows);
+    k.march_rows_per_task = env_int("SPMV_AMD_ROWS_PER_TASK", 0);
+    k.csr_stream_shape = env_int("SPMV_AMD_CSR_STREAM_SHAPE", k.csr_stream_shape);
+    k.csr_stream_rows = env_int("SPMV_AMD_CSR_STREAM_ROWS", 0);
+    k.ell_shape = env_int("SPMV_AMD_ELL_SHAPE", k.ell_shape);
+    return k;
+}
+}  // namespace
 
 LaunchShape current_launch_shape() {
     static int cached_device = -1;
@@ -20,6 +48,8 @@ LaunchShape current_launch_shape() {
         cached.blocks_per_cu = 7;
         cached_device = dev;
     }
+    cached.knobs = read_tunables();
+    cached.reverse = false;
     return cached;
 }
 

@@ -26,9 +26,26 @@ struct SlabCsr {
     int halo_after = 0;
 };
 
+// Measurement switches (SPMV_AMD_* environment variables, tools/README.md). They are read ONCE, when an operator
+// is initialised or a solver slab is created (current_launch_shape()), into this struct; nothing on a launch path
+// calls getenv. Defaults are the measured optima quoted next to the kernels.
+struct Tunables {
+    int rowlds_min_grid = 512;    // smallest grid that takes row-lds automatically
+    int rowlds_group = 4;         // consecutive row-lds tiles per XCD
+    int direct_rows = 1;          // grid rows per thread in row-direct (1, 2, 4)
+    int wavetile_oneshot = 1;     // 0 = persistent XCD-banded walk
+    int march_blocks_per_cu = 20;
+    int march_max_rows = 16;
+    int march_rows_per_task = 0;  // 0 = derived
+    int csr_stream_shape = 0;     // 0: 256 x 4, 1: 64 x 6, 2: 64 x 8, 3: 128 x 5
+    int csr_stream_rows = 0;      // 0 = derived from the mean row length
+    int ell_shape = 2;            // bit 0: one-wave workgroups, bit 1: nontemporal planes / y
+};
+
 struct LaunchShape {
     int compute_units = 256;
     int blocks_per_cu = 7;
+    Tunables knobs;
     // walk the tiles from the last to the first (row-lds kernel): results are identical, only the order in
     // which addresses are touched changes (sweep direction alternation of the CG loop, cg_slab.hip)
     bool reverse = false;
@@ -48,6 +65,27 @@ void launch_verify_stencil5_csr(const SlabCsr& m, int* d_mismatch, hipStream_t s
 // y[r] = alpha * (A x)[r]. d_dot_partials, if non-null, receives one partial of
 // sum_r x[r]*y_unscaled[r] per launched wave (count: stencil5_partials_needed()).
 enum class Stencil5Variant { Auto, RowDirect, ColumnMarch, WaveTile, RowGeneric, RowLds };
+// Everything about one STENCIL5 launch over local rows [first_row, last_row) that does not depend on the vectors:
+// which kernel, its grid, how many dot partials it writes. Computed once per (slab, row range) -- by an operator's
+// init, by a solver slab's creation -- and reused for every launch.
+struct Stencil5Plan {
+    Stencil5Variant variant = Stencil5Variant::RowGeneric;
+    int first_row = 0, last_row = 0;
+    // column-march: the range splits into up to two global-boundary grid rows (row kernel) and
+    // the grid rows [gi_lo, gi_hi) in between
+    bool head_rows = false, tail_rows = false;
+    int gi_lo = 0, gi_hi = 0, rows_per_task = 0, strips = 0, march_blocks = 0;
+    int row_blocks = 0;  // blocks of one boundary-grid-row launch
+    int tile_blocks = 0;
+    bool oneshot = true;
+    int partials = 0;        // dot-partial slots one launch writes
+    const char* name = "";   // "stencil5/row-lds", ...
+};
+Stencil5Plan plan_stencil5(const SlabCsr& m, int first_row, int last_row, Stencil5Variant variant,
+                           const LaunchShape& shape);
+// Launch by plan. reverse: walk the tiles from the last to the first (row-lds only; same results).
+int launch_stencil5_spmv(const SlabCsr& m, const Stencil5Plan& plan, const double* x, double* y, double alpha,
+                         double* d_dot_partials, const int* d_skip_flag, bool reverse, hipStream_t stream);
 // Partial-sum slots a launch over [first_row, last_row) writes (a fixed function of the slab, the
 // range and the launch shape, so reductions keep one shape for the life of a solver).
 int stencil5_partials_needed(const SlabCsr& m, int first_row, int last_row, Stencil5Variant variant,
@@ -64,25 +102,26 @@ int launch_stencil5_spmv(const SlabCsr& m, const double* x, double* y, double al
 
 // The first and the last grid row of a slab made of whole grid rows (the rows that wait for the halos), in one
 // launch where the row-lds kernel applies, in two otherwise. Partial slots: first grid row's, then last grid row's.
-int launch_stencil5_spmv_first_and_last_gridrow(const SlabCsr& m, const double* x, double* y, double alpha,
-                                                double* d_dot_partials, const int* d_skip_flag,
+// `head` = plan_stencil5(m, 0, grid_size, ...), the plan of the slab's first grid row.
+int launch_stencil5_spmv_first_and_last_gridrow(const SlabCsr& m, const Stencil5Plan& head, const double* x, double* y,
+                                                double alpha, double* d_dot_partials, const int* d_skip_flag,
                                                 const LaunchShape& shape, hipStream_t stream);
 
 // ---- CSR SpMV ----
 enum class CsrVariant { Auto, Stream, RowScalar, Wavefront, SubWave4, SubWave8, SubWave16, SubWave32 };
 CsrVariant csr_auto_variant(const SlabCsr& m);
 void launch_csr_spmv(const SlabCsr& m, const double* x, double* y, double alpha,
-                     CsrVariant variant, hipStream_t stream);
+                     CsrVariant variant, const Tunables& knobs, hipStream_t stream);
 
 // ---- ELLPACK SpMV (device layout: slot-major, element (r,k) at [k * rows + r]) ----
 void launch_ell_transpose(int rows, int width, const int* idx_rowmajor, const double* val_rowmajor,
                           int* idx_slotmajor, double* val_slotmajor, hipStream_t stream);
 void launch_ell_spmv(int rows, int width, const int* idx, const double* val, const double* x,
-                     double* y, double alpha, double beta, hipStream_t stream);
+                     double* y, double alpha, double beta, const Tunables& knobs, hipStream_t stream);
 // Interior rows take W,C,E,N,S from slots 1,2,3,0,4 with computed columns; others walk slots.
 void launch_ell_stencil5_spmv(int rows, int width, int grid_size, const int* idx,
                               const double* val, const double* x, double* y, double alpha,
-                              double beta, hipStream_t stream);
+                              double beta, const Tunables& knobs, hipStream_t stream);
 
 // ---- BLAS1 + reductions for CG ----
 // Device scalars of one CG solve, laid out in one small allocation.

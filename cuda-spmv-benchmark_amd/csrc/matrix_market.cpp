@@ -1,7 +1,9 @@
 // matrix_market.cpp -- Matrix Market coordinate reader and the 5-point stencil writer.
 // Same file format, comment protocol ("% STENCIL_GRID_SIZE n") and 0-based Entry output as
 // reference src/io/io.cu; the text of write_matrix_market_stencil5 is byte-identical to the
-// reference writer's (checked against oracle/_ref in tests/test_io_host.py).
+// reference writer's, and both readers are checked against the reference's own io.cu compiled in place
+// (oracle/_ref/libref_io.so; tests/test_host_logic.py::test_writer_matches_reference_writer_and_golden,
+// ::test_reader_matches_reference_reader, ::test_symmetric_reader_matches_reference_symtogen).
 //
 // Deliberate differences from the reference reader, all on error paths or unfinished code:
 //  * load_matrix_market returns non-zero when the file cannot be opened or is truncated
@@ -188,6 +190,31 @@ extern "C" void read_matrix_symtogen(MatrixData* mat, const char* filename, int*
     }
     free(tri.entries);
     *nnz_general = (int)full;
+    // The CSR arrays the reference builds (io.cu:259-307): counts per row, prefix sum, then every stored entry
+    // placed in its row followed at once by its mirror image in the column's row -- i.e. the expanded list
+    // bucketed by row in list order. Columns inside a row are therefore NOT sorted.
+    if (csr_rowptr && csr_colind && csr_val) {
+        int* rp = (int*)calloc((size_t)tri.rows + 1, sizeof(int));
+        int* ci = (int*)malloc((full ? full : 1) * sizeof(int));
+        double* va = (double*)malloc((full ? full : 1) * sizeof(double));
+        int* fill = (int*)calloc((size_t)(tri.rows ? tri.rows : 1), sizeof(int));
+        if (!rp || !ci || !va || !fill) {
+            fprintf(stderr, "Memory allocation error\n");
+            free(rp), free(ci), free(va), free(fill), free(out);
+            return;
+        }
+        for (size_t k = 0; k < full; ++k) rp[out[k].row + 1]++;
+        for (int r = 1; r <= tri.rows; ++r) rp[r] += rp[r - 1];
+        for (size_t k = 0; k < full; ++k) {
+            const int at = rp[out[k].row] + fill[out[k].row]++;
+            ci[at] = out[k].col;
+            va[at] = out[k].value;
+        }
+        free(fill);
+        *csr_rowptr = rp;
+        *csr_colind = ci;
+        *csr_val = va;
+    }
     mat->entries = out;
     mat->rows = tri.rows;
     mat->cols = tri.cols;

@@ -25,6 +25,8 @@ constexpr hipStream_t kDefaultStream = nullptr;  // the reference launches on th
 
 struct CsrBackedOperator {
     const char* tag;
+    LaunchShape shape;        // device geometry + the SPMV_AMD_* switches, read when a variant is picked
+    Stencil5Plan plan;        // stencil5-csr: the launch plan of the whole matrix, made once per init / variant change
     DeviceCsr A;
     double* dX = nullptr;
     double* dY = nullptr;
@@ -81,8 +83,9 @@ CsrBackedOperator g_csr{"cusparse-csr"};
 // ---- stencil5-csr ----------------------------------------------------------------
 
 void stencil_pick_variant() {
-    g_stencil.variant_name = stencil5_variant_name(g_stencil.A.view, 0, g_stencil.rows,
-                                                   g_stencil.stencil_variant, current_launch_shape());
+    g_stencil.shape = current_launch_shape();
+    g_stencil.plan = plan_stencil5(g_stencil.A.view, 0, g_stencil.rows, g_stencil.stencil_variant, g_stencil.shape);
+    g_stencil.variant_name = g_stencil.plan.name;
 }
 
 int stencil_init(MatrixData* mat) {
@@ -100,9 +103,8 @@ int stencil_run_device(const double* d_x, double* d_y) {
         fprintf(stderr, "[stencil5-csr] run before init\n");
         return EXIT_FAILURE;
     }
-    (void)launch_stencil5_spmv(g_stencil.A.view, d_x, d_y, /*alpha=*/1.0, 0, g_stencil.rows, nullptr,
-                               nullptr, g_stencil.stencil_variant, current_launch_shape(),
-                               kDefaultStream);
+    (void)launch_stencil5_spmv(g_stencil.A.view, g_stencil.plan, d_x, d_y, /*alpha=*/1.0, nullptr, nullptr,
+                               /*reverse=*/false, kDefaultStream);
     return 0;
 }
 
@@ -145,6 +147,7 @@ const char* csr_variant_name(CsrVariant v, const SlabCsr& m) {
 
 int csr_init(MatrixData* mat) {
     if (g_csr.init_from_host(mat) != 0) return EXIT_FAILURE;
+    g_csr.shape = current_launch_shape();
     g_csr.variant_name = csr_variant_name(g_csr.csr_variant, g_csr.A.view);
     printf("[cusparse-csr] %d rows, %d nnz, variant %s\n", csr_mat.nb_rows, csr_mat.nb_nonzeros,
            g_csr.variant_name);
@@ -156,7 +159,7 @@ int csr_run_device(const double* d_x, double* d_y) {
         fprintf(stderr, "[cusparse-csr] run before init\n");
         return EXIT_FAILURE;
     }
-    launch_csr_spmv(g_csr.A.view, d_x, d_y, /*alpha=*/1.0, g_csr.csr_variant, kDefaultStream);
+    launch_csr_spmv(g_csr.A.view, d_x, d_y, /*alpha=*/1.0, g_csr.csr_variant, g_csr.shape.knobs, kDefaultStream);
     return EXIT_SUCCESS;
 }
 
@@ -186,7 +189,9 @@ struct EllOperator {
         ready = false;
         variant_name = "uninitialised";
     }
+    Tunables knobs;
     void pick() {
+        knobs = current_launch_shape().knobs;
         variant_name = (stencil_fast_path && verified && grid_size >= 3) ? "ell/stencil5-direct"
                                                                         : "ell/slot-major";
     }
@@ -271,10 +276,10 @@ int ell_run(EllOperator& op, const double* d_x, double* d_y, double alpha = 1.0,
         return EXIT_FAILURE;
     }
     if (op.stencil_fast_path && op.verified)
-        launch_ell_stencil5_spmv(op.rows, op.width, op.grid_size, op.idx, op.val, d_x, d_y, alpha, beta,
+        launch_ell_stencil5_spmv(op.rows, op.width, op.grid_size, op.idx, op.val, d_x, d_y, alpha, beta, op.knobs,
                                  kDefaultStream);
     else
-        launch_ell_spmv(op.rows, op.width, op.idx, op.val, d_x, d_y, alpha, beta, kDefaultStream);
+        launch_ell_spmv(op.rows, op.width, op.idx, op.val, d_x, d_y, alpha, beta, op.knobs, kDefaultStream);
     return 0;
 }
 
@@ -352,6 +357,7 @@ extern "C" int spmv_amd_init_stencil5_synthetic(const char* mode, int n) {
         case Which::Csr:
             if (g_csr.init_synthetic(n) != 0) return EXIT_FAILURE;
             HIP_CHECK(hipStreamSynchronize(kDefaultStream));
+            g_csr.shape = current_launch_shape();
             g_csr.variant_name = csr_variant_name(g_csr.csr_variant, g_csr.A.view);
             return 0;
         case Which::Ell: return ell_init_synthetic(g_ell, n);

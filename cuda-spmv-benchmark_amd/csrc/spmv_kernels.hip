@@ -921,26 +921,29 @@ static int wavetile_blocks(const LaunchShape& shape) {
     return blocks < 8 ? 8 : blocks;
 }
 
-static int env_int(const char* name, int fallback) {
-    const char* v = getenv(name);
-    return (v && *v) ? atoi(v) : fallback;
+static int plan_partials(const Stencil5Plan& p) {
+    if (p.variant == Stencil5Variant::RowGeneric) return p.row_blocks * kWavesPerBlock;
+    if (p.variant == Stencil5Variant::RowDirect)
+        return p.row_blocks * ((p.gi_hi - p.gi_lo + p.rows_per_task - 1) / p.rows_per_task);
+    if (p.variant == Stencil5Variant::RowLds) return p.row_blocks * (p.gi_hi - p.gi_lo);
+    if (p.variant == Stencil5Variant::WaveTile) return p.tile_blocks * kWavesPerBlock;
+    return (p.march_blocks + (p.head_rows ? p.row_blocks : 0) + (p.tail_rows ? p.row_blocks : 0)) * kWavesPerBlock;
 }
 
-namespace {
-struct Stencil5Plan {
-    Stencil5Variant variant;
-    // column-march: the range splits into up to two global-boundary grid rows (row kernel) and
-    // the grid rows [gi_lo, gi_hi) in between
-    bool head_rows = false, tail_rows = false;
-    int gi_lo = 0, gi_hi = 0, rows_per_task = 0, strips = 0, march_blocks = 0;
-    int row_blocks = 0;  // blocks of one boundary-grid-row launch
-    int tile_blocks = 0;
-    bool oneshot = true;
-};
+static const char* plan_name(const Stencil5Plan& p, const SlabCsr& m) {
+    switch (p.variant) {
+        case Stencil5Variant::RowDirect: return "stencil5/row-direct";
+        case Stencil5Variant::RowLds: return "stencil5/row-lds";
+        case Stencil5Variant::ColumnMarch: return "stencil5/column-march";
+        case Stencil5Variant::WaveTile: return "stencil5/wave-tile";
+        default: return m.verified_stencil ? "stencil5/row-generic" : "stencil5/row-generic(csr-loop)";
+    }
+}
 
 Stencil5Plan plan_stencil5(const SlabCsr& m, int first_row, int last_row, Stencil5Variant variant,
                            const LaunchShape& shape) {
     Stencil5Plan p;
+    const Tunables& knobs = shape.knobs;
     const int n = m.grid_size;
     const bool tile_ok = m.verified_stencil && n >= kTileRows;
     const bool march_ok = tile_ok && m.row_offset % n == 0 && m.n_local % n == 0 &&
@@ -948,7 +951,7 @@ Stencil5Plan plan_stencil5(const SlabCsr& m, int first_row, int last_row, Stenci
     const bool direct_ok = m.verified_stencil && n >= 2 && m.row_offset % n == 0 &&
                            m.n_local % n == 0 && first_row % n == 0 && last_row % n == 0;
     // row-lds needs grid rows long enough that the two clamped edge tiles are a small share
-    const int lds_min_n = env_int("SPMV_AMD_ROWLDS_MIN_GRID", 512);
+    const int lds_min_n = knobs.rowlds_min_grid;
     if (variant == Stencil5Variant::Auto)
         variant = direct_ok ? (n >= lds_min_n ? Stencil5Variant::RowLds : Stencil5Variant::RowDirect)
                   : tile_ok ? Stencil5Variant::WaveTile
@@ -965,18 +968,18 @@ Stencil5Plan plan_stencil5(const SlabCsr& m, int first_row, int last_row, Stenci
         p.gi_lo = first_row / n;
         p.gi_hi = last_row / n;
         p.row_blocks = (int)blocks_for(n);  // column blocks per grid row
-        p.rows_per_task = env_int("SPMV_AMD_DIRECT_ROWS", 1);
+        p.rows_per_task = knobs.direct_rows;
         if (p.rows_per_task != 2 && p.rows_per_task != 4) p.rows_per_task = 1;
     } else if (variant == Stencil5Variant::RowLds) {
         p.gi_lo = first_row / n;
         p.gi_hi = last_row / n;
         p.row_blocks = (n + kLdsTileCols - 1) / kLdsTileCols;  // column tiles (= workgroups) per grid row
-        p.rows_per_task = env_int("SPMV_AMD_ROWLDS_GROUP", 4);  // consecutive tiles per XCD
+        p.rows_per_task = knobs.rowlds_group;  // consecutive tiles per XCD
         if (p.rows_per_task < 1 || p.rows_per_task > 64) p.rows_per_task = 4;
     } else if (variant == Stencil5Variant::WaveTile) {
         // one tile per wave in dispatch order by default (4.65 ms at 20 000^2); SPMV_AMD_WAVETILE_ONESHOT=0
         // selects the persistent, XCD-banded walk (5.87 ms), kept for the record
-        p.oneshot = env_int("SPMV_AMD_WAVETILE_ONESHOT", 1) != 0;
+        p.oneshot = knobs.wavetile_oneshot != 0;
         const int tiles = (last_row + kTileRows - 1) / kTileRows - first_row / kTileRows;
         p.tile_blocks = p.oneshot ? (tiles + kWavesPerBlock - 1) / kWavesPerBlock : wavetile_blocks(shape);
     } else {
@@ -992,50 +995,49 @@ Stencil5Plan plan_stencil5(const SlabCsr& m, int first_row, int last_row, Stenci
         const int G = p.gi_hi - p.gi_lo;
         if (G > 0) {
             // enough blocks for several rounds over the chip, few enough start-up rows per task
-            const long long target = (long long)shape.compute_units * env_int("SPMV_AMD_MARCH_BLOCKS_PER_CU", 20);
+            const long long target = (long long)shape.compute_units * knobs.march_blocks_per_cu;
             long long R = ((long long)G * strip_groups) / (target > 0 ? target : 1);
             // measured on MI355X at n = 20000: 16 rows per task beats 8 / 32 / 64 (4.40 vs 4.53 / 4.66 / 4.58 ms)
-            const int r_max = env_int("SPMV_AMD_MARCH_MAX_ROWS", 16), r_min = 4;
+            const int r_max = knobs.march_max_rows, r_min = 4;
             R = R > r_max ? r_max : (R < r_min ? r_min : R);
             if (R > G) R = G;
-            p.rows_per_task = env_int("SPMV_AMD_ROWS_PER_TASK", (int)R);
+            p.rows_per_task = knobs.march_rows_per_task > 0 ? knobs.march_rows_per_task : (int)R;
             if (p.rows_per_task < 1) p.rows_per_task = 1;
             p.march_blocks = ((G + p.rows_per_task - 1) / p.rows_per_task) * strip_groups;
         }
     }
+    p.first_row = first_row;
+    p.last_row = last_row;
+    p.partials = plan_partials(p);
+    p.name = plan_name(p, m);
     return p;
 }
-}  // namespace
 
 int stencil5_partials_needed(const SlabCsr& m, int first_row, int last_row, Stencil5Variant variant,
                              const LaunchShape& shape) {
-    const Stencil5Plan p = plan_stencil5(m, first_row, last_row, variant, shape);
-    if (p.variant == Stencil5Variant::RowGeneric) return p.row_blocks * kWavesPerBlock;
-    if (p.variant == Stencil5Variant::RowDirect)
-        return p.row_blocks * ((p.gi_hi - p.gi_lo + p.rows_per_task - 1) / p.rows_per_task);
-    if (p.variant == Stencil5Variant::RowLds) return p.row_blocks * (p.gi_hi - p.gi_lo);
-    if (p.variant == Stencil5Variant::WaveTile) return p.tile_blocks * kWavesPerBlock;
-    return (p.march_blocks + (p.head_rows ? p.row_blocks : 0) + (p.tail_rows ? p.row_blocks : 0)) * kWavesPerBlock;
+    return plan_stencil5(m, first_row, last_row, variant, shape).partials;
 }
 
 const char* stencil5_variant_name(const SlabCsr& m, int first_row, int last_row, Stencil5Variant variant,
                                   const LaunchShape& shape) {
-    switch (plan_stencil5(m, first_row, last_row, variant, shape).variant) {
-        case Stencil5Variant::RowDirect: return "stencil5/row-direct";
-        case Stencil5Variant::RowLds: return "stencil5/row-lds";
-        case Stencil5Variant::ColumnMarch: return "stencil5/column-march";
-        case Stencil5Variant::WaveTile: return "stencil5/wave-tile";
-        default: return m.verified_stencil ? "stencil5/row-generic" : "stencil5/row-generic(csr-loop)";
-    }
+    return plan_stencil5(m, first_row, last_row, variant, shape).name;
 }
 
+// One-off form (plans, then launches): for callers outside a loop.
 int launch_stencil5_spmv(const SlabCsr& m, const double* x, double* y, double alpha,
                          int first_row, int last_row, double* d_dot_partials,
                          const int* d_skip_flag, Stencil5Variant variant,
                          const LaunchShape& shape, hipStream_t stream) {
     if (last_row <= first_row) return 0;
+    return launch_stencil5_spmv(m, plan_stencil5(m, first_row, last_row, variant, shape), x, y, alpha, d_dot_partials,
+                                d_skip_flag, shape.reverse, stream);
+}
+
+int launch_stencil5_spmv(const SlabCsr& m, const Stencil5Plan& p, const double* x, double* y, double alpha,
+                         double* d_dot_partials, const int* d_skip_flag, bool reverse, hipStream_t stream) {
+    const int first_row = p.first_row, last_row = p.last_row;
+    if (last_row <= first_row) return 0;
     const int n = m.grid_size;
-    const Stencil5Plan p = plan_stencil5(m, first_row, last_row, variant, shape);
     const bool dot = d_dot_partials != nullptr;
     const bool analytic = m.verified_stencil && n >= 2;
 
@@ -1085,11 +1087,11 @@ int launch_stencil5_spmv(const SlabCsr& m, const double* x, double* y, double al
         const int gfirst = m.row_offset / n;
         if (dot)
             hipLaunchKernelGGL((stencil5_rowlds_kernel<true>), grid, dim3(64), 0, stream, m, x, y, alpha, p.gi_lo, 1,
-                               gfirst, p.row_blocks, (int)tiles, p.rows_per_task, shape.reverse ? 1 : 0, d_dot_partials,
+                               gfirst, p.row_blocks, (int)tiles, p.rows_per_task, reverse ? 1 : 0, d_dot_partials,
                                d_skip_flag);
         else
             hipLaunchKernelGGL((stencil5_rowlds_kernel<false>), grid, dim3(64), 0, stream, m, x, y, alpha, p.gi_lo, 1,
-                               gfirst, p.row_blocks, (int)tiles, p.rows_per_task, shape.reverse ? 1 : 0, d_dot_partials,
+                               gfirst, p.row_blocks, (int)tiles, p.rows_per_task, reverse ? 1 : 0, d_dot_partials,
                                d_skip_flag);
         return (int)tiles;
     }
@@ -1140,12 +1142,11 @@ int launch_stencil5_spmv(const SlabCsr& m, const double* x, double* y, double al
     return used;
 }
 
-int launch_stencil5_spmv_first_and_last_gridrow(const SlabCsr& m, const double* x, double* y, double alpha,
-                                                double* d_dot_partials, const int* d_skip_flag,
+int launch_stencil5_spmv_first_and_last_gridrow(const SlabCsr& m, const Stencil5Plan& head, const double* x, double* y,
+                                                double alpha, double* d_dot_partials, const int* d_skip_flag,
                                                 const LaunchShape& shape, hipStream_t stream) {
     const int n = m.grid_size;
     const int local_gridrows = n > 0 ? m.n_local / n : 0;
-    const Stencil5Plan head = plan_stencil5(m, 0, n > 0 ? n : 0, Stencil5Variant::Auto, shape);
     if (n <= 0 || local_gridrows < 2 || head.variant != Stencil5Variant::RowLds) {
         // two launches over the two row ranges (any variant)
         int used = launch_stencil5_spmv(m, x, y, alpha, 0, n, d_dot_partials, d_skip_flag, Stencil5Variant::Auto, shape, stream);
@@ -1178,7 +1179,6 @@ int launch_stencil5_spmv_first_and_last_gridrow(const SlabCsr& m, const double* 
 CsrVariant csr_auto_variant(const SlabCsr& m) {
     const double avg = m.n_local > 0 ? (double)m.nnz_local / m.n_local : 0.0;
     return avg <= 10.0    ? CsrVariant::Stream
-           : avg <= 8.0   ? CsrVariant::RowScalar
            : avg <= 16.0  ? CsrVariant::SubWave4
            : avg <= 32.0  ? CsrVariant::SubWave8
            : avg <= 64.0  ? CsrVariant::SubWave16
@@ -1187,7 +1187,7 @@ CsrVariant csr_auto_variant(const SlabCsr& m) {
 }
 
 void launch_csr_spmv(const SlabCsr& m, const double* x, double* y, double alpha,
-                     CsrVariant variant, hipStream_t stream) {
+                     CsrVariant variant, const Tunables& knobs, hipStream_t stream) {
     if (m.n_local == 0) return;
     if (variant == CsrVariant::Auto) variant = csr_auto_variant(m);
     const long long rows = m.n_local;
@@ -1198,12 +1198,12 @@ void launch_csr_spmv(const SlabCsr& m, const double* x, double* y, double alpha,
             // threads x entries per thread; measured on MI355X at 10 000^2 / 15 000^2: 256 x 4 1.43 / 3.13 ms,
             // 64 x 6 1.42 / 3.23-3.40, 64 x 8 1.55 / 3.30, 128 x 5 1.44 / 3.20 -> unlike the dense streams, the
             // one-wave shapes do not pay here (fewer rows per block = more shared edge lines)
-            const int shape = env_int("SPMV_AMD_CSR_STREAM_SHAPE", 0);  // 0: 256 x 4, 1: 64 x 6, 2: 64 x 8, 3: 128 x 5
+            const int shape = knobs.csr_stream_shape;  // 0: 256 x 4, 1: 64 x 6, 2: 64 x 8, 3: 128 x 5
             const int threads = shape == 0 ? 256 : (shape == 3 ? 128 : 64);
             const int cap = shape == 0 ? 1024 : (shape == 1 ? 384 : (shape == 2 ? 512 : 640));
             int per_block = (int)(0.9 * cap / (avg > 1.0 ? avg : 1.0));
             per_block = per_block > threads ? threads : (per_block < 16 ? 16 : per_block & ~15);
-            per_block = env_int("SPMV_AMD_CSR_STREAM_ROWS", per_block);
+            if (knobs.csr_stream_rows > 0) per_block = knobs.csr_stream_rows;
             if (per_block > threads) per_block = threads;
             const dim3 grid((unsigned)((rows + per_block - 1) / per_block));
 #define SPMV_AMD_CSR_STREAM(T, P) \
@@ -1239,11 +1239,11 @@ void launch_ell_transpose(int rows, int width, const int* idx_rowmajor, const do
 }
 
 void launch_ell_spmv(int rows, int width, const int* idx, const double* val, const double* x,
-                     double* y, double alpha, double beta, hipStream_t stream) {
+                     double* y, double alpha, double beta, const Tunables& knobs, hipStream_t stream) {
     if (rows == 0) return;
     // bit 0: one-wave workgroups, bit 1: nontemporal planes / y. Measured on MI355X at 15 000^2 (generic /
     // stencil-aware): 0: 3.22 / 2.32 ms, 1: 3.00 / 2.51, 2: 2.96 / 2.26, 3: 3.00 / 2.47 -> 2.
-    const int shape = env_int("SPMV_AMD_ELL_SHAPE", 2);
+    const int shape = knobs.ell_shape;
 #define SPMV_AMD_ELL(B, NT)                                                                                   \
     hipLaunchKernelGGL((ell_spmv_kernel<B, NT>), dim3((unsigned)(((long long)rows + B - 1) / B)), dim3(B), 0, \
                        stream, rows, width, idx, val, x, y, alpha, beta)
@@ -1256,13 +1256,13 @@ void launch_ell_spmv(int rows, int width, const int* idx, const double* val, con
 
 void launch_ell_stencil5_spmv(int rows, int width, int grid_size, const int* idx,
                               const double* val, const double* x, double* y, double alpha,
-                              double beta, hipStream_t stream) {
+                              double beta, const Tunables& knobs, hipStream_t stream) {
     if (rows == 0) return;
     if (grid_size < 3 || (long long)grid_size * grid_size != rows) {
-        launch_ell_spmv(rows, width, idx, val, x, y, alpha, beta, stream);
+        launch_ell_spmv(rows, width, idx, val, x, y, alpha, beta, knobs, stream);
         return;
     }
-    const int shape = env_int("SPMV_AMD_ELL_SHAPE", 2);
+    const int shape = knobs.ell_shape;
 #define SPMV_AMD_ELL5(B, NT)                                                                                      \
     hipLaunchKernelGGL((ell_stencil5_kernel<B, NT>), dim3((unsigned)(((long long)rows + B - 1) / B)), dim3(B), 0, \
                        stream, rows, width, grid_size, idx, val, x, y, alpha, beta)

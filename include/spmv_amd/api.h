@@ -212,6 +212,20 @@ const char* spmv_amd_operator_variant(const char* mode);
  * whose preconditions the matrix does not meet falls back to the next applicable one. */
 int spmv_amd_operator_select_variant(const char* mode, const char* variant);
 
+/* ---- the CG building blocks one at a time (device pointers, each call synchronises) ----
+ * reference kernels: axpy_kernel / axpby_kernel (cg_solver.cu:38-54), axpy_kernel_device /
+ * axpy_sub_kernel_device (:59-74), update_p_kernel (:90-95), dot_kernel + final_sum_kernel (:110-132,384-409). */
+int spmv_amd_blas1_axpy(size_t n, double a, const double* d_x, double* d_y);
+int spmv_amd_blas1_axpby(size_t n, double a, const double* d_x, double b, const double* d_y, double* d_z);
+int spmv_amd_blas1_axpy_dev(size_t n, double a, const double* d_x, double* d_y, int subtract);
+int spmv_amd_blas1_update_p_dev(size_t n, const double* d_r, double b, double* d_p);
+int spmv_amd_blas1_dot(size_t n, const double* d_x, const double* d_y, double* result);
+/* The slab solver's fused steps on caller data. which = 0: r -= (rr_old/pAp)*Ap and r.r (d_a = Ap, d_b = r);
+ * 1: p_out = r + beta*p_in (d_a = r, d_b = p_in, d_c = p_out); 2: r = b - Ap, p = r and r.r (d_a = b, d_b = Ap,
+ * d_c = [r | p], 2n doubles). scalars = {rr_old, pAp, beta}. reverse: sweep direction (results must not depend on it). */
+int spmv_amd_cg_fused_step(int which, size_t n, const double* scalars, const double* d_a, double* d_b, double* d_c,
+                           int reverse, double* dot_out);
+
 /* ---- residual history of the most recent CG solve in this process ---- */
 /* Copies ||r_k||, k = 0..iterations, into out (at most cap values); returns how
  * many the solve recorded. */

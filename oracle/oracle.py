@@ -168,6 +168,31 @@ def spmv_ell(rows, width, idx, val, x, y0=None, alpha=1.0, beta=0.0):
     return y
 
 
+def axpy(alpha, x, y):
+    y = _f64(y).copy()
+    lib().oracle_axpy(len(y), C.c_double(alpha), _dp(_f64(x)), _dp(y))
+    return y
+
+
+def axpby(alpha, x, beta, y):
+    x, y = _f64(x), _f64(y)
+    z = np.empty_like(x)
+    lib().oracle_axpby(len(x), C.c_double(alpha), _dp(x), C.c_double(beta), _dp(y), _dp(z))
+    return z
+
+
+def axpy_sub(alpha, x, y):
+    y = _f64(y).copy()
+    lib().oracle_axpy_sub(len(y), C.c_double(alpha), _dp(_f64(x)), _dp(y))
+    return y
+
+
+def update_p(r, beta, p):
+    p = _f64(p).copy()
+    lib().oracle_update_p(len(p), _dp(_f64(r)), C.c_double(beta), _dp(p))
+    return p
+
+
 def dot_host(x, y):
     x, y = _f64(x), _f64(y)
     return lib().oracle_dot_host(len(x), _dp(x), _dp(y))
@@ -289,3 +314,19 @@ def ref_load_matrix_market(path):
 
 def ref_write_stencil5(n, path):
     return ref_io().write_matrix_market_stencil5(int(n), path.encode())
+
+
+def ref_read_matrix_symtogen(path):
+    """The reference's own symmetric reader (src/io/io.cu:189-310, compiled in place into oracle/_ref):
+    returns rows, cols, stored nnz, expanded nnz and its CSR arrays (columns in a row unsorted, io.cu:288-307)."""
+    L = ref_io()
+    m = RefMatrixData()
+    rows, cols, nnz, full = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    rp, ci, va = C.POINTER(C.c_int)(), C.POINTER(C.c_int)(), C.POINTER(C.c_double)()
+    L.read_matrix_symtogen(C.byref(m), os.fsencode(path), C.byref(rows), C.byref(cols), C.byref(nnz), C.byref(rp), C.byref(ci), C.byref(va), C.byref(full))
+    out = (rows.value, cols.value, nnz.value, full.value, np.ctypeslib.as_array(rp, shape=(rows.value + 1,)).copy(),
+           np.ctypeslib.as_array(ci, shape=(full.value,)).copy(), np.ctypeslib.as_array(va, shape=(full.value,)).copy())
+    libc = C.CDLL(None)
+    for ptr in (rp, ci, va):
+        libc.free(ptr)
+    return out

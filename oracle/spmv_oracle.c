@@ -243,6 +243,30 @@ void oracle_spmv_ell(int rows, int width, const int* ell_idx, const double* ell_
 }
 
 /* ------------------------------------------------------------------ */
+/* BLAS1 kernels, element for element (nvcc contracts a*x + y to fma)  */
+/* ------------------------------------------------------------------ */
+
+/* axpy_kernel: y[i] = alpha*x[i] + y[i] (cg_solver.cu:38-43; mgpu :125-130) */
+void oracle_axpy(int n, double alpha, const double* x, double* y) {
+    for (int i = 0; i < n; i++) y[i] = fma(alpha, x[i], y[i]);
+}
+
+/* axpby_kernel: z[i] = alpha*x[i] + beta*y[i] (cg_solver.cu:48-54; mgpu :136-140 writes y in place) */
+void oracle_axpby(int n, double alpha, const double* x, double beta, const double* y, double* z) {
+    for (int i = 0; i < n; i++) z[i] = fma(alpha, x[i], beta * y[i]);
+}
+
+/* axpy_sub_kernel_device: y[i] -= alpha*x[i], i.e. y[i] = fma(-alpha, x[i], y[i]) (cg_solver.cu:69-74) */
+void oracle_axpy_sub(int n, double alpha, const double* x, double* y) {
+    for (int i = 0; i < n; i++) y[i] = fma(-alpha, x[i], y[i]);
+}
+
+/* update_p_kernel: p[i] = r[i] + beta*p[i] (cg_solver.cu:90-95) */
+void oracle_update_p(int n, const double* r, double beta, double* p) {
+    for (int i = 0; i < n; i++) p[i] = fma(beta, p[i], r[i]);
+}
+
+/* ------------------------------------------------------------------ */
 /* dot products (cg_solver.cu:110-149, 384-409)                        */
 /* ------------------------------------------------------------------ */
 

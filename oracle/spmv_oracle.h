@@ -96,6 +96,14 @@ void oracle_build_ell(int rows, const int* row_ptr, const int* col_idx, const do
 void oracle_spmv_ell(int rows, int width, const int* ell_idx, const double* ell_val,
                      const double* x, double* y, double alpha, double beta);
 
+/* The BLAS1 kernels element for element, nvcc's contraction written out as fma():
+ * axpy_kernel (cg_solver.cu:38-43), axpby_kernel (:48-54), axpy_sub_kernel_device (:69-74),
+ * update_p_kernel (:90-95). */
+void oracle_axpy(int n, double alpha, const double* x, double* y);
+void oracle_axpby(int n, double alpha, const double* x, double beta, const double* y, double* z);
+void oracle_axpy_sub(int n, double alpha, const double* x, double* y);
+void oracle_update_p(int n, const double* r, double beta, double* p);
+
 /* dot_kernel + sum_block_results (cg_solver.cu:110-149): 256-wide tree per block,
  * then a left-to-right host sum over the blocks. */
 double oracle_dot_host(int n, const double* x, const double* y);

@@ -293,3 +293,39 @@ def test_slab_solver_nonzero_initial_guess_and_zero_iterations(B, O, fresh_host_
     st0 = slab.solve(max_iters=0)
     assert st0.iterations == 0 and st0.converged == 0 and np.array_equal(slab.gather(), x0)
     slab.destroy()
+
+
+@pytest.mark.parametrize("name", ["sym_spd40.mtx", "sym_stencil8.mtx", "sym_hand3.mtx"])
+def test_symmetric_matrix_market_file_through_the_operators_and_cg(B, O, fresh_host_matrices, name):
+    """a `coordinate real symmetric` file -> load_matrix_market (expanded to general, the reference reader's
+    own expansion order, checked against reference src/io/io.cu:189-310 in test_host_logic.py) -> every operator:
+    SpMV bit-exact against oracle_spmv_csr on the sorted CSR, CG (all three are SPD) at 1e-10 against the oracle."""
+    m = B.load_matrix_market(os.path.join(GOLDEN, name))
+    rows = m.c.rows
+    rp, ci, va = O.build_csr(m.entries, rows)
+    x = np.random.default_rng(3).standard_normal(rows)
+    want = O.spmv_csr(rp, ci, va, x)
+    grid = m.c.grid_size
+    for mode in ("cusparse-csr", "ellpack", "stencil5-csr", "stencil5-ellpack"):
+        op = B.Operator(mode)
+        assert op.init(m) == 0
+        got, ms = op.run_timed(x)
+        if mode == "stencil5-csr" and grid > 0:   # interior rows in W,C,E,N,S order
+            assert np.array_equal(got, O.spmv_stencil5(rp, ci, va, x, grid))
+        else:
+            assert np.array_equal(got, want), mode
+        op.free()
+    op = B.Operator("cusparse-csr")
+    assert op.init(m) == 0
+    xs, hist, st = B.cg_solve(op, m, np.ones(rows), np.zeros(rows), device=True)
+    xo, ho, ro = O.cg(rp, ci, va, -1, np.ones(rows), np.zeros(rows), device_form=True)
+    assert st.iterations == ro.iterations and st.converged == 1
+    assert hist_err(hist, ho) < TOL and np.max(np.abs(xs - xo)) <= TOL * np.max(np.abs(xo))
+    op.free()
+    # and the slab solver on the same host matrix
+    B.lib().spmv_amd_reset_host_matrices()
+    slab = B.CgSlab.from_matrix(m)
+    st2 = slab.solve()
+    assert st2.iterations == ro.iterations and hist_err(slab.history(), ho) < TOL
+    assert np.max(np.abs(slab.gather() - xo)) <= TOL * np.max(np.abs(xo))
+    slab.destroy()

@@ -4,7 +4,9 @@ offset arithmetic, harness statistics/metrics, and that the library loads and ex
 symbol include/spmv_amd/api.h declares. No GPU compute is called here."""
 import ctypes as C
 import filecmp
+import json
 import os
+import re
 
 import numpy as np
 import pytest
@@ -99,6 +101,46 @@ def test_symmetric_reader_expands(B, tmp_path):
     assert m.c.nnz == 6
     got = sorted((int(e["row"]), int(e["col"]), float(e["value"])) for e in m.entries)
     assert got == [(0, 0, 2.0), (0, 1, -1.0), (1, 0, -1.0), (1, 1, 2.0), (1, 2, -1.0), (2, 1, -1.0)]
+
+
+@pytest.mark.parametrize("name", ["sym_hand3.mtx", "sym_spd40.mtx", "sym_stencil8.mtx"])
+def test_symmetric_reader_matches_reference_symtogen(B, O, name):
+    """read_matrix_symtogen against the reference's own reader (src/io/io.cu:189-310): against its committed output
+    (tests/golden/symmetric_reader.json, made by make_symmetric_golden.py through oracle/_ref/libref_io.so) and, where
+    that library exists, against a live call. Dimensions, both counts and the CSR arrays must be identical,
+    including the reader's unsorted column order inside a row. load_matrix_market must hand the same expanded
+    matrix on as entries (the reference leaves mat->entries unset there: documented deviation)."""
+    path = os.path.join(GOLDEN, name)
+    want = json.load(open(os.path.join(GOLDEN, "symmetric_reader.json")))["files"][name]
+    assert B.lib().read_matrix_type(path.encode()) == 2
+    rows, cols, nnz, full, rp, ci, va, ent = B.read_matrix_symtogen(path)
+    assert (rows, cols, nnz, full) == (want["rows"], want["cols"], want["nnz_stored"], want["nnz_general"])
+    assert rp.tolist() == want["row_ptr"] and ci.tolist() == want["col_idx"] and va.tolist() == want["values"]
+    if O.ref_io_available():
+        live = O.ref_read_matrix_symtogen(path)
+        assert live[:4] == (rows, cols, nnz, full)
+        assert np.array_equal(live[4], rp) and np.array_equal(live[5], ci) and np.array_equal(live[6], va)
+    # the expanded entries, bucketed by row in list order, ARE that CSR
+    m = B.load_matrix_market(path)
+    assert (m.c.rows, m.c.cols, m.c.nnz) == (rows, cols, full) and np.array_equal(m.entries, ent)
+    order = np.argsort(ent["row"], kind="stable")
+    assert np.array_equal(ent["col"][order], ci) and np.array_equal(ent["value"][order], va)
+    # and it is symmetric
+    dense = np.zeros((rows, cols))
+    dense[ent["row"], ent["col"]] = ent["value"]
+    assert np.array_equal(dense, dense.T)
+    assert m.c.grid_size == (8 if name == "sym_stencil8.mtx" else -1)
+
+
+def test_only_the_declared_api_leaves_the_library(B):
+    """csrc/exports.map: exactly the declared symbols are dynamic exports; no spmv_amd::launch_* or kernel stub leaks."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", B.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {line.split()[-1] for line in out.splitlines() if line.strip()}
+    declared = set(B.DECLARED_SYMBOLS + B.DECLARED_CXX_SYMBOLS)
+    assert exported == declared, (sorted(exported - declared)[:10], sorted(declared - exported)[:10])
+    listed = set(re.findall(r"^\s+([A-Za-z_][A-Za-z0-9_]*);", open(os.path.join(ROOT, "cuda-spmv-benchmark_amd", "csrc", "exports.map")).read(), flags=re.M))
+    assert listed == declared
 
 
 @pytest.mark.parametrize("case", ["stencil81_old", "stencil40", "random", "unbalanced", "upper"])

@@ -1,7 +1,8 @@
 // tools/rocalution_cg.cpp -- comparator slot (the role AmgX plays in the reference's
 // external/benchmarks/amgx): the vendor library's unpreconditioned CG (rocALUTION) on the same generator stencil,
 // b = 1, x0 = 0, relative tolerance 1e-6. Not part of the product; nothing here is linked into libspmv_amd.so.
-//   hipcc -O2 tools/rocalution_cg.cpp -lrocalution -o tools/bin/rocalution_cg ;  tools/bin/rocalution_cg 20000
+//   make -C tools  (-> tools/bin/rocalution_cg) ;  tools/bin/rocalution_cg 20000 [runs]
+// The last line, "RESULT iterations=<k> residual=<%.17e> ...", is what tests/test_comparators_gpu.py parses.
 #include <hip/hip_runtime.h>
 #include <rocalution/rocalution.hpp>
 #include <stdio.h>
@@ -72,6 +73,7 @@ int main(int argc, char** argv) {
                "median of %d solves %.2f ms (min %.2f, max %.2f) = %.1f iterations/s\n",
                n, n, (long long)rows, iterations, residual, runs, ms[ms.size() / 2], ms.front(), ms.back(),
                iterations / (ms[ms.size() / 2] / 1e3));
+        printf("RESULT iterations=%d residual=%.17e grid=%d median_ms=%.4f\n", iterations, residual, n, ms[ms.size() / 2]);
         cg.Clear();
     }
     stop_rocalution();

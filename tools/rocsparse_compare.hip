@@ -1,8 +1,11 @@
 // tools/rocsparse_compare.hip -- comparator slot (the role AmgX / cuSPARSE play for the
 // reference): the vendor library's CSR SpMV on the same synthetic 5-point matrix, same timing rule.
 // Not part of the product and not linked into libspmv_amd.so.
-//   hipcc --offload-arch=gfx950 -O3 tools/rocsparse_compare.hip -lrocsparse -o tools/bin/rocsparse_compare
-//   tools/bin/rocsparse_compare 10000
+//   make -C tools            (-> tools/bin/rocsparse_compare)
+//   tools/bin/rocsparse_compare 10000                  timing of every rocsparse_spmv CSR algorithm, x = 1
+//   tools/bin/rocsparse_compare 2048 x.bin y.bin       x read from x.bin (rows doubles), y of the default algorithm
+//                                                      written to y.bin: what tests/test_comparators_gpu.py compares
+//                                                      with this repository's operators
 #include <hip/hip_runtime.h>
 #include <rocsparse/rocsparse.h>
 #include <stdio.h>
@@ -38,6 +41,8 @@ __global__ void fill(double* p, size_t n, double v) { size_t i = (size_t)blockId
 
 int main(int argc, char** argv) {
     const int n = argc > 1 ? atoi(argv[1]) : 10000;
+    const char* x_file = argc > 3 ? argv[2] : nullptr;
+    const char* y_file = argc > 3 ? argv[3] : nullptr;
     const long long rows = (long long)n * n, nnz = 5LL * n * n - 4LL * n;
     int *rp, *ci; double *va, *x, *y;
     CK(hipMalloc(&rp, (rows + 1) * 4)); CK(hipMalloc(&ci, nnz * 4)); CK(hipMalloc(&va, nnz * 8));
@@ -45,6 +50,13 @@ int main(int argc, char** argv) {
     hipLaunchKernelGGL(gen, dim3((unsigned)((rows + 256) / 256)), dim3(256), 0, 0, n, rp, ci, va);
     hipLaunchKernelGGL(fill, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, 0, x, (size_t)rows, 1.0);
     CK(hipDeviceSynchronize());
+    if (x_file) {
+        std::vector<double> hx((size_t)rows);
+        FILE* f = fopen(x_file, "rb");
+        if (!f || fread(hx.data(), sizeof(double), (size_t)rows, f) != (size_t)rows) { printf("cannot read %s\n", x_file); return 1; }
+        fclose(f);
+        CK(hipMemcpy(x, hx.data(), (size_t)rows * 8, hipMemcpyHostToDevice));
+    }
     rocsparse_handle h; RS(rocsparse_create_handle(&h));
     rocsparse_spmat_descr A; rocsparse_dnvec_descr vx, vy;
     RS(rocsparse_create_csr_descr(&A, rows, rows, nnz, rp, ci, va, rocsparse_indextype_i32, rocsparse_indextype_i32, rocsparse_index_base_zero, rocsparse_datatype_f64_r));
@@ -73,6 +85,14 @@ int main(int argc, char** argv) {
         std::vector<double> hy(8);
         CK(hipMemcpy(hy.data(), y, 64, hipMemcpyDeviceToHost));
         printf("rocsparse_spmv CSR %-13s grid %d: median %.3f ms  %.1f GB/s (reference 'effective' bytes)  y[0..2]=%g %g %g\n", a.name, n, med, bytes / med / 1e6, hy[0], hy[1], hy[2]);
+        if (y_file && a.alg == rocsparse_spmv_alg_default) {
+            std::vector<double> out((size_t)rows);
+            CK(hipMemcpy(out.data(), y, (size_t)rows * 8, hipMemcpyDeviceToHost));
+            FILE* f = fopen(y_file, "wb");
+            if (!f || fwrite(out.data(), sizeof(double), (size_t)rows, f) != (size_t)rows) { printf("cannot write %s\n", y_file); return 1; }
+            fclose(f);
+            printf("wrote y of rocsparse_spmv (default algorithm) to %s\n", y_file);
+        }
         CK(hipFree(buf));
     }
     return 0;
