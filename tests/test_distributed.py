@@ -169,9 +169,9 @@ def test_watchdog_turns_a_wedged_barrier_into_a_diagnosable_exit(tmp_path):
 
 @pytest.mark.gpu
 def test_watchdog_names_the_stage_of_a_wedged_all_reduce(tmp_path):
-    """Two-rank staged communicator whose all-reduce callback stops answering in the third call (= the p.Ap
-    all-reduce of iteration 0, after the initial r.r and ... ): the solve ends with the watchdog's report naming
-    the all-reduce and the iteration, with the state of both streams, instead of hanging."""
+    """Two-rank staged communicator whose all-reduce callback stops answering in its third call (initial r.r, p.Ap of
+    iteration 0, then r.r of iteration 0): the solve ends with the watchdog's report naming the all-reduce and the
+    iteration, with the state of both streams, instead of hanging."""
     script = tmp_path / "wedged_allreduce.py"
     script.write_text(
         "import sys, time\n"
