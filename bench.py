@@ -199,7 +199,7 @@ def cpu_baseline(sample_grid, full_rows):
     return rec
 
 
-def scaling_probe(B, torch, grid, full_ms, full_iterations, steps=5):
+def scaling_probe(B, torch, grid, full_ms, full_iterations, steps=5, use_mailbox=True):
     """What ONE GPU can say about strong scaling (N = 1 only; a projection). For P = 2, 4, 8 the real slab of the
     edge rank (one neighbour) and of a middle rank (two neighbours) of this grid -- rows [r*N/P, (r+1)*N/P), same CSR
     bytes, `grid`-double halos -- is solved for exactly `full_iterations` iterations through the complete multi-rank
@@ -215,6 +215,8 @@ def scaling_probe(B, torch, grid, full_ms, full_iterations, steps=5):
     os.environ["SPMV_AMD_SELF_NEIGHBOUR"] = os.environ["SPMV_AMD_FORCE_COLLECTIVES"] = "1"
     try:
         comm = B.Comm.rccl(0, 1, B.Comm.unique_id())
+        if comm is not None and use_mailbox:
+            out["mailbox"] = bool(comm.mailbox_enable())  # world = 1: the launch cost of the mailbox path, no peer latency
     finally:
         for k, v in saved.items():
             if v is None:
@@ -243,13 +245,19 @@ def scaling_probe(B, torch, grid, full_ms, full_iterations, steps=5):
         slab.destroy()
         return rec
 
+    out["allreduce_path"] = "peer mailbox (one rank: launch cost only)" if out.get("mailbox") else "ncclAllReduce (one rank: launch cost only)"
     for P in (2, 4, 8):
         ranks = sorted({0, min(P - 1, max(1, P // 2 - 1))})  # edge rank and (P > 2) one with two neighbours: 1 of 4, 3 of 8
         roles = [run(P, r) for r in ranks]
         slowest = max(v["ms_per_solve"] for v in roles)
-        eff = {f"{lat}us": full_ms / (P * (slowest + out["allreduces_per_solve"] * lat / 1e3)) for lat in (0, 10, 25, 50)}
+        eff = {f"{lat}us": full_ms / (P * (slowest + out["allreduces_per_solve"] * lat / 1e3)) for lat in (0, 5, 10, 25, 50)}
         out["slabs"].append({"gpus": P, "roles": roles, "slowest_role_ms_per_solve": slowest,
                              "ideal_ms_per_solve": full_ms / P, "projected_efficiency_by_allreduce_latency": eff})
+    if out.get("mailbox"):
+        # the same P = 8 slabs with the mailbox off: what two ncclAllReduce launches per iteration cost on this GPU
+        comm.mailbox_disable()
+        roles = [run(8, r) for r in (0, 3)]
+        out["p8_with_nccl_allreduce_launches"] = {"roles": roles, "slowest_role_ms_per_solve": max(v["ms_per_solve"] for v in roles)}
     comm.destroy()
     return out
 
@@ -442,6 +450,16 @@ def main():
                 print(f"bench.py: {degraded}", file=sys.stderr)
         else:
             give_up(f"RCCL unusable, and the host-staged transport is not a substitute for the headline number: {why}")
+    # The two 8-byte all-reduces per iteration: peer mailbox (stores between the GPUs' hipIpc-mapped memory, one small
+    # launch each) when every rank's mailbox passes its self-test, else the transport's own (ncclAllReduce). Both are
+    # device-side paths over xGMI; the line says which one ran. SPMV_AMD_BENCH_ALLREDUCE=rccl keeps the mailbox off.
+    allreduce = "none (single rank)"
+    if comm is not None:
+        allreduce = "ncclAllReduce" if transport == "rccl" else "host callbacks (staged)"
+        if os.environ.get("SPMV_AMD_BENCH_ALLREDUCE", "auto") != "rccl" and comm.mailbox_enable():
+            allreduce = "peer mailbox (system-scope stores into hipIpc-mapped device memory)"
+        if rank == 0:
+            print(f"bench.py: dot-product all-reduce: {allreduce}", file=sys.stderr)
     slab = B.CgSlab.stencil5(n, comm)
 
     for _ in range(args.warmup):
@@ -521,7 +539,7 @@ def main():
                            "grid": n, "unknowns": rows, "nnz": nnz, "partition": f"{world} row slab(s)", "transport": transport,
                            "iterations_per_solve": iterations, "converged": bool(st.converged), "final_residual": st.residual_norm,
                            "residual_history": [float(v) for v in hist]},
-                   transport=transport, rccl_ranks=rccl_ranks, devices=devices,
+                   transport=transport, allreduce=allreduce, rccl_ranks=rccl_ranks, devices=devices,
                    launched_by="bench.py (self-launched ranks)" if os.environ.get("SPMV_AMD_BENCH_SELF_LAUNCHED") == "1" else
                    ("external launcher (RANK/WORLD_SIZE in the environment)" if "RANK" in os.environ else "single process"),
                    roofline=roofline)

@@ -89,6 +89,8 @@ DECLARED_SYMBOLS = [
     "spmv_amd_operator_select_variant", "spmv_amd_cg_last_history", "spmv_amd_comm_unique_id", "spmv_amd_comm_create_rccl",
     "spmv_amd_comm_create_staged", "spmv_amd_comm_destroy", "spmv_amd_comm_set_world", "spmv_amd_comm_rank", "spmv_amd_comm_size", "spmv_amd_comm_selftest",
     "spmv_amd_comm_barrier", "spmv_amd_comm_transport", "spmv_amd_comm_transport_ranks",
+    "spmv_amd_comm_mailbox_enable", "spmv_amd_comm_mailbox_prepare", "spmv_amd_comm_mailbox_connect", "spmv_amd_comm_mailbox_selftest",
+    "spmv_amd_comm_mailbox_disable", "spmv_amd_comm_mailbox_ready",
     "spmv_amd_cg_slab_create", "spmv_amd_cg_slab_create_stencil5", "spmv_amd_cg_slab_create_stencil5_as", "spmv_amd_cg_slab_set_vectors", "spmv_amd_cg_slab_solve",
     "spmv_amd_cg_slab_gather", "spmv_amd_cg_slab_history", "spmv_amd_cg_slab_spmv", "spmv_amd_cg_slab_info",
     "spmv_amd_cg_slab_time_spmv", "spmv_amd_cg_slab_variant", "spmv_amd_cg_slab_destroy", "spmv_amd_version", "spmv_amd_write_stencil5_values",
@@ -168,6 +170,12 @@ def lib():
     L.spmv_amd_comm_size.argtypes = [C.c_void_p]
     L.spmv_amd_comm_selftest.argtypes = [C.c_void_p]
     L.spmv_amd_comm_barrier.argtypes = [C.c_void_p]
+    L.spmv_amd_comm_mailbox_enable.argtypes = [C.c_void_p]
+    L.spmv_amd_comm_mailbox_prepare.argtypes = [C.c_void_p, C.c_void_p]
+    L.spmv_amd_comm_mailbox_connect.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    L.spmv_amd_comm_mailbox_selftest.argtypes = [C.c_void_p, C.c_int]
+    L.spmv_amd_comm_mailbox_disable.argtypes = [C.c_void_p]
+    L.spmv_amd_comm_mailbox_ready.argtypes = [C.c_void_p]
     L.spmv_amd_comm_transport.restype = C.c_char_p
     L.spmv_amd_comm_transport.argtypes = [C.c_void_p]
     L.spmv_amd_comm_transport_ranks.argtypes = [C.c_void_p]
@@ -468,6 +476,16 @@ class Comm:
 
     def barrier(self):
         return lib().spmv_amd_comm_barrier(self.handle)
+
+    def mailbox_enable(self):
+        """Collective: peer-mailbox all-reduce over hipIpc-mapped device memory; True when every rank's passed its self-test."""
+        return lib().spmv_amd_comm_mailbox_enable(self.handle) == 1
+
+    def mailbox_ready(self):
+        return lib().spmv_amd_comm_mailbox_ready(self.handle) == 1
+
+    def mailbox_disable(self):
+        lib().spmv_amd_comm_mailbox_disable(self.handle)
 
     def transport(self):
         return lib().spmv_amd_comm_transport(self.handle).decode()

@@ -348,6 +348,10 @@ void exchange_halo(SpmvAmdCgSlab* s, double* v, hipStream_t stream) {
                            s->has_prev ? v - s->halo : nullptr, s->has_next ? v + s->n_local : nullptr, s->halo, stream);
 }
 void allreduce_scalar(SpmvAmdCgSlab* s, double* d_value, const char* stage) {
+    if (s->comm->mailbox_ready()) {  // stores between the GPUs, one small launch, nothing for the host to wait on
+        launch_mailbox_allreduce(s->comm, d_value, s->compute);
+        return;
+    }
     WatchdogScope guard(stage, s->comm->rank, s->enqueued_iteration, report_slab_state, s);
     s->comm->allreduce_sum(d_value, 1, s->compute);
 }
@@ -622,6 +626,7 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
             start_p_halo();
         }
         wait_for_status(s);
+        mailbox_check(comm);
         if (s->h_poll->converged) done = true;
         if (config->verbose >= 2 && comm->rank == 0) {
             CgScalars now;

@@ -271,6 +271,7 @@ extern "C" SpmvAmdComm* spmv_amd_comm_create_staged(int rank, int world, SpmvAmd
 
 extern "C" void spmv_amd_comm_destroy(SpmvAmdComm* comm) {
     if (comm == nullptr || comm == &g_self) return;
+    spmv_amd::mailbox_release(comm);
     if (comm == g_world) g_world = nullptr;
     delete comm;
 }

@@ -18,9 +18,37 @@
 
 #include "spmv_amd.h"
 
+// ---- peer mailbox: the dot products' all-reduce as plain stores over xGMI ----
+// An 8-byte all-reduce is pure latency: an RCCL launch per reduction costs tens of microseconds on a loop whose
+// whole iteration is ~1 ms at 8 GPUs, and there are two per iteration. Each rank therefore owns a small mailbox in
+// uncached device memory, mapped into every other rank's address space (hipIpc over the node's xGMI fabric). To
+// all-reduce, one wave writes {value, sequence} into its slot of EVERY rank's mailbox (system-scope stores, the
+// sequence number released after the value), waits until its own mailbox holds this sequence number from every rank,
+// and adds the values in rank order -- so all ranks obtain the same bits, independent of arrival order. Two slot sets
+// alternate by sequence parity: a rank can only be one all-reduce ahead of the slowest reader, never two.
+// Every wait is bounded (timeout_ticks of the 100 MHz wall clock); a timeout raises *host_error and the solver ends.
+// Optional: a communicator without a (working) mailbox all-reduces through its transport (ncclAllReduce / staged).
+constexpr int kMailboxMaxRanks = 16;
+struct MailboxSlot {
+    unsigned long long value_bits;  // the double, as bits: written and read with 8-byte system-scope atomics
+    unsigned long long seq;
+};
+struct PeerMailbox {
+    MailboxSlot* inbox;                          // this rank's mailbox: [2][world] slots
+    MailboxSlot* peer_inbox[kMailboxMaxRanks];   // every rank's mailbox as mapped into this process (own one included)
+    unsigned long long* seq;                     // all-reduces completed so far (device memory, advanced by the kernels)
+    int* host_error;                             // pinned host memory: non-zero once a wait has timed out
+    int rank, world;
+    long long timeout_ticks;
+};
+
 struct SpmvAmdComm {
     int rank = 0;
     int world = 1;
+    // device copy of the connected mailbox, or null (see above; mailbox.hip)
+    PeerMailbox* d_mailbox = nullptr;
+    struct MailboxHost* mailbox_host = nullptr;  // owner of the allocations behind d_mailbox
+    bool mailbox_ready() const { return d_mailbox != nullptr; }
     // Test hook (SPMV_AMD_FORCE_COLLECTIVES=1): issue the all-reduces even with one rank, so that a
     // 1-GPU box drives the RCCL calls of the CG loop; a 1-rank all-reduce is the identity.
     bool force_collectives = false;
@@ -61,6 +89,11 @@ struct SpmvAmdComm {
 };
 
 namespace spmv_amd {
+// In-place sum of d_value over the ranks through the mailbox (comm->mailbox_ready() must hold); one tiny launch.
+void launch_mailbox_allreduce(const SpmvAmdComm* comm, double* d_value, hipStream_t stream);
+// Aborts with a message if a mailbox wait has timed out since the last call (cheap: reads one pinned int).
+void mailbox_check(const SpmvAmdComm* comm);
+void mailbox_release(SpmvAmdComm* comm);
 // The communicator cg_solve_mgpu_partitioned uses; never NULL (SelfComm by default).
 SpmvAmdComm* world_comm();
 SpmvAmdComm* self_comm();

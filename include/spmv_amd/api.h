@@ -276,6 +276,21 @@ int spmv_amd_comm_barrier(SpmvAmdComm* comm);
 const char* spmv_amd_comm_transport(const SpmvAmdComm* comm);
 int spmv_amd_comm_transport_ranks(const SpmvAmdComm* comm);
 
+/* ---- peer-mailbox all-reduce (optional; csrc/comm.hpp) ----
+ * The two dot-product all-reduces per CG iteration (reference: MPI_Allreduce on the host,
+ * cg_solver_mgpu_partitioned.cu:583,645) as direct stores between the GPUs of one node: every rank owns a small
+ * mailbox in uncached device memory that all ranks map through hipIpc. spmv_amd_comm_mailbox_enable() does the
+ * whole set-up over the communicator's own transport (collective; returns 1 when EVERY rank has a mailbox that
+ * passed the self-test, else 0 and the communicator keeps all-reducing through RCCL / the staged callbacks).
+ * The three steps are also available one by one for callers that exchange the handles themselves. */
+#define SPMV_AMD_MAILBOX_HANDLE_BYTES 64
+int spmv_amd_comm_mailbox_enable(SpmvAmdComm* comm);
+int spmv_amd_comm_mailbox_prepare(SpmvAmdComm* comm, void* handle_out64);
+int spmv_amd_comm_mailbox_connect(SpmvAmdComm* comm, const void* all_handles, int count);
+int spmv_amd_comm_mailbox_selftest(SpmvAmdComm* comm, int rounds);
+void spmv_amd_comm_mailbox_disable(SpmvAmdComm* comm);
+int spmv_amd_comm_mailbox_ready(const SpmvAmdComm* comm);
+
 /* ---- resident multi-GPU CG (what cg_solve_mgpu_partitioned is built from) ---- */
 typedef struct SpmvAmdCgSlab SpmvAmdCgSlab;
 

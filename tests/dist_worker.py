@@ -4,6 +4,7 @@ MASTER_ADDR / MASTER_PORT set, rendezvous over gloo on 127.0.0.1.
   mode oracle : (CPU) the partitioned CG algorithm with the ORACLE's per-rank kernels and real
                 gloo messages (halo rows by send/recv, dots by all_reduce); rank 0 checks the
                 residual history against the serial oracle.
+  mode gpu-mailbox / gpu-synthetic-mailbox : as gpu / gpu-synthetic, with the peer-mailbox all-reduce switched on.
   mode gpu    : (GPU) libspmv_amd's slab solver, one rank per process sharing the box's single
                 GPU, over the staged communicator whose host callbacks are these gloo calls;
                 rank 0 checks against the oracle's partitioned CG.
@@ -81,12 +82,16 @@ def run_oracle(n, rank, world):
     print(f"rank {rank}: oracle distributed CG ok ({len(hist) - 1} iterations)")
 
 
-def run_gpu(n, rank, world, synthetic):
+def run_gpu(n, rank, world, synthetic, mailbox=False):
     B = load_binding()
     B.lib()
 
     comm = B.Comm.staged_over_torch(rank, world, dist)
     assert comm.selftest() == 0  # all-reduce + neighbour exchange + barrier through the communicator
+    if mailbox:
+        # the dot products' all-reduce as stores between the ranks' hipIpc-mapped mailboxes (here: processes sharing
+        # one GPU; on a node: GPUs over xGMI); set up over the communicator itself, self-tested on every rank
+        assert comm.mailbox_enable() and comm.mailbox_ready()
     N = n * n
     if synthetic:
         slab = B.CgSlab.stencil5(n, comm)
@@ -136,6 +141,10 @@ def main():
             run_gpu(n, rank, world, synthetic=False)
         elif mode == "gpu-synthetic":
             run_gpu(n, rank, world, synthetic=True)
+        elif mode == "gpu-mailbox":
+            run_gpu(n, rank, world, synthetic=False, mailbox=True)
+        elif mode == "gpu-synthetic-mailbox":
+            run_gpu(n, rank, world, synthetic=True, mailbox=True)
         else:
             raise SystemExit(f"unknown mode {mode}")
     finally:

@@ -61,6 +61,17 @@ def test_slab_solver_multi_rank_one_gpu(world, n, mode):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("world,n,mode", [(2, 256, "gpu-mailbox"), (3, 192, "gpu-synthetic-mailbox"), (4, 1024, "gpu-synthetic-mailbox"),
+                                          (2, 2048, "gpu-synthetic-mailbox")])
+def test_slab_solver_with_the_peer_mailbox_all_reduce(world, n, mode):
+    """The dot products' all-reduce as direct stores between hipIpc-mapped mailboxes (csrc/mailbox.hip), between 2-4
+    processes sharing the box's GPU: handles exchanged over the communicator, every rank's self-test green, then the
+    same parity bar as every other transport (iteration count, ||r_k|| and x at 1e-10 against the oracle)."""
+    outs = launch(world, mode, n)
+    assert all("slab solver over staged/gloo communicator ok" in o for o in outs)
+
+
+@pytest.mark.gpu
 def test_rccl_communicator_single_rank(B, O, fresh_host_matrices):
     uid = B.Comm.unique_id()
     assert len(uid) == B.COMM_ID_BYTES and any(uid)
