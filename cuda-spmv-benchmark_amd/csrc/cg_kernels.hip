@@ -22,6 +22,8 @@
 
 #include <stdlib.h>
 
+#include "mailbox_device.hpp"
+
 namespace spmv_amd {
 namespace {
 
@@ -136,29 +138,6 @@ __global__ __launch_bounds__(kStream) void dot_partials_kernel(size_t n, const d
 }
 
 // Single block: thread t sums partials t, t+256, ... then a 256-wide tree in LDS.
-// host_progress (may be null): an int in host-coherent pinned memory that receives progress_value once the sum
-// is stored -- the solver's watchdog reads it to say how far the GPU got when a rank stops making progress.
-__global__ __launch_bounds__(kBlock) void reduce_partials_kernel(const double* __restrict__ partials,
-                                                                 int count, double* __restrict__ out,
-                                                                 const int* __restrict__ skip_flag,
-                                                                 int* host_progress, int progress_value) {
-    __shared__ double s[kBlock];
-    if (skip_flag != nullptr && *skip_flag != 0) return;
-    double acc = 0.0;
-    for (int i = threadIdx.x; i < count; i += kBlock) acc += partials[i];
-    s[threadIdx.x] = acc;
-    __syncthreads();
-    for (int stride = kBlock / 2; stride > 0; stride >>= 1) {
-        if ((int)threadIdx.x < stride) s[threadIdx.x] += s[threadIdx.x + stride];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        *out = s[0];
-        if (host_progress != nullptr)
-            __hip_atomic_store(host_progress, progress_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-}
-
 // Stage one of a wide reduction: block b sums the contiguous slice [b*slice, (b+1)*slice) of the
 // partials into stage[b] (thread-strided order, then the 256-wide tree). Fixed shape.
 __global__ __launch_bounds__(kBlock) void reduce_slices_kernel(const double* __restrict__ partials,
@@ -206,15 +185,7 @@ __device__ __forceinline__ void cg_scalars_step(CgScalars* s, double tol, double
     }
 }
 
-// Both stages of the wide reduction in ONE launch: block b sums its slice exactly as
-// reduce_slices_kernel does and publishes stage[b]; the block that draws the last ticket then sums
-// the stage values exactly as reduce_partials_kernel does (thread-strided, 256-wide tree), so the
-// result is bit-identical to the two-launch form and independent of which block finishes last.
-// Cross-XCD visibility: stage values and the ticket counter are agent-scope atomics (the L2s of the
-// eight XCDs are not coherent for plain accesses); the acq_rel ticket orders a block's stage store
-// before its ticket and the last block's stage loads after the final ticket.
-// step_scalars != nullptr (single-rank solves: no all-reduce between the sum and the step): the
-// last block also runs the CG scalar step on the freshly written sum.
+// The CG scalar step, optional, in the tail of the last reduction stage (StepArgs.scalars == nullptr: none).
 struct StepArgs {
     CgScalars* scalars;
     double tol;
@@ -225,6 +196,56 @@ struct StepArgs {
     int ring_slots;
 };
 
+// Last stage of every dot product. Single block: thread t sums partials t, t+256, ... then a 256-wide tree in LDS.
+//  * mailbox (may be null): the sum is completed ACROSS THE RANKS here, by the block's first wave, through the peer
+//    mailbox (comm.hpp) -- no separate all-reduce launch, no host involvement;
+//  * step.scalars (may be null): the CG scalar step runs on the finished sum in the same launch;
+//  * host_progress (may be null): an int in host-coherent pinned memory that receives progress_value once the local
+//    sum is known -- the solver's watchdog reads it to say how far the GPU got when a rank stops making progress.
+// A launch enqueued past convergence (skip_flag set; identical on all ranks, since it derives from all-reduced
+// values) sums nothing and exchanges nothing, but still publishes a pending status record.
+__global__ __launch_bounds__(kBlock) void reduce_partials_kernel(const double* __restrict__ partials,
+                                                                 int count, double* __restrict__ out,
+                                                                 const int* __restrict__ skip_flag,
+                                                                 int* host_progress, int progress_value,
+                                                                 const PeerMailbox* mailbox, StepArgs step) {
+    __shared__ double s[kBlock];
+    if (skip_flag != nullptr && *skip_flag != 0) {
+        if (step.scalars != nullptr && threadIdx.x == 0)
+            cg_scalars_step(step.scalars, step.tol, step.history, step.host_record, step.sequence, step.alpha_ring,
+                            step.ring_slots);
+        return;
+    }
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < count; i += kBlock) acc += partials[i];
+    s[threadIdx.x] = acc;
+    __syncthreads();
+    for (int stride = kBlock / 2; stride > 0; stride >>= 1) {
+        if ((int)threadIdx.x < stride) s[threadIdx.x] += s[threadIdx.x + stride];
+        __syncthreads();
+    }
+    if (threadIdx.x >= 64) return;  // the first wave finishes
+    double total = s[0];
+    if (threadIdx.x == 0 && host_progress != nullptr)
+        __hip_atomic_store(host_progress, progress_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (mailbox != nullptr) total = mailbox_allreduce_wave(*mailbox, total);
+    if (threadIdx.x == 0) {
+        *out = total;
+        if (step.scalars != nullptr)
+            cg_scalars_step(step.scalars, step.tol, step.history, step.host_record, step.sequence, step.alpha_ring,
+                            step.ring_slots);
+    }
+}
+
+// Both stages of the wide reduction in ONE launch: block b sums its slice exactly as
+// reduce_slices_kernel does and publishes stage[b]; the block that draws the last ticket then sums
+// the stage values exactly as reduce_partials_kernel does (thread-strided, 256-wide tree), so the
+// result is bit-identical to the two-launch form and independent of which block finishes last.
+// Cross-XCD visibility: stage values and the ticket counter are agent-scope atomics (the L2s of the
+// eight XCDs are not coherent for plain accesses); the acq_rel ticket orders a block's stage store
+// before its ticket and the last block's stage loads after the final ticket.
+// step_scalars != nullptr (single-rank solves: no all-reduce between the sum and the step): the
+// last block also runs the CG scalar step on the freshly written sum.
 __global__ __launch_bounds__(kBlock) void reduce_fused_kernel(const double* __restrict__ partials, int count,
                                                               int slice, double* stage, unsigned* ticket,
                                                               double* __restrict__ out,
@@ -560,43 +581,44 @@ static bool reduce_in_two_launches() {
     return two;
 }
 
-void launch_reduce_partials(const double* partials, int count, double* d_out, const int* d_skip_flag,
-                            hipStream_t stream, double* stage, int* host_progress, int progress_value) {
+namespace {
+const StepArgs kNoStep{nullptr, 0.0, nullptr, nullptr, 0, nullptr, 0};
+
+void reduce_impl(const double* partials, int count, double* d_out, const int* d_skip_flag, hipStream_t stream, double* stage,
+                 int* host_progress, int progress_value, const PeerMailbox* mailbox, const StepArgs& step) {
     // One block walking tens of thousands of partials is latency-bound (0.3 ms for 200k on MI355X);
-    // with a stage buffer the sum is split over kReduceStageBlocks blocks first, in one launch whose
-    // last-finishing block adds the stage values. Both shapes are fixed.
+    // with a stage buffer the sum is split over kReduceStageBlocks blocks first. Both shapes are fixed.
     if (stage != nullptr && count > 4 * kBlock) {
         const int slice = (count + kReduceStageBlocks - 1) / kReduceStageBlocks;
         const int blocks = (count + slice - 1) / slice;
-        if (reduce_in_two_launches()) {
+        if (reduce_in_two_launches() || mailbox != nullptr) {
             hipLaunchKernelGGL(reduce_slices_kernel, dim3(blocks), dim3(kBlock), 0, stream, partials, count, slice,
                                stage, d_skip_flag);
             hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(kBlock), 0, stream, stage, blocks, d_out,
-                               d_skip_flag, host_progress, progress_value);
+                               d_skip_flag, host_progress, progress_value, mailbox, step);
             return;
         }
         hipLaunchKernelGGL(reduce_fused_kernel, dim3(blocks), dim3(kBlock), 0, stream, partials, count, slice, stage,
-                           reinterpret_cast<unsigned*>(stage + kReduceStageBlocks), d_out, d_skip_flag,
-                           StepArgs{nullptr, 0.0, nullptr, nullptr, 0, nullptr, 0});
+                           reinterpret_cast<unsigned*>(stage + kReduceStageBlocks), d_out, d_skip_flag, step);
         return;
     }
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(kBlock), 0, stream, partials, count, d_out,
-                       d_skip_flag, host_progress, progress_value);
+                       d_skip_flag, host_progress, progress_value, mailbox, step);
+}
+}  // namespace
+
+void launch_reduce_partials(const double* partials, int count, double* d_out, const int* d_skip_flag,
+                            hipStream_t stream, double* stage, int* host_progress, int progress_value,
+                            const PeerMailbox* mailbox) {
+    reduce_impl(partials, count, d_out, d_skip_flag, stream, stage, host_progress, progress_value, mailbox, kNoStep);
 }
 
 void launch_reduce_partials_and_step(const double* partials, int count, double* d_out, const int* d_skip_flag,
                                      hipStream_t stream, double* stage, CgScalars* s, double tol, double* history,
-                                     int* host_record, int sequence, double* alpha_ring, int ring_slots) {
-    if (stage != nullptr && count > 4 * kBlock && !reduce_in_two_launches()) {
-        const int slice = (count + kReduceStageBlocks - 1) / kReduceStageBlocks;
-        const int blocks = (count + slice - 1) / slice;
-        hipLaunchKernelGGL(reduce_fused_kernel, dim3(blocks), dim3(kBlock), 0, stream, partials, count, slice, stage,
-                           reinterpret_cast<unsigned*>(stage + kReduceStageBlocks), d_out, d_skip_flag,
-                           StepArgs{s, tol, history, host_record, sequence, alpha_ring, ring_slots});
-        return;
-    }
-    launch_reduce_partials(partials, count, d_out, d_skip_flag, stream, stage);
-    launch_cg_scalars_step(s, tol, history, host_record, sequence, stream, alpha_ring, ring_slots);
+                                     int* host_record, int sequence, double* alpha_ring, int ring_slots,
+                                     const PeerMailbox* mailbox, int* host_progress, int progress_value) {
+    reduce_impl(partials, count, d_out, d_skip_flag, stream, stage, host_progress, progress_value, mailbox,
+                StepArgs{s, tol, history, host_record, sequence, alpha_ring, ring_slots});
 }
 
 // stage values + one slot for the ticket counter, which must be ZERO before the first launch

@@ -72,6 +72,9 @@ struct SpmvAmdCgSlab {
     // pinned, host-coherent. progress = 4 * sequence + k, written by the last block of the local reductions of the
     // iteration that will publish `sequence`: k = 1 local p.Ap summed, k = 2 local r.r summed (watchdog report only)
     struct Poll { int sequence; int converged; int iterations; int progress; }* h_poll = nullptr;
+    // non-null while a solve runs on a communicator with a working peer mailbox: the last stage of every dot
+    // product then completes the sum across the ranks itself (no all-reduce launch)
+    const PeerMailbox* reduce_mailbox = nullptr;
     int* spmv_progress = nullptr;  // where the p.Ap reduction of the SpMV being enqueued reports (in-loop SpMVs only)
     int spmv_progress_value = 0;
     const char* enqueued_stage = "";  // the last piece of work the host put on the streams
@@ -283,7 +286,7 @@ void slab_spmv(SpmvAmdCgSlab* s, bool with_dot, bool overlap, const int* skip,
     if (with_dot) {
         if (part)
             launch_reduce_partials(part, used, &s->d_s->pAp, skip, s->compute, s->reduce_stage, s->spmv_progress,
-                                   s->spmv_progress_value);
+                                   s->spmv_progress_value, s->reduce_mailbox);
         else
             launch_dot((size_t)s->n_local, s->p, s->Ap, s->partials_blas, &s->d_s->pAp, s->compute);
     }
@@ -442,6 +445,10 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
     SpmvAmdComm* comm = s->comm;
     const bool multi = comm->exchanges_halos();  // halo exchange needed
     const bool reduce = comm->collective();   // all-reduce of the dot products needed
+    // with a peer mailbox the all-reduce happens inside the reductions' last stage; `separate` = it needs a call of its own
+    const PeerMailbox* mailbox = (reduce && comm->mailbox_ready()) ? comm->d_mailbox : nullptr;
+    const bool separate = reduce && mailbox == nullptr;
+    s->reduce_mailbox = nullptr;  // the initial SpMV has no dot product
     memset(stats, 0, sizeof(*stats));
 
     // residual history: one slot per iteration, capped at 2^20 entries (later iterations go unrecorded)
@@ -501,10 +508,12 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
         launch_cg_init_residual(nl, s->b, s->Ap, s->r, s->p, s->partials_blas, s->compute);
     });
     timed(&stats->time_dot_rs_initial_ms, nullptr, [&] {
-        launch_reduce_partials(s->partials_blas, cg_partial_count(nl), &s->d_s->rr_new, nullptr, s->compute, s->reduce_stage);
+        launch_reduce_partials(s->partials_blas, cg_partial_count(nl), &s->d_s->rr_new, nullptr, s->compute, s->reduce_stage,
+                               nullptr, 0, mailbox);
     });
     s->enqueued_stage = "initial residual";
-    if (reduce) allreduce_scalar(s, &s->d_s->rr_new, "all-reduce of the initial r.r");
+    if (separate) allreduce_scalar(s, &s->d_s->rr_new, "all-reduce of the initial r.r");
+    s->reduce_mailbox = s->fused_dot ? mailbox : nullptr;  // the in-loop SpMVs' p.Ap reduction
     launch_cg_scalars_init(s->d_s, s->d_hist, s->compute);
     bool halo_in_flight = false;
     auto start_p_halo = [&] {  // halo rows of the new p: side stream, under the interior SpMV
@@ -559,7 +568,7 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
         trace.pop();
         s->spmv_progress = nullptr;
         s->enqueued_stage = "all-reduce of p.Ap";
-        if (reduce) {
+        if (separate || (reduce && !s->fused_dot)) {
             TraceScope r(trace, "AllReduce");
             timed(&stats->time_allreduce_ms, nullptr, [&] { allreduce_scalar(s, &s->d_s->pAp, "all-reduce of p.Ap"); });
         }
@@ -574,7 +583,7 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
         // between the sum and the step, the step runs in the tail of the reduction's launch.
         ++s->poll_sequence;
         trace.push("Dot_Product");
-        if (reduce) {
+        if (separate) {
             timed(&stats->time_reductions_ms, &stats->time_dot_rs_new_ms, [&] {
                 launch_reduce_partials(s->partials_blas, cg_partial_count(nl), &s->d_s->rr_new, skip, s->compute, s->reduce_stage,
                                        &s->h_poll->progress, 4 * s->poll_sequence + 2);
@@ -588,9 +597,11 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
                                    s->compute, s->d_alpha_ring, slots);
         } else {
             timed(&stats->time_reductions_ms, &stats->time_dot_rs_new_ms, [&] {
+                // single rank, or mailbox: sum (completed across the ranks in place) and scalar step in one launch
                 launch_reduce_partials_and_step(s->partials_blas, cg_partial_count(nl), &s->d_s->rr_new, skip, s->compute,
                                                 s->reduce_stage, s->d_s, config->tolerance, s->d_hist,
-                                                &s->h_poll->sequence, s->poll_sequence, s->d_alpha_ring, slots);
+                                                &s->h_poll->sequence, s->poll_sequence, s->d_alpha_ring, slots, mailbox,
+                                                &s->h_poll->progress, 4 * s->poll_sequence + 2);
             });
         }
         trace.pop();
@@ -636,6 +647,7 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
         }
     }
     s->shape.reverse = false;
+    s->reduce_mailbox = nullptr;
     if (slots > 1 && enqueued > window_start)  // x <- x + the directions of the last window
         timed(&stats->time_blas1_ms, nullptr, [&] {
             launch_cg_flush_x(nl, s->d_alpha_ring, ring_view, slots, window_start % slots, enqueued - window_start,

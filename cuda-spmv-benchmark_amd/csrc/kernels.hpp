@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 
+struct PeerMailbox;  // comm.hpp: the dot products' all-reduce as stores between the GPUs
+
 namespace spmv_amd {
 
 // A row slab of a CSR matrix resident in HBM. For a single-GPU operator the slab
@@ -195,14 +197,18 @@ int cg_partial_count(size_t n);  // partial slots written by the two reducing ke
 int reduce_stage_doubles();
 // host_progress (may be null): int in host-coherent pinned memory, set to progress_value once the sum is stored
 // (two-launch and single-block forms only); read by the solver's watchdog report.
+// mailbox (may be null; comm.hpp): the sum is completed across the ranks inside the last stage's launch.
 void launch_reduce_partials(const double* partials, int count, double* d_out,
                             const int* d_skip_flag, hipStream_t stream, double* stage = nullptr,
-                            int* host_progress = nullptr, int progress_value = 0);
+                            int* host_progress = nullptr, int progress_value = 0,
+                            const PeerMailbox* mailbox = nullptr);
 // The same reduction followed by launch_cg_scalars_step(), in one launch when the wide path is taken
 // (only valid when no all-reduce has to happen between the sum and the step).
 void launch_reduce_partials_and_step(const double* partials, int count, double* d_out, const int* d_skip_flag,
                                      hipStream_t stream, double* stage, CgScalars* s, double tol, double* history,
-                                     int* host_record, int sequence, double* alpha_ring = nullptr, int ring_slots = 0);
+                                     int* host_record, int sequence, double* alpha_ring = nullptr, int ring_slots = 0,
+                                     const PeerMailbox* mailbox = nullptr, int* host_progress = nullptr,
+                                     int progress_value = 0);
 // After the (all-reduced) r.r is known: b_norm (first call), residual, history, convergence
 // flag, beta, rr_old <- rr_new, iteration counter.
 void launch_cg_scalars_init(CgScalars* s, double* history, hipStream_t stream);

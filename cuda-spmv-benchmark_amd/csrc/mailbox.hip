@@ -104,7 +104,7 @@ extern "C" int spmv_amd_comm_mailbox_connect(SpmvAmdComm* comm, const void* all_
     mb.inbox = h->inbox;
     mb.rank = comm->rank;
     mb.world = comm->world;
-    double limit_s = 2.0;
+    double limit_s = 20.0;  // far above any skew between ranks inside a solve, below the host watchdog (60 s)
     if (const char* v = getenv("SPMV_AMD_MAILBOX_TIMEOUT_S")) limit_s = atof(v);
     mb.timeout_ticks = (long long)(limit_s * 1e8);  // wall_clock64 runs at 100 MHz
     for (int r = 0; r < comm->world; ++r) {

@@ -299,7 +299,7 @@ def test_slab_solver_nonzero_initial_guess_and_zero_iterations(B, O, fresh_host_
 def test_symmetric_matrix_market_file_through_the_operators_and_cg(B, O, fresh_host_matrices, name):
     """a `coordinate real symmetric` file -> load_matrix_market (expanded to general, the reference reader's
     own expansion order, checked against reference src/io/io.cu:189-310 in test_host_logic.py) -> every operator:
-    SpMV bit-exact against oracle_spmv_csr on the sorted CSR, CG (all three are SPD) at 1e-10 against the oracle."""
+    SpMV bit-exact against oracle_spmv_csr on the sorted CSR, CG (the two SPD files) at 1e-10 against the oracle."""
     m = B.load_matrix_market(os.path.join(GOLDEN, name))
     rows = m.c.rows
     rp, ci, va = O.build_csr(m.entries, rows)
@@ -315,6 +315,8 @@ def test_symmetric_matrix_market_file_through_the_operators_and_cg(B, O, fresh_h
         else:
             assert np.array_equal(got, want), mode
         op.free()
+    if name == "sym_hand3.mtx":
+        return  # the hand case has no (3,3) entry: symmetric but not positive definite, SpMV only
     op = B.Operator("cusparse-csr")
     assert op.init(m) == 0
     xs, hist, st = B.cg_solve(op, m, np.ones(rows), np.zeros(rows), device=True)

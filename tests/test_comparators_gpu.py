@@ -51,9 +51,11 @@ def test_rocsparse_csr_spmv_agrees_with_every_operator(B, O, fresh_host_matrices
 
 
 def test_rocalution_cg_agrees_with_the_slab_solver(B):
-    """rocALUTION's CG (no preconditioner, b = 1, x0 = 0, relative tolerance 1e-6) on the 2048 x 2048 stencil: same
-    iteration count, final residual within 1e-10 relative of the slab solver's."""
-    n = 2048
+    """rocALUTION's CG (no preconditioner, b = 1, x0 = 0, relative tolerance 1e-6) on the 4096 x 4096 stencil: same
+    iteration count, final residual within 1e-10 relative of the slab solver's. (Not 2048: rocALUTION 4.0 / ROCm 7.2
+    returns a NaN residual from its first iteration at 2048 x 2048 and 2049 x 2049 on this GPU -- while 512, 4096,
+    10 000 and 20 000 are fine -- a vendor-side defect this repository does not depend on.)"""
+    n = 4096
     out = subprocess.run([tool("rocalution_cg"), str(n), "2"], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout + out.stderr
     m = re.search(r"RESULT iterations=(\d+) residual=([0-9.eE+-]+)", out.stdout)
