@@ -185,6 +185,9 @@ void make_common(SpmvAmdCgSlab* s) {
         HIP_CHECK(hipMemset(s->d_alpha_ring, 0, kMaxRingSlots * sizeof(double)));
     }
     s->shape = current_launch_shape();
+    // every launch is timed on big slabs; below 100 M rows (multi-GPU slabs: an iteration under 2 ms) every 4th, since
+    // each event pair puts ~7 us of queue barriers next to the SpMV (rocprofv3 timeline, profiles/r02_slab_timeline.txt)
+    s->spmv_event_stride = nl >= 100000000 ? 1 : 4;
     if (const char* v = getenv("SPMV_AMD_SPMV_EVENT_STRIDE")) s->spmv_event_stride = atoi(v);
     if (const char* v = getenv("SPMV_AMD_PINGPONG")) s->pingpong = v[0] == '1';
     if (const char* v = getenv("SPMV_AMD_NO_OVERLAP")) s->no_overlap = v[0] == '1';

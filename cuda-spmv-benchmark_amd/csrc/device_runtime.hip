@@ -21,7 +21,7 @@ Tunables read_tunables() {
     Tunables k;
     k.rowlds_min_grid = env_int("SPMV_AMD_ROWLDS_MIN_GRID", k.rowlds_min_grid);
     k.rowlds_group = env_int("SPMV_AMD_ROWLDS_GROUP", k.rowlds_group);
-    if (k.rowlds_group < 1 || k.rowlds_group > 64) k.rowlds_group = 4;
+    if (k.rowlds_group < 0 || k.rowlds_group > 64) k.rowlds_group = 0;
     k.direct_rows = env_int("SPMV_AMD_DIRECT_ROWS", k.direct_rows);
     if (k.direct_rows != 2 && k.direct_rows != 4) k.direct_rows = 1;
     k.wavetile_oneshot = env_int("SPMV_AMD_WAVETILE_ONESHOT", k.wavetile_oneshot);
@@ -31,6 +31,8 @@ Tunables read_tunables() {
     k.csr_stream_shape = env_int("SPMV_AMD_CSR_STREAM_SHAPE", k.csr_stream_shape);
     k.csr_stream_rows = env_int("SPMV_AMD_CSR_STREAM_ROWS", 0);
     k.ell_shape = env_int("SPMV_AMD_ELL_SHAPE", k.ell_shape);
+    k.xcd_group = env_int("SPMV_AMD_XCD_GROUP", k.xcd_group);
+    if (k.xcd_group < 0 || k.xcd_group > 64) k.xcd_group = 0;
     return k;
 }
 }  // namespace

@@ -33,7 +33,7 @@ struct SlabCsr {
 // calls getenv. Defaults are the measured optima quoted next to the kernels.
 struct Tunables {
     int rowlds_min_grid = 512;    // smallest grid that takes row-lds automatically
-    int rowlds_group = 4;         // consecutive row-lds tiles per XCD
+    int rowlds_group = 0;         // consecutive row-lds tiles per XCD; 0 = derived from the grid (xcd_run_group())
     int direct_rows = 1;          // grid rows per thread in row-direct (1, 2, 4)
     int wavetile_oneshot = 1;     // 0 = persistent XCD-banded walk
     int march_blocks_per_cu = 20;
@@ -42,7 +42,20 @@ struct Tunables {
     int csr_stream_shape = 0;     // 0: 256 x 4, 1: 64 x 6, 2: 64 x 8, 3: 128 x 5
     int csr_stream_rows = 0;      // 0 = derived from the mean row length
     int ell_shape = 2;            // bit 0: one-wave workgroups, bit 1: nontemporal planes / y
+    int xcd_group = 0;            // SPMV_AMD_XCD_GROUP: consecutive logical blocks per XCD in the CSR-stream / ELLPACK kernels;
+                                  // 0 = per-kernel default (ELLPACK: derived from the grid or 8, CSR-stream 1 = dispatch order)
 };
+
+// How many consecutive logical blocks (each `block_columns` grid columns wide) one XCD takes of every run of
+// 8 * group, for kernels that walk an n x n grid row-major. Measured on MI355X (profiles/r02_xcd_group.txt): the
+// best run is one grid row plus ~1100 columns -- STENCIL5 row-lds at 20 000^2: 3.74-3.79 ms with runs of 4 tiles per
+// XCD, 3.65-3.71 ms with 21; 17 000^2: 2.77 -> 2.70 ms; stencil-aware ELLPACK at 20 000^2: 4.01 ms in dispatch
+// order, 3.6-3.7 ms so -- for grids of 8192 columns and more; smaller grids keep short runs (4096^2: 0.150 vs 0.165 ms).
+inline int xcd_run_group(int n, int block_columns, int small_grid_group) {
+    if (n < 8000) return small_grid_group;
+    const int g = (n + 1100 + 8 * block_columns - 1) / (8 * block_columns);
+    return g < 1 ? 1 : (g > 64 ? 64 : g);
+}
 
 struct LaunchShape {
     int compute_units = 256;
@@ -118,8 +131,10 @@ void launch_csr_spmv(const SlabCsr& m, const double* x, double* y, double alpha,
 // ---- ELLPACK SpMV (device layout: slot-major, element (r,k) at [k * rows + r]) ----
 void launch_ell_transpose(int rows, int width, const int* idx_rowmajor, const double* val_rowmajor,
                           int* idx_slotmajor, double* val_slotmajor, hipStream_t stream);
+// grid_hint: n if the matrix is known to be an n x n stencil (block -> XCD relabelling is sized to a grid row), else 0.
 void launch_ell_spmv(int rows, int width, const int* idx, const double* val, const double* x,
-                     double* y, double alpha, double beta, const Tunables& knobs, hipStream_t stream);
+                     double* y, double alpha, double beta, const Tunables& knobs, hipStream_t stream,
+                     int grid_hint = 0);
 // Interior rows take W,C,E,N,S from slots 1,2,3,0,4 with computed columns; others walk slots.
 void launch_ell_stencil5_spmv(int rows, int width, int grid_size, const int* idx,
                               const double* val, const double* x, double* y, double alpha,

@@ -279,7 +279,8 @@ int ell_run(EllOperator& op, const double* d_x, double* d_y, double alpha = 1.0,
         launch_ell_stencil5_spmv(op.rows, op.width, op.grid_size, op.idx, op.val, d_x, d_y, alpha, beta, op.knobs,
                                  kDefaultStream);
     else
-        launch_ell_spmv(op.rows, op.width, op.idx, op.val, d_x, d_y, alpha, beta, op.knobs, kDefaultStream);
+        launch_ell_spmv(op.rows, op.width, op.idx, op.val, d_x, d_y, alpha, beta, op.knobs, kDefaultStream,
+                        op.verified ? op.grid_size : 0);
     return 0;
 }
 

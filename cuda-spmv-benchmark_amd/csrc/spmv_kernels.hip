@@ -31,6 +31,18 @@ constexpr int kLdsDoublesPerWave = 656;  // 640 values + 2 alignment slack, 5248
 
 typedef double d2 __attribute__((ext_vector_type(2)));
 
+// Workgroups are dealt round-robin to the eight XCDs. logical_block() re-labels them so that each XCD works on
+// `group` CONSECUTIVE logical blocks of every run of 8 * group (the row-lds finding, DESIGN.md section 3: with the
+// same kernel body, which XCD touches which addresses is worth ~5 %). The launcher pads the grid to a multiple of
+// 8 * group; blocks relabelled past `total` return. group <= 1: identity.
+__device__ __forceinline__ long long logical_block(int group, long long total) {
+    const long long b = blockIdx.x;
+    if (group <= 1) return b;
+    const long long span = 8LL * group;
+    const long long t = (b / span) * span + (b & 7) * group + ((b >> 3) % group);
+    return t < total ? t : -1;
+}
+
 // x[col - row_offset] if that index is readable, else 0 (halo kernel semantics,
 // reference src/spmv/spmv_stencil_partitioned_halo_kernel.cu:77-94).
 __device__ __forceinline__ double x_at(const double* __restrict__ x, long long local_col,
@@ -666,13 +678,15 @@ __global__ __launch_bounds__(kBlock) void csr_row_scalar_kernel(SlabCsr m, const
 template <int kThreads, int kPerThread>
 __global__ __launch_bounds__(kThreads) void csr_stream_kernel(SlabCsr m, const double* __restrict__ x,
                                                               double* __restrict__ y, double alpha,
-                                                              int rows_per_block) {
+                                                              int rows_per_block, int xcd_group, int total_blocks) {
     constexpr int kCsrStreamCap = kThreads * kPerThread;
     constexpr int kCsrStreamPerThread = kPerThread;
     __shared__ double sv[kCsrStreamCap];
     __shared__ double sx[kCsrStreamCap];
     const int lo = -m.halo_before, hi = m.n_local + m.halo_after;
-    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    const long long blk = logical_block(xcd_group, total_blocks);
+    if (blk < 0) return;
+    const long long r0 = blk * rows_per_block;
     const long long r1 = min(r0 + rows_per_block, (long long)m.n_local);
     const int kb = m.row_ptr[r0], ke = m.row_ptr[r1];
     const long long row = r0 + threadIdx.x;
@@ -805,8 +819,10 @@ __global__ __launch_bounds__(kEllBlock) void ell_spmv_kernel(int rows, int width
                                                              const double* __restrict__ val,
                                                              const double* __restrict__ x,
                                                              double* __restrict__ y, double alpha,
-                                                             double beta) {
-    const long long r = (long long)blockIdx.x * kEllBlock + threadIdx.x;
+                                                             double beta, int xcd_group, int total_blocks) {
+    const long long blk = logical_block(xcd_group, total_blocks);
+    if (blk < 0) return;
+    const long long r = blk * kEllBlock + threadIdx.x;
     if (r >= rows) return;
     const double sum = ell_row_walk<kNt>(rows, width, idx, val, x, r);
     const double out = ell_finish(alpha, beta, sum, beta == 0.0 ? 0.0 : y[r]);
@@ -822,8 +838,10 @@ __global__ __launch_bounds__(kEllBlock) void ell_stencil5_kernel(int rows, int w
                                                                  const double* __restrict__ val,
                                                                  const double* __restrict__ x,
                                                                  double* __restrict__ y, double alpha,
-                                                                 double beta) {
-    const long long r = (long long)blockIdx.x * kEllBlock + threadIdx.x;
+                                                                 double beta, int xcd_group, int total_blocks) {
+    const long long blk = logical_block(xcd_group, total_blocks);
+    if (blk < 0) return;
+    const long long r = blk * kEllBlock + threadIdx.x;
     if (r >= rows) return;
     const int i = (int)(r / n), j = (int)(r - (long long)i * n);
     double sum;
@@ -974,7 +992,8 @@ Stencil5Plan plan_stencil5(const SlabCsr& m, int first_row, int last_row, Stenci
         p.gi_lo = first_row / n;
         p.gi_hi = last_row / n;
         p.row_blocks = (n + kLdsTileCols - 1) / kLdsTileCols;  // column tiles (= workgroups) per grid row
-        p.rows_per_task = knobs.rowlds_group;  // consecutive tiles per XCD
+        // consecutive tiles per XCD: one grid row + ~1100 columns per run of 8 * group tiles (xcd_run_group)
+        p.rows_per_task = knobs.rowlds_group > 0 ? knobs.rowlds_group : xcd_run_group(n, kLdsTileCols, 4);
         if (p.rows_per_task < 1 || p.rows_per_task > 64) p.rows_per_task = 4;
     } else if (variant == Stencil5Variant::WaveTile) {
         // one tile per wave in dispatch order by default (4.65 ms at 20 000^2); SPMV_AMD_WAVETILE_ONESHOT=0
@@ -1205,9 +1224,14 @@ void launch_csr_spmv(const SlabCsr& m, const double* x, double* y, double alpha,
             per_block = per_block > threads ? threads : (per_block < 16 ? 16 : per_block & ~15);
             if (knobs.csr_stream_rows > 0) per_block = knobs.csr_stream_rows;
             if (per_block > threads) per_block = threads;
-            const dim3 grid((unsigned)((rows + per_block - 1) / per_block));
+            const long long blocks = (rows + per_block - 1) / per_block;
+            // dispatch order: relabelling blocks so that an XCD takes runs of consecutive blocks measured SLOWER here
+            // (10 000^2: 1.35 ms plain, 1.40-1.45 ms for runs of 2-16; profiles/r02_xcd_group_ab.txt)
+            const int group = knobs.xcd_group > 0 ? knobs.xcd_group : 1;
+            const long long span = group > 1 ? 8LL * group : 1;
+            const dim3 grid((unsigned)((blocks + span - 1) / span * span));
 #define SPMV_AMD_CSR_STREAM(T, P) \
-    hipLaunchKernelGGL((csr_stream_kernel<T, P>), grid, dim3(T), 0, stream, m, x, y, alpha, per_block)
+    hipLaunchKernelGGL((csr_stream_kernel<T, P>), grid, dim3(T), 0, stream, m, x, y, alpha, per_block, group, (int)blocks)
             if (shape == 1) SPMV_AMD_CSR_STREAM(64, 6);
             else if (shape == 2) SPMV_AMD_CSR_STREAM(64, 8);
             else if (shape == 3) SPMV_AMD_CSR_STREAM(128, 5);
@@ -1239,14 +1263,18 @@ void launch_ell_transpose(int rows, int width, const int* idx_rowmajor, const do
 }
 
 void launch_ell_spmv(int rows, int width, const int* idx, const double* val, const double* x,
-                     double* y, double alpha, double beta, const Tunables& knobs, hipStream_t stream) {
+                     double* y, double alpha, double beta, const Tunables& knobs, hipStream_t stream, int grid_hint) {
     if (rows == 0) return;
     // bit 0: one-wave workgroups, bit 1: nontemporal planes / y. Measured on MI355X at 15 000^2 (generic /
     // stencil-aware): 0: 3.22 / 2.32 ms, 1: 3.00 / 2.51, 2: 2.96 / 2.26, 3: 3.00 / 2.47 -> 2.
     const int shape = knobs.ell_shape;
-#define SPMV_AMD_ELL(B, NT)                                                                                   \
-    hipLaunchKernelGGL((ell_spmv_kernel<B, NT>), dim3((unsigned)(((long long)rows + B - 1) / B)), dim3(B), 0, \
-                       stream, rows, width, idx, val, x, y, alpha, beta)
+    // each XCD takes `group` consecutive 256-row blocks of every run of 8 * group (15 000^2: 2.95-3.03 ms in dispatch
+    // order, 2.86 ms with runs of 9; 10 000^2: 1.35 -> 1.30 ms; profiles/r02_xcd_group.txt)
+    const int group = knobs.xcd_group > 0 ? knobs.xcd_group : (grid_hint > 0 ? xcd_run_group(grid_hint, 256, 7) + 1 : 8);
+    const long long span = group > 1 ? 8LL * group : 1;
+#define SPMV_AMD_ELL(B, NT)                                                                                              \
+    hipLaunchKernelGGL((ell_spmv_kernel<B, NT>), dim3((unsigned)(((((long long)rows + B - 1) / B) + span - 1) / span * span)), \
+                       dim3(B), 0, stream, rows, width, idx, val, x, y, alpha, beta, group, (int)(((long long)rows + B - 1) / B))
     if ((shape & 3) == 3) SPMV_AMD_ELL(64, true);
     else if (shape & 1) SPMV_AMD_ELL(64, false);
     else if (shape & 2) SPMV_AMD_ELL(256, true);
@@ -1259,13 +1287,17 @@ void launch_ell_stencil5_spmv(int rows, int width, int grid_size, const int* idx
                               double beta, const Tunables& knobs, hipStream_t stream) {
     if (rows == 0) return;
     if (grid_size < 3 || (long long)grid_size * grid_size != rows) {
-        launch_ell_spmv(rows, width, idx, val, x, y, alpha, beta, knobs, stream);
+        launch_ell_spmv(rows, width, idx, val, x, y, alpha, beta, knobs, stream, 0);
         return;
     }
     const int shape = knobs.ell_shape;
-#define SPMV_AMD_ELL5(B, NT)                                                                                      \
-    hipLaunchKernelGGL((ell_stencil5_kernel<B, NT>), dim3((unsigned)(((long long)rows + B - 1) / B)), dim3(B), 0, \
-                       stream, rows, width, grid_size, idx, val, x, y, alpha, beta)
+    // 15 000^2: 2.27-2.29 ms in dispatch order, 2.01 ms with runs of 8 blocks per XCD; 20 000^2: 4.01 -> 3.6-3.7 ms
+    const int group = knobs.xcd_group > 0 ? knobs.xcd_group : xcd_run_group(grid_size, 256, 8);
+    const long long span = group > 1 ? 8LL * group : 1;
+#define SPMV_AMD_ELL5(B, NT)                                                                                                 \
+    hipLaunchKernelGGL((ell_stencil5_kernel<B, NT>), dim3((unsigned)(((((long long)rows + B - 1) / B) + span - 1) / span * span)), \
+                       dim3(B), 0, stream, rows, width, grid_size, idx, val, x, y, alpha, beta, group,                        \
+                       (int)(((long long)rows + B - 1) / B))
     if ((shape & 3) == 3) SPMV_AMD_ELL5(64, true);
     else if (shape & 1) SPMV_AMD_ELL5(64, false);
     else if (shape & 2) SPMV_AMD_ELL5(256, true);
