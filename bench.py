@@ -117,7 +117,7 @@ def spmv_headline(B, n, warmup=5, runs=10):
 
 
 def stream_ceiling(B, rows=200_000_000, reps=20):
-    """The 48:8 read:write stream probe on the benchmark's data (csrc/stream_ceiling.hip), ~50 ms of GPU time."""
+    """The 48:8 read:write stream probe on the benchmark's data (csrc/stream_ceiling.hip), ~100 ms of GPU time at 4e8 rows."""
     ms, nbytes = B.stream_ceiling(rows, warmup=3, reps=reps)
     med, _ = reference_stats(ms)
     return {"gbs": nbytes / (med / 1e3) / 1e9, "median_ms": med, "rows": rows, "bytes_per_launch": nbytes, "launches": reps,
@@ -514,7 +514,7 @@ def main():
     }
     if rank == 0 and not args.no_ceiling and local_rows >= 1_000_000:
         try:
-            ceil = stream_ceiling(B, rows=min(200_000_000, local_rows))
+            ceil = stream_ceiling(B, rows=local_rows)  # same row count as the slab: the rate depends on it (6.2-6.4 TB/s for 2e8 / 4e8 rows)
             roofline["ceiling_measured"] = ceil["gbs"]
             roofline["frac_of_ceiling"] = achieved / ceil["gbs"]
             roofline["ceiling_probe"] = ceil
