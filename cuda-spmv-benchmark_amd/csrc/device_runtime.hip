@@ -22,6 +22,7 @@ Tunables read_tunables() {
     k.rowlds_min_grid = env_int("SPMV_AMD_ROWLDS_MIN_GRID", k.rowlds_min_grid);
     k.rowlds_group = env_int("SPMV_AMD_ROWLDS_GROUP", k.rowlds_group);
     if (k.rowlds_group < 0 || k.rowlds_group > 64) k.rowlds_group = 0;
+    k.rowlds_we_lds = env_int("SPMV_AMD_ROWLDS_WE_LDS", k.rowlds_we_lds);
     k.direct_rows = env_int("SPMV_AMD_DIRECT_ROWS", k.direct_rows);
     if (k.direct_rows != 2 && k.direct_rows != 4) k.direct_rows = 1;
     k.wavetile_oneshot = env_int("SPMV_AMD_WAVETILE_ONESHOT", k.wavetile_oneshot);

@@ -34,6 +34,8 @@ struct SlabCsr {
 struct Tunables {
     int rowlds_min_grid = 512;    // smallest grid that takes row-lds automatically
     int rowlds_group = 0;         // consecutive row-lds tiles per XCD; 0 = derived from the grid (xcd_run_group())
+    int rowlds_we_lds = 1;        // row-lds: W / E neighbours from an LDS copy of the tile's x values (0 = two more global
+                                  // loads per row): 20 000^2 3.67-3.71 -> 3.65-3.68 ms, 10 000^2 0.950 -> 0.925 ms, same bits
     int direct_rows = 1;          // grid rows per thread in row-direct (1, 2, 4)
     int wavetile_oneshot = 1;     // 0 = persistent XCD-banded walk
     int march_blocks_per_cu = 20;
@@ -93,6 +95,7 @@ struct Stencil5Plan {
     int row_blocks = 0;  // blocks of one boundary-grid-row launch
     int tile_blocks = 0;
     bool oneshot = true;
+    bool we_from_lds = false;  // row-lds: W / E neighbours from an LDS copy of the tile's x values
     int partials = 0;        // dot-partial slots one launch writes
     const char* name = "";   // "stencil5/row-lds", ...
 };
