@@ -340,17 +340,24 @@ __global__ __launch_bounds__(kStream) void cg_update_r_kernel(size_t n, const Cg
                                                              const double* __restrict__ Ap,
                                                              double* __restrict__ r,
                                                              double* __restrict__ partials, int reverse) {
-    if (s->converged) return;
-    // alpha = rr_old / pAp from the (all-reduced) dot product: one IEEE division of two wave-uniform
-    // scalars per thread, the same value the scalar step stores for the x update further down
-    const double alpha = s->rr_old / s->pAp;
-    double acc = 0.0;
+    // The vector loads are issued BEFORE the scalars are looked at: a wave does not wait for the scalar loads, the
+    // convergence test and an fp64 division ahead of its first memory request (a launch enqueued past convergence
+    // only reads). alpha = rr_old / pAp from the (all-reduced) dot product: one IEEE division of two wave-uniform
+    // scalars per thread, the same value the scalar step stores for the x update further down.
     const unsigned block = reverse ? gridDim.x - 1 - blockIdx.x : blockIdx.x;  // logical workgroup
     const size_t pairs = n >> 1;
     const size_t i = (size_t)block * kStream + threadIdx.x;
+    d2 av = {0.0, 0.0}, rv = {0.0, 0.0};
     if (i < pairs) {
-        const d2 av = load_once(Ap, i);
-        d2 rv = load_once(r, i);
+        av = load_once(Ap, i);
+        rv = load_once(r, i);
+    }
+    const int converged = s->converged;
+    const double rr_old = s->rr_old, pAp = s->pAp;
+    if (converged) return;
+    const double alpha = rr_old / pAp;
+    double acc = 0.0;
+    if (i < pairs) {
         rv.x = fma(-alpha, av.x, rv.x);
         rv.y = fma(-alpha, av.y, rv.y);
         store_once(r, i, rv);
@@ -358,9 +365,9 @@ __global__ __launch_bounds__(kStream) void cg_update_r_kernel(size_t n, const Cg
         acc = fma(rv.y, rv.y, acc);
     }
     if ((n & 1) && block == 0 && threadIdx.x == 0) {
-        const double rv = fma(-alpha, Ap[n - 1], r[n - 1]);
-        r[n - 1] = rv;
-        acc = fma(rv, rv, acc);
+        const double rl = fma(-alpha, Ap[n - 1], r[n - 1]);
+        r[n - 1] = rl;
+        acc = fma(rl, rl, acc);
     }
     acc = wave_sum(acc);
     if (threadIdx.x == 0) partials[block] = acc;
@@ -429,14 +436,19 @@ __global__ __launch_bounds__(kStream) void cg_update_p_ring_kernel(size_t n, con
                                                                    const double* __restrict__ p_in,
                                                                    double* __restrict__ p_out, int iteration,
                                                                    int reverse) {
-    if (s->iterations != iteration || s->converged != 0) return;
-    const double beta = s->beta;
+    // loads first, scalars second (see cg_update_r_kernel)
     const unsigned block = reverse ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
     const size_t pairs = n >> 1;
     const size_t i = (size_t)block * kStream + threadIdx.x;
+    d2 rv = {0.0, 0.0}, pv = {0.0, 0.0};
     if (i < pairs) {
-        const d2 rv = load_once(r, i);
-        d2 pv = load_once(p_in, i);
+        rv = load_once(r, i);
+        pv = load_once(p_in, i);
+    }
+    const int iterations = s->iterations, converged = s->converged;
+    const double beta = s->beta;
+    if (iterations != iteration || converged != 0) return;
+    if (i < pairs) {
         pv.x = fma(1.0, rv.x, beta * pv.x);
         pv.y = fma(1.0, rv.y, beta * pv.y);
         reinterpret_cast<d2*>(p_out)[i] = pv;  // plain: the next SpMV's neighbour loads re-use these lines

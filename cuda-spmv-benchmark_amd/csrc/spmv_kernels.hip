@@ -504,7 +504,9 @@ __global__ __launch_bounds__(64) void stencil5_rowlds_kernel(
     const int* __restrict__ skip_flag) {
     __shared__ double strip[5 * kLdsTileCols];
     __shared__ double xrow[kWeLds ? kLdsTileCols + 2 : 1];  // kWeLds: the tile's x values, W / E read back from here
-    if (skip_flag != nullptr && *skip_flag != 0) return;
+    // The convergence flag is REQUESTED here and tested after the tile's loads have been issued: a wave does not sit
+    // on a scalar-load round trip before its first vector load (a launch enqueued past convergence only reads).
+    const int skip = skip_flag != nullptr ? __builtin_nontemporal_load(skip_flag) : 0;
     const int lane = (int)threadIdx.x;
     const int b = (int)blockIdx.x;
     const int span = 8 * group;
@@ -558,6 +560,7 @@ __global__ __launch_bounds__(64) void stencil5_rowlds_kernel(
                 }
             }
         }
+        if (skip != 0) return;
 #pragma unroll
         for (int k = 0; k < 10; ++k) strip[64 * k + lane] = c[k];
         if (kWeLds) {
@@ -604,6 +607,7 @@ __global__ __launch_bounds__(64) void stencil5_rowlds_kernel(
         }
     } else {
         // first / last grid row of the whole grid: every row the reference's way
+        if (skip != 0) return;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int j = j0 + lane + 64 * h;
