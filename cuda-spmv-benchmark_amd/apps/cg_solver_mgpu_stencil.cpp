@@ -69,6 +69,12 @@ int main(int argc, char** argv) {
             fprintf(stderr, "[Rank %d] communicator self-test failed\n", rank);
             return 1;
         }
+        // dot-product all-reduces: peer mailbox when every rank's self-test passes, ncclAllReduce otherwise
+        const char* ar = getenv("SPMV_AMD_ALLREDUCE");
+        const int mailbox = (ar && !strcmp(ar, "rccl")) ? 0 : spmv_amd_comm_mailbox_enable(comm);
+        if (rank == 0)
+            printf("Transport: %s over %d ranks; dot-product all-reduce: %s\n", spmv_amd_comm_transport(comm),
+                   spmv_amd_comm_transport_ranks(comm), mailbox ? "peer mailbox (stores between the GPUs)" : "ncclAllReduce");
         spmv_amd_comm_set_world(comm);
     }
 

@@ -4,6 +4,7 @@ and derives profiles/hbm_traffic.json for the dominant kernel of bench.py.
    python tools/publish_profiles.py r01"""
 import csv
 import glob
+import hashlib
 import json
 import os
 import shutil
@@ -37,7 +38,8 @@ for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
     if f:
         shutil.copy(f, os.path.join(dst, f"{tag}_bench_{os.path.basename(d)}.csv"))
 shutil.copy(os.path.join(src, "summary.json"), os.path.join(dst, f"{tag}_bench_summary.json"))
-shutil.copy(os.path.join(src, "stream_probe.txt"), os.path.join(dst, f"{tag}_stream_probe.txt"))
+if os.path.exists(os.path.join(src, "stream_probe.txt")):
+    shutil.copy(os.path.join(src, "stream_probe.txt"), os.path.join(dst, f"{tag}_stream_probe.txt"))
 for line in open(os.path.join(src, "bench_default.json")):
     if line.startswith("{"):
         open(os.path.join(dst, f"{tag}_bench_default.json"), "w").write(line)
@@ -48,17 +50,22 @@ for line in open(os.path.join(src, "bench_stats_run.log")):
 summary = json.load(open(os.path.join(src, "summary.json")))
 bench = json.load(open(os.path.join(dst, f"{tag}_bench_default.json")))
 kernel = bench["roofline"]["kernel"].split(" (")[0]
-pmc = next(v for k, v in summary["pmc_avg_per_launch"].items() if kernel.split("<")[0] in k and "<true>" in k)
+# the in-loop instantiation (kDot = true): its PMC rows are the SpMV launches of the CG loop
+pmc = next(v for k, v in summary["pmc_avg_per_launch"].items() if kernel.split("<")[0] in k and kernel.split("<")[1].rstrip(">") in k)
+source = os.path.join(ROOT, "cuda-spmv-benchmark_amd", "csrc", "spmv_kernels.hip")
 fetch = pmc["FETCH_SIZE"] * 1024 * 2
 write = pmc["WRITE_SIZE"] * 1024
 alg = bench["roofline"]["algorithmic_bytes_per_launch"]
 rec = {
-    "grid": bench["config"]["grid"], "n_gpus": 1, "kernel": kernel, "bytes_per_launch": fetch + write,
+    "grid": bench["config"]["grid"], "n_gpus": 1, "kernel": kernel,
+    # bench.py reports `traffic` only while this hash equals the hash of the kernel source it runs
+    "kernel_source_sha256": hashlib.sha256(open(source, "rb").read()).hexdigest(), "kernel_source": "cuda-spmv-benchmark_amd/csrc/spmv_kernels.hip",
+    "bytes_per_launch": fetch + write,
     "fetch_bytes_corrected": fetch, "write_bytes": write, "FETCH_SIZE_KiB": pmc["FETCH_SIZE"], "WRITE_SIZE_KiB": pmc["WRITE_SIZE"],
     "TCC_HIT_sum": pmc.get("TCC_HIT_sum"), "TCC_MISS_sum": pmc.get("TCC_MISS_sum"), "algorithmic_bytes_per_launch": alg,
     "ratio_to_algorithmic": (fetch + write) / alg,
     "source": f"profiles/{tag}_bench_pmc_FETCH_SIZE.csv, {tag}_bench_pmc_WRITE_SIZE.csv (separate rocprofv3 --pmc passes over "
-              "`python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline`, averages over the in-loop launches)",
+              "`python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-scaling-probe --no-spmv --no-ceiling`, averages over the in-loop launches)",
     "note": "FETCH_SIZE x 1024 x 2 (gfx950 tallies 128-B fabric requests at 64 B; the factor is confirmed in the same passes by "
             "cg_update_r_kernel, whose FETCH_SIZE x 2 equals its 16 B/row of reads) + WRITE_SIZE x 1024. These are L2-to-fabric "
             "bytes: Infinity-Cache hits are counted. The excess over the algorithmic bytes is x[row-n] / x[row+n] missing the "
