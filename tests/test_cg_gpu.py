@@ -235,6 +235,35 @@ def test_reference_harness_binary_runs_on_this_library(O):
     assert "valid runs" in text  # the reference main went through cg_benchmark_with_stats_device
 
 
+def test_reference_spmv_bench_main_runs_on_this_library(golden, tmp_path):
+    """oracle/_ref/ref_spmv_bench is the reference's src/main/main.cu minus its one unused `#include <cuda_runtime.h>`
+    (dropped in a sed pipe by oracle/Makefile; nothing else is touched), compiled against this repo's include/ and
+    linked against libspmv_amd.so. Run on the reference's shipped 81 x 81 matrix with both of its modes: the checksums
+    it prints are the reference's known answers (Sum(y) = -52164), its JSON export carries the keys the
+    reference's scripts scrape."""
+    import json
+    import re
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_spmv_bench")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/ref_spmv_bench not built (reference sources absent at build time)")
+    base = tmp_path / "res.json"
+    out = subprocess.run([exe, os.path.join(GOLDEN, "example81x81.mtx"), "--mode=cusparse-csr,stencil5-csr", f"--json={base}"],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    want = golden["survey_8c"]["81:-4.0"]
+    sums = [float(v) for v in re.findall(r"Sum\(y\)\s*[:=]\s*(\S+)", out.stdout)]
+    norms = [float(v) for v in re.findall(r"Norm2\(y\)\s*[:=]\s*(\S+)", out.stdout)]
+    assert len(sums) == 2 and all(v == want["sum_y"] for v in sums), out.stdout[-3000:]
+    assert len(norms) == 2 and all(abs(v - want["norm2_y"]) <= 1e-12 * want["norm2_y"] for v in norms)
+    assert out.stdout.count("valid runs") == 2  # benchmark_with_stats ran for both modes
+    for mode in ("cusparse-csr", "stencil5-csr"):
+        rec = json.load(open(tmp_path / f"res_{mode}.json"))
+        text = json.dumps(rec)
+        assert "execution_time_ms" in text and "median_ms" in text
+
+
 def test_slab_solver_on_a_general_spd_matrix(B, O, fresh_host_matrices):
     """No stencil announced (grid_size = -1): the slab solver runs the CSR loop for every row and the
     plain dot kernel; results still match the oracle's CG on the same matrix."""
