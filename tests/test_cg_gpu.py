@@ -261,7 +261,8 @@ def test_reference_spmv_bench_main_runs_on_this_library(golden, tmp_path):
     for mode in ("cusparse-csr", "stencil5-csr"):
         rec = json.load(open(tmp_path / f"res_{mode}.json"))
         text = json.dumps(rec)
-        assert "execution_time_ms" in text and "median_ms" in text
+        assert "execution_time_ms" in text and "gflops" in text and "bandwidth_gb_s" in text  # keys scripts/run_all.sh scrapes
+        assert rec["benchmark"]["validation"]["sum_y"] == want["sum_y"] if "benchmark" in rec else '"sum_y": -52164.0' in text
 
 
 def test_slab_solver_on_a_general_spd_matrix(B, O, fresh_host_matrices):
