@@ -243,7 +243,7 @@ bool partition_ok(const SpmvAmdComm* comm, int n, int grid, int n_local) {
 
 // The slab's first and last grid row (the rows that read the halos) on `stream`; partial slots follow the
 // interior launch's. Returns the number of partials written (0 without partials).
-int slab_boundary_spmv(SpmvAmdCgSlab* s, double* part, const int* skip, hipStream_t stream) {
+int slab_boundary_spmv(SpmvAmdCgSlab* s, const double* in, double* part, const int* skip, hipStream_t stream) {
     const SlabCsr& A = s->A.view;
     const int lo = s->has_prev ? s->halo : 0;
     const int hi = s->n_local - (s->has_next ? s->halo : 0);
@@ -253,11 +253,11 @@ int slab_boundary_spmv(SpmvAmdCgSlab* s, double* part, const int* skip, hipStrea
     int used = 0;
     if (lo > 0 && hi < s->n_local && lo == A.grid_size && s->n_local - hi == A.grid_size) {
         // a rank with two neighbours: its first and last grid row in one launch
-        used += launch_stencil5_spmv_first_and_last_gridrow(A, s->plan_head, s->p, s->Ap, 1.0, at, skip, forward, stream);
+        used += launch_stencil5_spmv_first_and_last_gridrow(A, s->plan_head, in, s->Ap, 1.0, at, skip, forward, stream);
     } else {
-        if (lo > 0) used += launch_stencil5_spmv(A, s->plan_head, s->p, s->Ap, 1.0, at, skip, false, stream);
+        if (lo > 0) used += launch_stencil5_spmv(A, s->plan_head, in, s->Ap, 1.0, at, skip, false, stream);
         if (hi < s->n_local)
-            used += launch_stencil5_spmv(A, s->plan_tail, s->p, s->Ap, 1.0, at ? at + used : nullptr, skip, false, stream);
+            used += launch_stencil5_spmv(A, s->plan_tail, in, s->Ap, 1.0, at ? at + used : nullptr, skip, false, stream);
     }
     return part ? used : 0;
 }
@@ -281,9 +281,9 @@ void slab_spmv(SpmvAmdCgSlab* s, bool with_dot, bool overlap, const int* skip,
         // row of the slab once the halo rows have landed. (Launching those two rows behind the exchange on the
         // side stream instead, so that this stream only waits for an event, measured slower: 15.77 vs 15.59 ms
         // per solve at 50 M rows with the rank as its own neighbour.)
-        used = launch_stencil5_spmv(A, s->plan_interior, s->p, s->Ap, 1.0, part, skip, s->shape.reverse, s->compute);
+        used = launch_stencil5_spmv(A, s->plan_interior, in, s->Ap, 1.0, part, skip, s->shape.reverse, s->compute);
         HIP_CHECK(hipStreamWaitEvent(s->compute, s->ev_halo_done, 0));
-        used += slab_boundary_spmv(s, part, skip, s->compute);
+        used += slab_boundary_spmv(s, in, part, skip, s->compute);
     }
     if (spmv_done) HIP_CHECK(hipEventRecord(spmv_done, s->compute));
     if (with_dot) {
@@ -505,8 +505,21 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
 
     // ---- r0 = b - A x0 ; p0 = r0 ; rr0 ----
     // x0 is read where it lies: its allocation carries the halo rows the first / last grid row need
-    if (multi) timed(&stats->time_allgather_ms, nullptr, [&] { exchange_halo(s, s->x0, s->compute); });
-    slab_spmv(s, /*with_dot=*/false, /*overlap=*/false, nullptr, s->x0);
+    // (its halo rows travel like p's: on the side stream, under the interior rows, so that the point-to-point
+    // communicator is driven from one stream only; with detailed timers everything runs on the compute stream)
+    bool x0_halo_on_side = false;
+    if (multi) {
+        if (detail || s->no_overlap) {
+            timed(&stats->time_allgather_ms, nullptr, [&] { exchange_halo(s, s->x0, s->compute); });
+        } else {
+            HIP_CHECK(hipEventRecord(s->ev_p_ready, s->compute));
+            HIP_CHECK(hipStreamWaitEvent(s->side, s->ev_p_ready, 0));
+            exchange_halo(s, s->x0, s->side);
+            HIP_CHECK(hipEventRecord(s->ev_halo_done, s->side));
+            x0_halo_on_side = true;
+        }
+    }
+    slab_spmv(s, /*with_dot=*/false, /*overlap=*/x0_halo_on_side, nullptr, s->x0);
     timed(&stats->time_initial_r_ms, nullptr, [&] {
         launch_cg_init_residual(nl, s->b, s->Ap, s->r, s->p, s->partials_blas, s->compute);
     });
