@@ -87,6 +87,7 @@ struct SpmvAmdCgSlab {
     int partials_cap = 0;
     const char* variant_name = "";
     bool fused_dot = false;
+    bool fuse_init_residual = false;  // r0 = b - A x0, p0, r0.r0 written by the first SpMV's launches (row-lds slabs)
     std::vector<double> history;
     // event pairs around every spmv_event_stride-th in-loop SpMV (recorded without any host sync,
     // resolved after the loop): time_spmv_ms with timers off is the live average of those launches
@@ -221,6 +222,11 @@ void make_common(SpmvAmdCgSlab* s) {
         s->variant_name = s->plan_whole.name;
         // unverified / unaligned slabs run the row-generic kernel and use the plain dot kernel
         s->fused_dot = strstr(s->variant_name, "row-generic") == nullptr;
+        // the initial residual rides in the first SpMV where every launch of the slab is a row-lds launch
+        const auto rowlds = [](const Stencil5Plan& p) { return p.last_row <= p.first_row || p.variant == Stencil5Variant::RowLds; };
+        s->fuse_init_residual = s->plan_whole.variant == Stencil5Variant::RowLds && rowlds(s->plan_interior) &&
+                                rowlds(s->plan_head) && rowlds(s->plan_tail);
+        if (const char* v = getenv("SPMV_AMD_FUSE_INIT")) s->fuse_init_residual = s->fuse_init_residual && v[0] != '0';
     }
     launch_fill(s->b, nl, 1.0, s->compute);   // default right-hand side b = 1
     launch_fill(s->x0, nl, 0.0, s->compute);  // default initial guess x0 = 0
@@ -243,7 +249,8 @@ bool partition_ok(const SpmvAmdComm* comm, int n, int grid, int n_local) {
 
 // The slab's first and last grid row (the rows that read the halos) on `stream`; partial slots follow the
 // interior launch's. Returns the number of partials written (0 without partials).
-int slab_boundary_spmv(SpmvAmdCgSlab* s, const double* in, double* part, const int* skip, hipStream_t stream) {
+int slab_boundary_spmv(SpmvAmdCgSlab* s, const double* in, double* part, const int* skip, hipStream_t stream,
+                       const ResidualOut* init = nullptr) {
     const SlabCsr& A = s->A.view;
     const int lo = s->has_prev ? s->halo : 0;
     const int hi = s->n_local - (s->has_next ? s->halo : 0);
@@ -253,11 +260,11 @@ int slab_boundary_spmv(SpmvAmdCgSlab* s, const double* in, double* part, const i
     int used = 0;
     if (lo > 0 && hi < s->n_local && lo == A.grid_size && s->n_local - hi == A.grid_size) {
         // a rank with two neighbours: its first and last grid row in one launch
-        used += launch_stencil5_spmv_first_and_last_gridrow(A, s->plan_head, in, s->Ap, 1.0, at, skip, forward, stream);
+        used += launch_stencil5_spmv_first_and_last_gridrow(A, s->plan_head, in, s->Ap, 1.0, at, skip, forward, stream, init);
     } else {
-        if (lo > 0) used += launch_stencil5_spmv(A, s->plan_head, in, s->Ap, 1.0, at, skip, false, stream);
+        if (lo > 0) used += launch_stencil5_spmv(A, s->plan_head, in, s->Ap, 1.0, at, skip, false, stream, init);
         if (hi < s->n_local)
-            used += launch_stencil5_spmv(A, s->plan_tail, in, s->Ap, 1.0, at ? at + used : nullptr, skip, false, stream);
+            used += launch_stencil5_spmv(A, s->plan_tail, in, s->Ap, 1.0, at ? at + used : nullptr, skip, false, stream, init);
     }
     return part ? used : 0;
 }
@@ -265,25 +272,27 @@ int slab_boundary_spmv(SpmvAmdCgSlab* s, const double* in, double* part, const i
 // SpMV of the slab on p (halos must be current or in flight on the side stream).
 // overlap = the halo exchange was started on the side stream and ev_halo_done marks its end.
 // spmv_done (optional): recorded behind the last SpMV launch, before the reduction of its partials.
-void slab_spmv(SpmvAmdCgSlab* s, bool with_dot, bool overlap, const int* skip,
-               const double* input = nullptr, hipEvent_t spmv_done = nullptr) {
+// init (may be null): the launches write r = b - A x, p = r and r.r partials instead of A x (fused initial residual);
+// the caller reduces the partials. Returns the number of partial slots the launches wrote.
+int slab_spmv(SpmvAmdCgSlab* s, bool with_dot, bool overlap, const int* skip,
+              const double* input = nullptr, hipEvent_t spmv_done = nullptr, const ResidualOut* init = nullptr) {
     const SlabCsr& A = s->A.view;
     const double* in = input ? input : s->p;
-    double* part = (with_dot && s->fused_dot) ? s->partials_spmv : nullptr;
+    double* part = ((with_dot && s->fused_dot) || init) ? s->partials_spmv : nullptr;
     const int lo = s->has_prev ? s->halo : 0;
     const int hi = s->n_local - (s->has_next ? s->halo : 0);
     int used = 0;
     if (!overlap || hi <= lo || (lo == 0 && hi == s->n_local)) {
         if (overlap) HIP_CHECK(hipStreamWaitEvent(s->compute, s->ev_halo_done, 0));
-        used = launch_stencil5_spmv(A, s->plan_whole, in, s->Ap, 1.0, part, skip, s->shape.reverse, s->compute);
+        used = launch_stencil5_spmv(A, s->plan_whole, in, s->Ap, 1.0, part, skip, s->shape.reverse, s->compute, init);
     } else {
         // rows whose north and south neighbours are local run under the halo exchange; the first / last grid
         // row of the slab once the halo rows have landed. (Launching those two rows behind the exchange on the
         // side stream instead, so that this stream only waits for an event, measured slower: 15.77 vs 15.59 ms
         // per solve at 50 M rows with the rank as its own neighbour.)
-        used = launch_stencil5_spmv(A, s->plan_interior, in, s->Ap, 1.0, part, skip, s->shape.reverse, s->compute);
+        used = launch_stencil5_spmv(A, s->plan_interior, in, s->Ap, 1.0, part, skip, s->shape.reverse, s->compute, init);
         HIP_CHECK(hipStreamWaitEvent(s->compute, s->ev_halo_done, 0));
-        used += slab_boundary_spmv(s, in, part, skip, s->compute);
+        used += slab_boundary_spmv(s, in, part, skip, s->compute, init);
     }
     if (spmv_done) HIP_CHECK(hipEventRecord(spmv_done, s->compute));
     if (with_dot) {
@@ -293,6 +302,7 @@ void slab_spmv(SpmvAmdCgSlab* s, bool with_dot, bool overlap, const int* skip,
         else
             launch_dot((size_t)s->n_local, s->p, s->Ap, s->partials_blas, &s->d_s->pAp, s->compute);
     }
+    return used;
 }
 
 const char* query_name(hipError_t e) {
@@ -519,14 +529,27 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
             x0_halo_on_side = true;
         }
     }
-    slab_spmv(s, /*with_dot=*/false, /*overlap=*/x0_halo_on_side, nullptr, s->x0);
-    timed(&stats->time_initial_r_ms, nullptr, [&] {
-        launch_cg_init_residual(nl, s->b, s->Ap, s->r, s->p, s->partials_blas, s->compute);
-    });
-    timed(&stats->time_dot_rs_initial_ms, nullptr, [&] {
-        launch_reduce_partials(s->partials_blas, cg_partial_count(nl), &s->d_s->rr_new, nullptr, s->compute, s->reduce_stage,
-                               nullptr, 0, mailbox);
-    });
+    if (s->fuse_init_residual) {
+        // row-lds slabs: r0 = b - A x0, p0 = r0 and the r0.r0 partials come out of the SpMV launch itself (A x0 is
+        // never written out and read back: 16 B/row less, once per solve)
+        const ResidualOut init{s->b, s->r, s->p};
+        int used = 0;
+        timed(&stats->time_initial_r_ms, nullptr, [&] {
+            used = slab_spmv(s, /*with_dot=*/false, /*overlap=*/x0_halo_on_side, nullptr, s->x0, nullptr, &init);
+        });
+        timed(&stats->time_dot_rs_initial_ms, nullptr, [&] {
+            launch_reduce_partials(s->partials_spmv, used, &s->d_s->rr_new, nullptr, s->compute, s->reduce_stage, nullptr, 0, mailbox);
+        });
+    } else {
+        slab_spmv(s, /*with_dot=*/false, /*overlap=*/x0_halo_on_side, nullptr, s->x0);
+        timed(&stats->time_initial_r_ms, nullptr, [&] {
+            launch_cg_init_residual(nl, s->b, s->Ap, s->r, s->p, s->partials_blas, s->compute);
+        });
+        timed(&stats->time_dot_rs_initial_ms, nullptr, [&] {
+            launch_reduce_partials(s->partials_blas, cg_partial_count(nl), &s->d_s->rr_new, nullptr, s->compute, s->reduce_stage,
+                                   nullptr, 0, mailbox);
+        });
+    }
     s->enqueued_stage = "initial residual";
     if (separate) allreduce_scalar(s, &s->d_s->rr_new, "all-reduce of the initial r.r");
     s->reduce_mailbox = s->fused_dot ? mailbox : nullptr;  // the in-loop SpMVs' p.Ap reduction

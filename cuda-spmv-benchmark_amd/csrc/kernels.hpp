@@ -101,9 +101,18 @@ struct Stencil5Plan {
 };
 Stencil5Plan plan_stencil5(const SlabCsr& m, int first_row, int last_row, Stencil5Variant variant,
                            const LaunchShape& shape);
+// The first SpMV of a CG solve fused with the initial residual (row-lds plans only): instead of storing y = A x the
+// launch writes r = b - A x and p = r and one partial of r.r per wave into d_dot_partials.
+struct ResidualOut {
+    const double* b;
+    double* r;
+    double* p;
+};
 // Launch by plan. reverse: walk the tiles from the last to the first (row-lds only; same results).
+// init (may be null): see ResidualOut; y is then not written and may be null.
 int launch_stencil5_spmv(const SlabCsr& m, const Stencil5Plan& plan, const double* x, double* y, double alpha,
-                         double* d_dot_partials, const int* d_skip_flag, bool reverse, hipStream_t stream);
+                         double* d_dot_partials, const int* d_skip_flag, bool reverse, hipStream_t stream,
+                         const ResidualOut* init = nullptr);
 // Partial-sum slots a launch over [first_row, last_row) writes (a fixed function of the slab, the
 // range and the launch shape, so reductions keep one shape for the life of a solver).
 int stencil5_partials_needed(const SlabCsr& m, int first_row, int last_row, Stencil5Variant variant,
@@ -123,7 +132,8 @@ int launch_stencil5_spmv(const SlabCsr& m, const double* x, double* y, double al
 // `head` = plan_stencil5(m, 0, grid_size, ...), the plan of the slab's first grid row.
 int launch_stencil5_spmv_first_and_last_gridrow(const SlabCsr& m, const Stencil5Plan& head, const double* x, double* y,
                                                 double alpha, double* d_dot_partials, const int* d_skip_flag,
-                                                const LaunchShape& shape, hipStream_t stream);
+                                                const LaunchShape& shape, hipStream_t stream,
+                                                const ResidualOut* init = nullptr);
 
 // ---- CSR SpMV ----
 enum class CsrVariant { Auto, Stream, RowScalar, Wavefront, SubWave4, SubWave8, SubWave16, SubWave32 };

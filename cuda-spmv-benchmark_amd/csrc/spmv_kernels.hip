@@ -497,11 +497,17 @@ __global__ __launch_bounds__(kBlock) void stencil5_rowdirect_kernel(
 // ---------------------------------------------------------------------------------
 constexpr int kLdsTileCols = 128;
 
-template <bool kDot, bool kWeLds = false>
+// kMode 0: y = alpha A x. kMode 1: also one partial of x . (A x) per wave (the CG loop's p.Ap).
+// kMode 2 (first SpMV of a solve, x = the initial guess): y is NOT stored; instead r = b - A x (one fma, the
+// reference's axpy_kernel(-1, Ap, b), mgpu :475), p = r, and one partial of r.r per wave -- the initial residual
+// without writing A x0 out and reading it back (16 B/row less, once per solve).
+template <int kMode, bool kWeLds = false>
 __global__ __launch_bounds__(64) void stencil5_rowlds_kernel(
     SlabCsr m, const double* __restrict__ x, double* __restrict__ y, double alpha, int gi_lo, int row_step,
     int gfirst, int col_tiles, int total_tiles, int group, int reverse, double* __restrict__ dot_partials,
-    const int* __restrict__ skip_flag) {
+    const int* __restrict__ skip_flag, ResidualOut res) {
+    constexpr bool kDot = kMode == 1;
+    constexpr bool kInit = kMode == 2;
     __shared__ double strip[5 * kLdsTileCols];
     __shared__ double xrow[kWeLds ? kLdsTileCols + 2 : 1];  // kWeLds: the tile's x values, W / E read back from here
     // The convergence flag is REQUESTED here and tested after the tile's loads have been issued: a wave does not sit
@@ -542,14 +548,15 @@ __global__ __launch_bounds__(64) void stencil5_rowlds_kernel(
 #pragma unroll
             for (int k = 0; k < 10; ++k) c[k] = __builtin_nontemporal_load(vals + e + 64 * k);
         }
-        double xc[2], xw[2], xe[2], xn[2], xs[2];
+        double xc[2], xw[2], xe[2], xn[2], xs[2], bv[2];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int j = j0 + lane + 64 * h;
-            xc[h] = xw[h] = xe[h] = xn[h] = xs[h] = 0.0;
+            xc[h] = xw[h] = xe[h] = xn[h] = xs[h] = bv[h] = 0.0;
             if (j < n) {
                 const double* __restrict__ xl = x + ((long long)li * n + j);
                 xc[h] = xl[0], xn[h] = xl[-n], xs[h] = xl[n];
+                if (kInit) bv[h] = __builtin_nontemporal_load(res.b + ((long long)li * n + j));
                 if (!kWeLds) {
                     if (j > 0) xw[h] = xl[-1];
                     if (j < n - 1) xe[h] = xl[1];
@@ -602,7 +609,15 @@ __global__ __launch_bounds__(64) void stencil5_rowlds_kernel(
                     sum = fma(v[3], xs[h], sum);
                 }
                 if (kDot) dot_acc = fma(xc[h], sum, dot_acc);
-                __builtin_nontemporal_store(alpha * sum, y + ((long long)li * n + j));
+                if (kInit) {
+                    const long long lr = (long long)li * n + j;
+                    const double rv = fma(-1.0, alpha * sum, bv[h]);
+                    __builtin_nontemporal_store(rv, res.r + lr);
+                    res.p[lr] = rv;  // plain: the next SpMV's neighbour loads re-use these lines
+                    dot_acc = fma(rv, rv, dot_acc);
+                } else {
+                    __builtin_nontemporal_store(alpha * sum, y + ((long long)li * n + j));
+                }
             }
         }
     } else {
@@ -615,11 +630,18 @@ __global__ __launch_bounds__(64) void stencil5_rowlds_kernel(
                 const long long lr = (long long)li * n + j;
                 const double sum = row_reference<false>(m, x, (int)lr, gi, j);
                 if (kDot) dot_acc = fma(x[lr], sum, dot_acc);
-                y[lr] = alpha * sum;
+                if (kInit) {
+                    const double rv = fma(-1.0, alpha * sum, res.b[lr]);
+                    res.r[lr] = rv;
+                    res.p[lr] = rv;
+                    dot_acc = fma(rv, rv, dot_acc);
+                } else {
+                    y[lr] = alpha * sum;
+                }
             }
         }
     }
-    if (kDot) {
+    if (kDot || kInit) {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) dot_acc += __shfl_down(dot_acc, off);
         if (lane == 0) dot_partials[tile] = dot_acc;
@@ -1080,9 +1102,14 @@ int launch_stencil5_spmv(const SlabCsr& m, const double* x, double* y, double al
 }
 
 int launch_stencil5_spmv(const SlabCsr& m, const Stencil5Plan& p, const double* x, double* y, double alpha,
-                         double* d_dot_partials, const int* d_skip_flag, bool reverse, hipStream_t stream) {
+                         double* d_dot_partials, const int* d_skip_flag, bool reverse, hipStream_t stream,
+                         const ResidualOut* init) {
     const int first_row = p.first_row, last_row = p.last_row;
     if (last_row <= first_row) return 0;
+    if (init != nullptr && (p.variant != Stencil5Variant::RowLds || d_dot_partials == nullptr)) {
+        fprintf(stderr, "[spmv] the fused initial residual exists for the row-lds kernel only\n");
+        exit(EXIT_FAILURE);
+    }
     const int n = m.grid_size;
     const bool dot = d_dot_partials != nullptr;
     const bool analytic = m.verified_stencil && n >= 2;
@@ -1131,15 +1158,18 @@ int launch_stencil5_spmv(const SlabCsr& m, const Stencil5Plan& p, const double* 
         const int span = 8 * p.rows_per_task;  // rows_per_task carries the tiles-per-XCD group here
         const dim3 grid((unsigned)((tiles + span - 1) / span * span));
         const int gfirst = m.row_offset / n;
-#define SPMV_AMD_LAUNCH_ROWLDS(DOT, WE)                                                                            \
-    hipLaunchKernelGGL((stencil5_rowlds_kernel<DOT, WE>), grid, dim3(64), 0, stream, m, x, y, alpha, p.gi_lo, 1, gfirst, \
-                       p.row_blocks, (int)tiles, p.rows_per_task, reverse ? 1 : 0, d_dot_partials, d_skip_flag)
+        const ResidualOut res = init ? *init : ResidualOut{nullptr, nullptr, nullptr};
+#define SPMV_AMD_LAUNCH_ROWLDS(MODE, WE)                                                                            \
+    hipLaunchKernelGGL((stencil5_rowlds_kernel<MODE, WE>), grid, dim3(64), 0, stream, m, x, y, alpha, p.gi_lo, 1, gfirst, \
+                       p.row_blocks, (int)tiles, p.rows_per_task, reverse ? 1 : 0, d_dot_partials, d_skip_flag, res)
         if (p.we_from_lds) {
-            if (dot) SPMV_AMD_LAUNCH_ROWLDS(true, true);
-            else SPMV_AMD_LAUNCH_ROWLDS(false, true);
+            if (init) SPMV_AMD_LAUNCH_ROWLDS(2, true);
+            else if (dot) SPMV_AMD_LAUNCH_ROWLDS(1, true);
+            else SPMV_AMD_LAUNCH_ROWLDS(0, true);
         } else {
-            if (dot) SPMV_AMD_LAUNCH_ROWLDS(true, false);
-            else SPMV_AMD_LAUNCH_ROWLDS(false, false);
+            if (init) SPMV_AMD_LAUNCH_ROWLDS(2, false);
+            else if (dot) SPMV_AMD_LAUNCH_ROWLDS(1, false);
+            else SPMV_AMD_LAUNCH_ROWLDS(0, false);
         }
 #undef SPMV_AMD_LAUNCH_ROWLDS
         return (int)tiles;
@@ -1193,9 +1223,13 @@ int launch_stencil5_spmv(const SlabCsr& m, const Stencil5Plan& p, const double* 
 
 int launch_stencil5_spmv_first_and_last_gridrow(const SlabCsr& m, const Stencil5Plan& head, const double* x, double* y,
                                                 double alpha, double* d_dot_partials, const int* d_skip_flag,
-                                                const LaunchShape& shape, hipStream_t stream) {
+                                                const LaunchShape& shape, hipStream_t stream, const ResidualOut* init) {
     const int n = m.grid_size;
     const int local_gridrows = n > 0 ? m.n_local / n : 0;
+    if (init != nullptr && (head.variant != Stencil5Variant::RowLds || d_dot_partials == nullptr || local_gridrows < 2)) {
+        fprintf(stderr, "[spmv] the fused initial residual exists for the row-lds kernel only\n");
+        exit(EXIT_FAILURE);
+    }
     if (n <= 0 || local_gridrows < 2 || head.variant != Stencil5Variant::RowLds) {
         // two launches over the two row ranges (any variant)
         int used = launch_stencil5_spmv(m, x, y, alpha, 0, n, d_dot_partials, d_skip_flag, Stencil5Variant::Auto, shape, stream);
@@ -1209,12 +1243,16 @@ int launch_stencil5_spmv_first_and_last_gridrow(const SlabCsr& m, const Stencil5
     const int span = 8 * head.rows_per_task;
     const dim3 grid((unsigned)((tiles + span - 1) / span * span));
     const int gfirst = m.row_offset / n;
-    if (d_dot_partials)
-        hipLaunchKernelGGL((stencil5_rowlds_kernel<true>), grid, dim3(64), 0, stream, m, x, y, alpha, 0, local_gridrows - 1,
-                           gfirst, head.row_blocks, tiles, head.rows_per_task, 0, d_dot_partials, d_skip_flag);
+    const ResidualOut res = init ? *init : ResidualOut{nullptr, nullptr, nullptr};
+    if (init)
+        hipLaunchKernelGGL((stencil5_rowlds_kernel<2>), grid, dim3(64), 0, stream, m, x, y, alpha, 0, local_gridrows - 1,
+                           gfirst, head.row_blocks, tiles, head.rows_per_task, 0, d_dot_partials, d_skip_flag, res);
+    else if (d_dot_partials)
+        hipLaunchKernelGGL((stencil5_rowlds_kernel<1>), grid, dim3(64), 0, stream, m, x, y, alpha, 0, local_gridrows - 1,
+                           gfirst, head.row_blocks, tiles, head.rows_per_task, 0, d_dot_partials, d_skip_flag, res);
     else
-        hipLaunchKernelGGL((stencil5_rowlds_kernel<false>), grid, dim3(64), 0, stream, m, x, y, alpha, 0, local_gridrows - 1,
-                           gfirst, head.row_blocks, tiles, head.rows_per_task, 0, d_dot_partials, d_skip_flag);
+        hipLaunchKernelGGL((stencil5_rowlds_kernel<0>), grid, dim3(64), 0, stream, m, x, y, alpha, 0, local_gridrows - 1,
+                           gfirst, head.row_blocks, tiles, head.rows_per_task, 0, d_dot_partials, d_skip_flag, res);
     return tiles;
 }
 
