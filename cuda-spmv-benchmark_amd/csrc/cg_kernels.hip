@@ -436,19 +436,17 @@ __global__ __launch_bounds__(kStream) void cg_update_p_ring_kernel(size_t n, con
                                                                    const double* __restrict__ p_in,
                                                                    double* __restrict__ p_out, int iteration,
                                                                    int reverse) {
-    // loads first, scalars second (see cg_update_r_kernel)
+    // Scalars FIRST here, unlike cg_update_r_kernel: this launch is enqueued before the host knows whether the
+    // iteration converged, and the launch of the converging iteration must cost nothing (loading first would read
+    // 16 B/row for nothing once per solve).
+    if (s->iterations != iteration || s->converged != 0) return;
+    const double beta = s->beta;
     const unsigned block = reverse ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
     const size_t pairs = n >> 1;
     const size_t i = (size_t)block * kStream + threadIdx.x;
-    d2 rv = {0.0, 0.0}, pv = {0.0, 0.0};
     if (i < pairs) {
-        rv = load_once(r, i);
-        pv = load_once(p_in, i);
-    }
-    const int iterations = s->iterations, converged = s->converged;
-    const double beta = s->beta;
-    if (iterations != iteration || converged != 0) return;
-    if (i < pairs) {
+        const d2 rv = load_once(r, i);
+        d2 pv = load_once(p_in, i);
         pv.x = fma(1.0, rv.x, beta * pv.x);
         pv.y = fma(1.0, rv.y, beta * pv.y);
         reinterpret_cast<d2*>(p_out)[i] = pv;  // plain: the next SpMV's neighbour loads re-use these lines
