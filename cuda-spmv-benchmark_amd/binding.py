@@ -481,6 +481,10 @@ class Comm:
         """Collective: peer-mailbox all-reduce over hipIpc-mapped device memory; True when every rank's passed its self-test."""
         return lib().spmv_amd_comm_mailbox_enable(self.handle) == 1
 
+    def mailbox_selftest(self, rounds=8):
+        """Collective: `rounds` back-to-back mailbox all-reduces with known sums; 0 = all correct."""
+        return lib().spmv_amd_comm_mailbox_selftest(self.handle, int(rounds))
+
     def mailbox_ready(self):
         return lib().spmv_amd_comm_mailbox_ready(self.handle) == 1
 
