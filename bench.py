@@ -481,8 +481,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t[0])
     hist = slab.history()
-    # template arguments: <kDot = true (p.Ap partials), kWeLds = W/E neighbours from LDS (the default)>
-    rowlds = "stencil5_rowlds_kernel<true, true>" if os.environ.get("SPMV_AMD_ROWLDS_WE_LDS", "1") != "0" else "stencil5_rowlds_kernel<true, false>"
+    # template arguments: <kMode = 1 (SpMV + p.Ap partials), kWeLds = W/E neighbours from LDS (the default)>
+    rowlds = "stencil5_rowlds_kernel<1, true>" if os.environ.get("SPMV_AMD_ROWLDS_WE_LDS", "1") != "0" else "stencil5_rowlds_kernel<1, false>"
     kernel_symbol = {"stencil5/row-lds": rowlds, "stencil5/row-direct": "stencil5_rowdirect_kernel<1, true>"}.get(slab.variant(), slab.variant())
 
     # dominant kernel: STENCIL5 SpMV of this rank's slab, average over the launches of the timed steps

@@ -50,6 +50,8 @@ for line in open(os.path.join(src, "bench_stats_run.log")):
 summary = json.load(open(os.path.join(src, "summary.json")))
 bench = json.load(open(os.path.join(dst, f"{tag}_bench_default.json")))
 kernel = bench["roofline"]["kernel"].split(" (")[0]
+if "<true" in kernel:  # line written before the kernel's template head changed from <bool kDot, .> to <int kMode, .>
+    kernel = kernel.replace("<true, ", "<1, ")
 # the in-loop instantiation (kDot = true): its PMC rows are the SpMV launches of the CG loop
 pmc = next(v for k, v in summary["pmc_avg_per_launch"].items() if kernel.split("<")[0] in k and kernel.split("<")[1].rstrip(">") in k)
 source = os.path.join(ROOT, "cuda-spmv-benchmark_amd", "csrc", "spmv_kernels.hip")
