@@ -476,7 +476,11 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     iterations = st.iterations
+    rank_ms = [dt / args.steps * 1e3]
     if multi:
+        box = [None] * world
+        dist.all_gather_object(box, rank_ms[0])
+        rank_ms = [float(v) for v in box]  # every rank's own wall time per step: the spread shows load imbalance
         t = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t[0])
@@ -540,7 +544,7 @@ def main():
                            "grid": n, "unknowns": rows, "nnz": nnz, "partition": f"{world} row slab(s)", "transport": transport,
                            "iterations_per_solve": iterations, "converged": bool(st.converged), "final_residual": st.residual_norm,
                            "residual_history": [float(v) for v in hist]},
-                   transport=transport, allreduce=allreduce, rccl_ranks=rccl_ranks, devices=devices,
+                   transport=transport, allreduce=allreduce, rccl_ranks=rccl_ranks, devices=devices, rank_ms_per_step=rank_ms,
                    launched_by="bench.py (self-launched ranks)" if os.environ.get("SPMV_AMD_BENCH_SELF_LAUNCHED") == "1" else
                    ("external launcher (RANK/WORLD_SIZE in the environment)" if "RANK" in os.environ else "single process"),
                    roofline=roofline)
