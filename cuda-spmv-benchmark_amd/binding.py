@@ -481,6 +481,16 @@ class Comm:
         """Collective: peer-mailbox all-reduce over hipIpc-mapped device memory; True when every rank's passed its self-test."""
         return lib().spmv_amd_comm_mailbox_enable(self.handle) == 1
 
+    def mailbox_prepare(self):
+        """Step 1 of the manual set-up: allocate this rank's mailbox, return its 64-byte hipIpc handle (None on failure)."""
+        buf = C.create_string_buffer(64)
+        return buf.raw if lib().spmv_amd_comm_mailbox_prepare(self.handle, buf) == 0 else None
+
+    def mailbox_connect(self, handles):
+        """Step 2: map every rank's mailbox (handles: list of 64-byte blobs in rank order); True on success."""
+        blob = b"".join(handles)
+        return lib().spmv_amd_comm_mailbox_connect(self.handle, C.create_string_buffer(blob, len(blob)), len(handles)) == 0
+
     def mailbox_selftest(self, rounds=8):
         """Collective: `rounds` back-to-back mailbox all-reduces with known sums; 0 = all correct."""
         return lib().spmv_amd_comm_mailbox_selftest(self.handle, int(rounds))

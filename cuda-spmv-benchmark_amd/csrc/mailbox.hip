@@ -104,9 +104,11 @@ extern "C" int spmv_amd_comm_mailbox_connect(SpmvAmdComm* comm, const void* all_
     mb.inbox = h->inbox;
     mb.rank = comm->rank;
     mb.world = comm->world;
-    double limit_s = 20.0;  // far above any skew between ranks inside a solve, below the host watchdog (60 s)
-    if (const char* v = getenv("SPMV_AMD_MAILBOX_TIMEOUT_S")) limit_s = atof(v);
-    mb.timeout_ticks = (long long)(limit_s * 1e8);  // wall_clock64 runs at 100 MHz
+    // Until the self-test has passed a wait gives up after 5 s (a mailbox that does not work must not cost more than
+    // that before the communicator falls back to its transport's all-reduce); then the limit becomes
+    // SPMV_AMD_MAILBOX_TIMEOUT_S (default 20 s: far above any skew between ranks inside a solve, below the host
+    // watchdog's 60 s).
+    mb.timeout_ticks = (long long)(5.0 * 1e8);  // wall_clock64 runs at 100 MHz
     for (int r = 0; r < comm->world; ++r) {
         if (r == comm->rank) {
             mb.peer_inbox[r] = h->inbox;
@@ -177,6 +179,12 @@ extern "C" int spmv_amd_comm_mailbox_selftest(SpmvAmdComm* comm, int rounds) {
         bad = 1;
     } else if (bad) {
         fprintf(stderr, "[comm/mailbox] rank %d: self-test produced a wrong sum\n", comm->rank);
+    }
+    if (!bad) {  // trusted from here on: the working limit replaces the probation limit
+        double limit_s = 20.0;
+        if (const char* v = getenv("SPMV_AMD_MAILBOX_TIMEOUT_S")) limit_s = atof(v);
+        const long long ticks = (long long)(limit_s * 1e8);
+        HIP_CHECK(hipMemcpy(&comm->d_mailbox->timeout_ticks, &ticks, sizeof ticks, hipMemcpyHostToDevice));
     }
     return bad;
 }

@@ -18,6 +18,9 @@ __device__ __forceinline__ double mailbox_allreduce_wave(const PeerMailbox& mb, 
     const int set = (int)(seq & 1) * world;
     double got = 0.0;
     int late = 0;
+    // once a wait has timed out the mailbox is dead: later calls return at once (the host ends the solve, or the
+    // self-test reports failure, without paying the limit again per call)
+    if (__hip_atomic_load(mb.host_error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) return mine;
     if (lane < world) {
         MailboxSlot* dst = mb.peer_inbox[lane] + set + mb.rank;
         __hip_atomic_store(&dst->value_bits, (unsigned long long)__double_as_longlong(mine), __ATOMIC_RELAXED,

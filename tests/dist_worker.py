@@ -135,7 +135,8 @@ def run_gpu(n, rank, world, synthetic, mailbox=False):
 def main():
     mode, n = sys.argv[1], int(sys.argv[2])
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import datetime
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
     try:
         if mode == "oracle":
             run_oracle(n, rank, world)

@@ -7,6 +7,7 @@ import os
 import socket
 import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -23,25 +24,37 @@ def free_port():
     return port
 
 
-def launch(world, mode, n, timeout=600):
+def launch(world, mode, n, timeout=300):
+    """Starts `world` ranks of tests/dist_worker.py. A rank that fails must not leave the others waiting in a gloo
+    collective until some outer limit: as soon as one exits non-zero (or the deadline passes) the rest are ended and
+    the failing rank's output is reported."""
     port = free_port()
-    procs = []
+    procs, logs = [], []
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1")
+        log = tempfile.TemporaryFile(mode="w+")
+        logs.append(log)
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), mode, str(n)],
-                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+                                      env=env, stdout=log, stderr=subprocess.STDOUT, text=True))
+    deadline = time.monotonic() + timeout
+    while any(p.poll() is None for p in procs):
+        if any(p.poll() not in (None, 0) for p in procs) or time.monotonic() > deadline:
+            time.sleep(2.0)  # let the others print what they have
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            break
+        time.sleep(0.05)
     outs = []
-    for p in procs:
-        try:
-            out, _ = p.communicate(timeout=timeout)
-        except subprocess.TimeoutExpired:
-            for q in procs:
-                q.kill()
-            raise
-        outs.append(out)
+    for p, log in zip(procs, logs):
+        p.wait()
+        log.seek(0)
+        outs.append(log.read())
+        log.close()
     for rank, (p, out) in enumerate(zip(procs, outs)):
-        assert p.returncode == 0, f"rank {rank} failed:\n{out}"
+        assert p.returncode == 0, f"rank {rank} exited with {p.returncode} (first failure decides; killed ranks show -9):\n" + \
+            "\n".join(f"--- rank {r} ---\n{o[-3000:]}" for r, o in enumerate(outs))
     return outs
 
 
@@ -69,6 +82,38 @@ def test_slab_solver_with_the_peer_mailbox_all_reduce(world, n, mode):
     same parity bar as every other transport (iteration count, ||r_k|| and x at 1e-10 against the oracle)."""
     outs = launch(world, mode, n)
     assert all("slab solver over staged/gloo communicator ok" in o for o in outs)
+
+
+@pytest.mark.gpu
+def test_a_mailbox_whose_peer_never_answers_fails_its_self_test_and_is_dropped(tmp_path):
+    """Rank 0 of a two-rank communicator sets its mailbox up by hand with a 'peer' that is its own second allocation
+    and never writes: either the mapping is refused, or the self-test gives up after its 5 s probation limit and
+    reports failure -- the process lives on and the communicator keeps its transport's all-reduce. Run in a child
+    process with a deadline, so that a defect here shows as a failure, not as a stalled test run."""
+    script = tmp_path / "dead_peer.py"
+    script.write_text(
+        "import sys, time\n"
+        f"sys.path.insert(0, {os.path.join(ROOT, 'tests')!r})\n"
+        "from conftest import load_binding\n"
+        "B = load_binding(); B.lib(); B.require_gpu()\n"
+        "comm = B.Comm.staged(0, 2, lambda *a: 0, lambda *a: 0)\n"
+        "other = B.Comm.staged(1, 2, lambda *a: 0, lambda *a: 0)   # same process: stands in for a dead peer\n"
+        "h0, h1 = comm.mailbox_prepare(), other.mailbox_prepare()\n"
+        "assert h0 is not None and h1 is not None\n"
+        "print('prepared', flush=True)\n"
+        "t0 = time.monotonic()\n"
+        "if comm.mailbox_connect([h0, h1]):\n"
+        "    print('connected', flush=True)\n"
+        "    assert comm.mailbox_selftest(4) != 0          # rank 1 never contributes\n"
+        "    assert time.monotonic() - t0 < 30\n"
+        "    comm.mailbox_disable()\n"
+        "else:\n"
+        "    print('mapping refused', flush=True)\n"
+        "assert not comm.mailbox_ready()\n"
+        "comm.destroy(); other.destroy()\n"
+        "print('alive', flush=True)\n")
+    out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "alive" in out.stdout, out.stdout + out.stderr
 
 
 @pytest.mark.gpu
