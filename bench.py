@@ -292,7 +292,7 @@ def self_launch(args):
         now = time.monotonic()
         if failed_at is None and any(p.poll() not in (None, 0) for p in procs):
             failed_at = now  # the other ranks notice through gloo / the solver's watchdog; give them a moment to report
-        if (failed_at is not None and now - failed_at > 90) or now > deadline:
+        if (failed_at is not None and now - failed_at > args.launch_grace) or now > deadline:
             for p in procs:
                 if p.poll() is None:
                     p.kill()  # exactly the children started above
@@ -325,6 +325,8 @@ def main():
     ap.add_argument("--no-scaling-probe", action="store_true", help="skip the N=1 one-GPU strong-scaling probe")
     ap.add_argument("--no-ceiling", action="store_true", help="skip the in-run stream-ceiling probe")
     ap.add_argument("--launch-timeout", type=float, default=1500.0, help="self-launch only: seconds before the parent ends the ranks")
+    ap.add_argument("--launch-grace", type=float, default=90.0,
+                    help="self-launch only: seconds the other ranks get to report after one rank has exited non-zero")
     ap.add_argument("--scaling-probe-only", nargs=2, metavar=("FULL_MS", "FULL_ITERATIONS"), default=None,
                     help="(internal) run only the scaling probe and print its JSON object")
     args = ap.parse_args()
@@ -354,6 +356,9 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if os.environ.get("SPMV_AMD_BENCH_TEST_CRASH_RANK") == str(rank):  # test hook: a rank that dies before the rendezvous
+        print(f"bench.py: rank {rank} exiting with status 7 on request (SPMV_AMD_BENCH_TEST_CRASH_RANK)", file=sys.stderr)
+        os._exit(7)
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
     if world != args.gpus:
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: running {world} rank(s)", file=sys.stderr)

@@ -200,6 +200,19 @@ def test_bench_self_launches_its_ranks_and_fails_loudly_without_gpus():
     assert "UNMEASURED" in out.stderr
 
 
+def test_bench_self_launch_reports_a_rank_that_died():
+    """One of the self-launched ranks dies before the rendezvous: the parent gives the others a moment, ends them,
+    prints ONE line saying nothing was measured and with which statuses the ranks ended, and exits non-zero itself."""
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="", SPMV_AMD_BENCH_TEST_CRASH_RANK="1")
+    env.pop("RANK", None), env.pop("WORLD_SIZE", None)
+    t0 = time.monotonic()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--grid", "256",
+                          "--launch-grace", "3"], env=env, capture_output=True, text=True, timeout=300)
+    lines = _json_lines(out.stdout)
+    assert out.returncode != 0 and time.monotonic() - t0 < 120, out.stdout + out.stderr
+    assert len(lines) == 1 and lines[0]["value"] is None and "7" in lines[0]["unmeasured"] and lines[0]["n_gpus"] == 2
+
+
 def test_watchdog_turns_a_wedged_barrier_into_a_diagnosable_exit(tmp_path):
     """A staged communicator whose barrier callback never returns (a peer that died): the watchdog names the rank and
     the stage and ends the process with a non-zero status after SPMV_AMD_WATCHDOG_S seconds. No GPU involved."""
