@@ -13,7 +13,7 @@ configuration of reference docs/PROBLEM_SIZE_SCALING_RESULTS.md:40-47, on N row 
   value     CG iterations per second, whole job = K * iterations / (max over ranks of the time
             of K steps, bracketed by barrier + torch.cuda.synchronize() on both sides).
   scaling   strong: the 400 M-unknown problem is fixed, slabs shrink as N grows.
-  roofline  the dominant kernel of the timed region, the STENCIL5 row-lds SpMV (fused with the
+  roofline  the dominant kernel of the timed region, the solver's STENCIL5 SpMV (row-planes kernel, fused with the
             p.Ap partials): algorithmic bytes of one launch (8*nnz + 8*cols + 8*rows of the slab,
             SURVEY.md 8d) / its average duration, from HIP events recorded on the solver's stream
             around every in-loop launch of the timed steps. Peak 8 TB/s (MI355X_MICROARCH.md).
@@ -492,7 +492,8 @@ def main():
     hist = slab.history()
     # template arguments: <kMode = 1 (SpMV + p.Ap partials), kWeLds = W/E neighbours from LDS (the default)>
     rowlds = "stencil5_rowlds_kernel<1, true>" if os.environ.get("SPMV_AMD_ROWLDS_WE_LDS", "1") != "0" else "stencil5_rowlds_kernel<1, false>"
-    kernel_symbol = {"stencil5/row-lds": rowlds, "stencil5/row-direct": "stencil5_rowdirect_kernel<1, true>"}.get(slab.variant(), slab.variant())
+    kernel_symbol = {"stencil5/row-lds": rowlds, "stencil5/row-planes": rowlds.replace("rowlds", "planes"),
+                     "stencil5/row-direct": "stencil5_rowdirect_kernel<1, true>"}.get(slab.variant(), slab.variant())
 
     # dominant kernel: STENCIL5 SpMV of this rank's slab, average over the launches of the timed steps
     local_rows, local_nnz = slab.n_local, slab.local_nnz if slab.local_nnz > 0 else None

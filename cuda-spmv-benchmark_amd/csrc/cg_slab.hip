@@ -203,6 +203,12 @@ void make_common(SpmvAmdCgSlab* s) {
     HIP_CHECK(hipHostMalloc((void**)&s->h_poll, sizeof(*s->h_poll), hipHostMallocCoherent | hipHostMallocMapped));
     memset(s->h_poll, 0, sizeof(*s->h_poll));
     s->A.verify_stencil(s->compute);
+    // SPMV_AMD_SLAB_PLANES=1 (off by default: measured slower in the loop, spmv_kernels.hip): a verified stencil slab
+    // made of whole grid rows also keeps its coefficients as five planes and runs the row-planes kernel (+40 B/row
+    // of HBM, built once here, outside every timed region like the rest of the set-up).
+    if (s->shape.knobs.slab_planes != 0 && s->A.view.verified_stencil && s->grid >= s->shape.knobs.rowlds_min_grid &&
+        s->row_offset % s->grid == 0 && s->n_local % s->grid == 0)
+        s->A.build_planes(s->compute);
     {
         // dot partials: one slot per launched wave; the launch geometry is a fixed function of the
         // slab and the row range, so size for the larger of the two ways a SpMV is issued
@@ -223,9 +229,9 @@ void make_common(SpmvAmdCgSlab* s) {
         // unverified / unaligned slabs run the row-generic kernel and use the plain dot kernel
         s->fused_dot = strstr(s->variant_name, "row-generic") == nullptr;
         // the initial residual rides in the first SpMV where every launch of the slab is a row-lds launch
-        const auto rowlds = [](const Stencil5Plan& p) { return p.last_row <= p.first_row || p.variant == Stencil5Variant::RowLds; };
-        s->fuse_init_residual = s->plan_whole.variant == Stencil5Variant::RowLds && rowlds(s->plan_interior) &&
-                                rowlds(s->plan_head) && rowlds(s->plan_tail);
+        const auto tiled = [](const Stencil5Plan& p) { return p.variant == Stencil5Variant::RowLds || p.variant == Stencil5Variant::RowPlanes; };
+        const auto rowlds = [&](const Stencil5Plan& p) { return p.last_row <= p.first_row || tiled(p); };
+        s->fuse_init_residual = tiled(s->plan_whole) && rowlds(s->plan_interior) && rowlds(s->plan_head) && rowlds(s->plan_tail);
         if (const char* v = getenv("SPMV_AMD_FUSE_INIT")) s->fuse_init_residual = s->fuse_init_residual && v[0] != '0';
     }
     launch_fill(s->b, nl, 1.0, s->compute);   // default right-hand side b = 1

@@ -23,6 +23,7 @@ Tunables read_tunables() {
     k.rowlds_group = env_int("SPMV_AMD_ROWLDS_GROUP", k.rowlds_group);
     if (k.rowlds_group < 0 || k.rowlds_group > 64) k.rowlds_group = 0;
     k.rowlds_we_lds = env_int("SPMV_AMD_ROWLDS_WE_LDS", k.rowlds_we_lds);
+    k.slab_planes = env_int("SPMV_AMD_SLAB_PLANES", k.slab_planes);
     k.direct_rows = env_int("SPMV_AMD_DIRECT_ROWS", k.direct_rows);
     if (k.direct_rows != 2 && k.direct_rows != 4) k.direct_rows = 1;
     k.wavetile_oneshot = env_int("SPMV_AMD_WAVETILE_ONESHOT", k.wavetile_oneshot);
@@ -127,7 +128,18 @@ void DeviceCsr::verify_stencil(hipStream_t stream) {
     view.verified_stencil = (h_flag == 0);
 }
 
+void DeviceCsr::build_planes(hipStream_t stream) {
+    if (!view.verified_stencil || view.grid_size < 2 || view.n_local <= 0) return;
+    device_release(planes);
+    planes = device_alloc<double>(5 * (size_t)view.n_local);
+    launch_build_stencil5_planes(view, planes, stream);
+    HIP_CHECK(hipStreamSynchronize(stream));
+    HIP_CHECK(hipGetLastError());
+    view.planes = planes;
+}
+
 void DeviceCsr::release() {
+    device_release(planes);
     device_release(row_ptr);
     device_release(col_idx);
     device_release(values);

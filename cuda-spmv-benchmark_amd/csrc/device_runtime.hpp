@@ -64,6 +64,7 @@ struct DeviceCsr {
     int* row_ptr = nullptr;
     int* col_idx = nullptr;
     double* values = nullptr;
+    double* planes = nullptr;  // optional plane copy of a verified stencil's coefficients (SlabCsr::planes)
     SlabCsr view;  // non-owning descriptor handed to the kernels
 
     // Uploads rows [row_offset, row_offset + n_local) of a host CSR, rebasing row_ptr to 0.
@@ -73,6 +74,8 @@ struct DeviceCsr {
                            hipStream_t stream);
     // Runs the structure check and records the verdict in view.verified_stencil.
     void verify_stencil(hipStream_t stream);
+    // After a successful verify_stencil: builds the five coefficient planes and publishes them in view.planes.
+    void build_planes(hipStream_t stream);
     void release();
 };
 

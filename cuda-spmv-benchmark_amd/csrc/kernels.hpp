@@ -22,6 +22,10 @@ struct SlabCsr {
     int n_global = 0;                // rows of the whole matrix
     int grid_size = -1;              // n of the n x n stencil, <= 0 if not a stencil
     bool verified_stencil = false;   // structure checked against the complete 5-point pattern
+    // Optional second copy of a verified stencil's coefficients as five planes [N | W | C | E | S], plane k of local
+    // row r at planes[k * n_local + r], absent entries 0 (solver slabs only, launch_build_stencil5_planes): every
+    // coefficient load becomes a 4 KiB-aligned, fully coalesced stream with no transpose behind it.
+    const double* planes = nullptr;
     // x is addressed as x[col - row_offset]; indices in [-halo_before, n_local + halo_after)
     // are readable, anything else contributes 0 (reference halo kernel semantics).
     int halo_before = 0;
@@ -34,6 +38,8 @@ struct SlabCsr {
 struct Tunables {
     int rowlds_min_grid = 512;    // smallest grid that takes row-lds automatically
     int rowlds_group = 0;         // consecutive row-lds tiles per XCD; 0 = derived from the grid (xcd_run_group())
+    int slab_planes = 0;          // 1: solver slabs keep a plane copy of a verified stencil's coefficients and run
+                                  // row-planes (measured slower in the CG loop than row-lds, see spmv_kernels.hip; off)
     int rowlds_we_lds = 1;        // row-lds: W / E neighbours from an LDS copy of the tile's x values (0 = two more global
                                   // loads per row): 20 000^2 3.67-3.71 -> 3.65-3.68 ms, 10 000^2 0.950 -> 0.925 ms, same bits
     int direct_rows = 1;          // grid rows per thread in row-direct (1, 2, 4)
@@ -78,10 +84,13 @@ void launch_generate_stencil5_csr(int n, int row_offset, int n_local, long long 
 // from the complete 5-point pattern of an n x n grid.
 void launch_verify_stencil5_csr(const SlabCsr& m, int* d_mismatch, hipStream_t stream);
 
+// Fills planes[5 * n_local] from the CSR values of a VERIFIED stencil slab (see SlabCsr::planes).
+void launch_build_stencil5_planes(const SlabCsr& m, double* planes, hipStream_t stream);
+
 // ---- STENCIL5 SpMV ----
 // y[r] = alpha * (A x)[r]. d_dot_partials, if non-null, receives one partial of
 // sum_r x[r]*y_unscaled[r] per launched wave (count: stencil5_partials_needed()).
-enum class Stencil5Variant { Auto, RowDirect, ColumnMarch, WaveTile, RowGeneric, RowLds };
+enum class Stencil5Variant { Auto, RowDirect, ColumnMarch, WaveTile, RowGeneric, RowLds, RowPlanes };
 // Everything about one STENCIL5 launch over local rows [first_row, last_row) that does not depend on the vectors:
 // which kernel, its grid, how many dot partials it writes. Computed once per (slab, row range) -- by an operator's
 // init, by a solver slab's creation -- and reused for every launch.

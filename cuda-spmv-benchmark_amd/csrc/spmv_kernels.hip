@@ -649,6 +649,139 @@ __global__ __launch_bounds__(64) void stencil5_rowlds_kernel(
 }
 
 // ---------------------------------------------------------------------------------
+// STENCIL5, row-planes variant (solver slabs; SlabCsr::planes). Index space, tile -> XCD runs, x handling, the three
+// modes and the arithmetic are row-lds's; the coefficients come from five planes [N | W | C | E | S] instead of the
+// CSR values array, so every coefficient load is a coalesced 8-byte-per-lane stream starting on a 1 KiB boundary and
+// nothing is transposed through LDS (a CSR tile of 640 coefficients starts wherever row (gi, j0) starts: 8-byte
+// aligned only -- the 3 % by which row-lds on tiles artificially aligned to 5 KiB beat the real layout).
+// Same 56 B per row. Every row of the grid is handled here: interior rows in the reference's W,C,E,N,S order
+// (spmv_stencil_csr_direct.cu:105-109), rows on the grid's border as the CSR loop would -- ascending column, i.e.
+// N, W, C, E, S without the absent ones, sum started at 0 (:116-119) -- so row_ptr / col_idx are never read.
+// MEASURED AND NOT ADOPTED (SPMV_AMD_SLAB_PLANES=1 selects it): bit-identical results, and as fast as row-lds in
+// back-to-back launches (3.66 ms at 20 000^2), but inside the CG loop its launches average 3.79-3.81 ms against
+// 3.62-3.69 ms for row-lds on the same box (solve 107.8-108.5 vs 104.6-106.4 ms; 13.85 vs 13.82 ms at 50 M rows):
+// five coefficient streams 3.2 GB apart per wave instead of one contiguous 5 KiB run do worse between the other
+// kernels of the loop than the alignment of the planes gains. The CSR array stays the solver's format.
+// ---------------------------------------------------------------------------------
+template <int kMode, bool kWeLds>
+__global__ __launch_bounds__(64) void stencil5_planes_kernel(
+    SlabCsr m, const double* __restrict__ x, double* __restrict__ y, double alpha, int gi_lo, int row_step,
+    int gfirst, int col_tiles, int total_tiles, int group, int reverse, double* __restrict__ dot_partials,
+    const int* __restrict__ skip_flag, ResidualOut res) {
+    constexpr bool kDot = kMode == 1;
+    constexpr bool kInit = kMode == 2;
+    __shared__ double xrow[kWeLds ? kLdsTileCols + 2 : 1];
+    const int skip = skip_flag != nullptr ? __builtin_nontemporal_load(skip_flag) : 0;  // tested after the loads are out
+    const int lane = (int)threadIdx.x;
+    const int b = (int)blockIdx.x;
+    const int span = 8 * group;
+    int tile = (b / span) * span + (b & 7) * group + ((b >> 3) % group);
+    if (tile >= total_tiles) return;
+    if (reverse) tile = total_tiles - 1 - tile;
+    const int n = m.grid_size;
+    const int row_group = tile / col_tiles;
+    const int col_tile = tile - row_group * col_tiles;
+    const int li = gi_lo + row_group * row_step;
+    const int gi = gfirst + li;
+    const int j0 = col_tile * kLdsTileCols;
+    const bool has_n = gi > 0, has_s = gi < n - 1;
+    const long long R = m.n_local;
+    const double* __restrict__ planes = m.planes;
+    double c[2][5], xc[2], xw[2], xe[2], xn[2], xs[2], bv[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int j = j0 + lane + 64 * h;
+        xc[h] = xw[h] = xe[h] = xn[h] = xs[h] = bv[h] = 0.0;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) c[h][k] = 0.0;
+        if (j < n) {
+            const long long lr = (long long)li * n + j;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) c[h][k] = __builtin_nontemporal_load(planes + k * R + lr);
+            const double* __restrict__ xl = x + lr;
+            xc[h] = xl[0];
+            if (has_n) xn[h] = xl[-n];
+            if (has_s) xs[h] = xl[n];
+            if (!kWeLds) {
+                if (j > 0) xw[h] = xl[-1];
+                if (j < n - 1) xe[h] = xl[1];
+            } else {
+                if (h == 0 && lane == 0 && j > 0) xw[0] = xl[-1];
+                if (h == 1 && lane == 63 && j < n - 1) xe[1] = xl[1];
+            }
+            if (kInit) bv[h] = __builtin_nontemporal_load(res.b + lr);
+        }
+    }
+    if (skip != 0) return;
+    if (kWeLds) {
+        xrow[1 + lane] = xc[0];
+        xrow[65 + lane] = xc[1];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (lane > 0) xw[0] = xrow[lane];
+        xe[0] = xrow[2 + lane];
+        xw[1] = xrow[64 + lane];
+        if (lane < 63) xe[1] = xrow[66 + lane];
+    }
+    double dot_acc = 0.0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int j = j0 + lane + 64 * h;
+        if (j < n) {
+            const long long lr = (long long)li * n + j;
+            const double vN = c[h][0], vW = c[h][1], vC = c[h][2], vE = c[h][3], vS = c[h][4];
+            double sum;
+            if (has_n && has_s && j > 0 && j < n - 1) {
+                sum = vW * xw[h];
+                sum = fma(vC, xc[h], sum);
+                sum = fma(vE, xe[h], sum);
+                sum = fma(vN, xn[h], sum);
+                sum = fma(vS, xs[h], sum);
+            } else {  // a row on the grid's border: the CSR loop's order over the entries that exist
+                sum = 0.0;
+                if (has_n) sum = fma(vN, xn[h], sum);
+                if (j > 0) sum = fma(vW, xw[h], sum);
+                sum = fma(vC, xc[h], sum);
+                if (j < n - 1) sum = fma(vE, xe[h], sum);
+                if (has_s) sum = fma(vS, xs[h], sum);
+            }
+            if (kDot) dot_acc = fma(xc[h], sum, dot_acc);
+            if (kInit) {
+                const double rv = fma(-1.0, alpha * sum, bv[h]);
+                __builtin_nontemporal_store(rv, res.r + lr);
+                res.p[lr] = rv;
+                dot_acc = fma(rv, rv, dot_acc);
+            } else {
+                __builtin_nontemporal_store(alpha * sum, y + lr);
+            }
+        }
+    }
+    if (kDot || kInit) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) dot_acc += __shfl_down(dot_acc, off);
+        if (lane == 0) dot_partials[tile] = dot_acc;
+    }
+}
+
+// One thread per local row of a verified stencil slab: the row's CSR entries [N,W,C,E,S minus the absent ones] spread
+// over the five planes, absent entries 0.
+__global__ __launch_bounds__(kBlock) void build_stencil5_planes_kernel(SlabCsr m, double* __restrict__ planes) {
+    const long long lr = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (lr >= m.n_local) return;
+    const int n = m.grid_size;
+    const long long g = (long long)m.row_offset + lr;
+    const int i = (int)(g / n), j = (int)(g - (long long)i * n);
+    long long k = stencil_row_start(i, j, n) - m.nnz_base;
+    const long long R = m.n_local;
+    planes[lr] = i > 0 ? m.values[k++] : 0.0;
+    planes[R + lr] = j > 0 ? m.values[k++] : 0.0;
+    planes[2 * R + lr] = m.values[k++];
+    planes[3 * R + lr] = j < n - 1 ? m.values[k++] : 0.0;
+    planes[4 * R + lr] = i < n - 1 ? m.values[k++] : 0.0;
+}
+
+// ---------------------------------------------------------------------------------
 // STENCIL5, row-generic variant: one thread per row, the reference's own shape. Used for
 // small grids, for matrices that are not a complete 5-point stencil (kAnalytic = false:
 // every row takes the CSR loop, as the reference does when grid_size = -1).
@@ -981,6 +1114,11 @@ void launch_verify_stencil5_csr(const SlabCsr& m, int* d_mismatch, hipStream_t s
                        m, d_mismatch);
 }
 
+void launch_build_stencil5_planes(const SlabCsr& m, double* planes, hipStream_t stream) {
+    if (m.n_local == 0) return;
+    hipLaunchKernelGGL(build_stencil5_planes_kernel, dim3(blocks_for(m.n_local)), dim3(kBlock), 0, stream, m, planes);
+}
+
 static int wavetile_blocks(const LaunchShape& shape) {
     int blocks = shape.compute_units * shape.blocks_per_cu;
     blocks = (blocks + 7) & ~7;
@@ -991,7 +1129,7 @@ static int plan_partials(const Stencil5Plan& p) {
     if (p.variant == Stencil5Variant::RowGeneric) return p.row_blocks * kWavesPerBlock;
     if (p.variant == Stencil5Variant::RowDirect)
         return p.row_blocks * ((p.gi_hi - p.gi_lo + p.rows_per_task - 1) / p.rows_per_task);
-    if (p.variant == Stencil5Variant::RowLds) return p.row_blocks * (p.gi_hi - p.gi_lo);
+    if (p.variant == Stencil5Variant::RowLds || p.variant == Stencil5Variant::RowPlanes) return p.row_blocks * (p.gi_hi - p.gi_lo);
     if (p.variant == Stencil5Variant::WaveTile) return p.tile_blocks * kWavesPerBlock;
     return (p.march_blocks + (p.head_rows ? p.row_blocks : 0) + (p.tail_rows ? p.row_blocks : 0)) * kWavesPerBlock;
 }
@@ -1000,6 +1138,7 @@ static const char* plan_name(const Stencil5Plan& p, const SlabCsr& m) {
     switch (p.variant) {
         case Stencil5Variant::RowDirect: return "stencil5/row-direct";
         case Stencil5Variant::RowLds: return "stencil5/row-lds";
+        case Stencil5Variant::RowPlanes: return "stencil5/row-planes";
         case Stencil5Variant::ColumnMarch: return "stencil5/column-march";
         case Stencil5Variant::WaveTile: return "stencil5/wave-tile";
         default: return m.verified_stencil ? "stencil5/row-generic" : "stencil5/row-generic(csr-loop)";
@@ -1019,9 +1158,11 @@ Stencil5Plan plan_stencil5(const SlabCsr& m, int first_row, int last_row, Stenci
     // row-lds needs grid rows long enough that the two clamped edge tiles are a small share
     const int lds_min_n = knobs.rowlds_min_grid;
     if (variant == Stencil5Variant::Auto)
-        variant = direct_ok ? (n >= lds_min_n ? Stencil5Variant::RowLds : Stencil5Variant::RowDirect)
+        variant = direct_ok ? (n >= lds_min_n ? (m.planes != nullptr ? Stencil5Variant::RowPlanes : Stencil5Variant::RowLds)
+                                              : Stencil5Variant::RowDirect)
                   : tile_ok ? Stencil5Variant::WaveTile
                             : Stencil5Variant::RowGeneric;
+    if (variant == Stencil5Variant::RowPlanes && (m.planes == nullptr || !direct_ok)) variant = Stencil5Variant::RowLds;
     if ((variant == Stencil5Variant::RowDirect || variant == Stencil5Variant::RowLds) && !direct_ok)
         variant = Stencil5Variant::RowGeneric;
     if (variant == Stencil5Variant::ColumnMarch && !march_ok)
@@ -1036,7 +1177,7 @@ Stencil5Plan plan_stencil5(const SlabCsr& m, int first_row, int last_row, Stenci
         p.row_blocks = (int)blocks_for(n);  // column blocks per grid row
         p.rows_per_task = knobs.direct_rows;
         if (p.rows_per_task != 2 && p.rows_per_task != 4) p.rows_per_task = 1;
-    } else if (variant == Stencil5Variant::RowLds) {
+    } else if (variant == Stencil5Variant::RowLds || variant == Stencil5Variant::RowPlanes) {
         p.gi_lo = first_row / n;
         p.gi_hi = last_row / n;
         p.row_blocks = (n + kLdsTileCols - 1) / kLdsTileCols;  // column tiles (= workgroups) per grid row
@@ -1106,7 +1247,7 @@ int launch_stencil5_spmv(const SlabCsr& m, const Stencil5Plan& p, const double* 
                          const ResidualOut* init) {
     const int first_row = p.first_row, last_row = p.last_row;
     if (last_row <= first_row) return 0;
-    if (init != nullptr && (p.variant != Stencil5Variant::RowLds || d_dot_partials == nullptr)) {
+    if (init != nullptr && ((p.variant != Stencil5Variant::RowLds && p.variant != Stencil5Variant::RowPlanes) || d_dot_partials == nullptr)) {
         fprintf(stderr, "[spmv] the fused initial residual exists for the row-lds kernel only\n");
         exit(EXIT_FAILURE);
     }
@@ -1151,6 +1292,28 @@ int launch_stencil5_spmv(const SlabCsr& m, const Stencil5Plan& p, const double* 
         }
 #undef SPMV_AMD_LAUNCH_DIRECT
         return (int)blocks;
+    }
+
+    if (p.variant == Stencil5Variant::RowPlanes) {
+        const long long tiles = (long long)p.row_blocks * (p.gi_hi - p.gi_lo);
+        const int span = 8 * p.rows_per_task;
+        const dim3 grid((unsigned)((tiles + span - 1) / span * span));
+        const int gfirst = m.row_offset / n;
+        const ResidualOut res = init ? *init : ResidualOut{nullptr, nullptr, nullptr};
+#define SPMV_AMD_LAUNCH_PLANES(MODE, WE)                                                                            \
+    hipLaunchKernelGGL((stencil5_planes_kernel<MODE, WE>), grid, dim3(64), 0, stream, m, x, y, alpha, p.gi_lo, 1, gfirst, \
+                       p.row_blocks, (int)tiles, p.rows_per_task, reverse ? 1 : 0, d_dot_partials, d_skip_flag, res)
+        if (p.we_from_lds) {
+            if (init) SPMV_AMD_LAUNCH_PLANES(2, true);
+            else if (dot) SPMV_AMD_LAUNCH_PLANES(1, true);
+            else SPMV_AMD_LAUNCH_PLANES(0, true);
+        } else {
+            if (init) SPMV_AMD_LAUNCH_PLANES(2, false);
+            else if (dot) SPMV_AMD_LAUNCH_PLANES(1, false);
+            else SPMV_AMD_LAUNCH_PLANES(0, false);
+        }
+#undef SPMV_AMD_LAUNCH_PLANES
+        return (int)tiles;
     }
 
     if (p.variant == Stencil5Variant::RowLds) {
@@ -1226,11 +1389,12 @@ int launch_stencil5_spmv_first_and_last_gridrow(const SlabCsr& m, const Stencil5
                                                 const LaunchShape& shape, hipStream_t stream, const ResidualOut* init) {
     const int n = m.grid_size;
     const int local_gridrows = n > 0 ? m.n_local / n : 0;
-    if (init != nullptr && (head.variant != Stencil5Variant::RowLds || d_dot_partials == nullptr || local_gridrows < 2)) {
+    const bool tiled = head.variant == Stencil5Variant::RowLds || head.variant == Stencil5Variant::RowPlanes;
+    if (init != nullptr && (!tiled || d_dot_partials == nullptr || local_gridrows < 2)) {
         fprintf(stderr, "[spmv] the fused initial residual exists for the row-lds kernel only\n");
         exit(EXIT_FAILURE);
     }
-    if (n <= 0 || local_gridrows < 2 || head.variant != Stencil5Variant::RowLds) {
+    if (n <= 0 || local_gridrows < 2 || !tiled) {
         // two launches over the two row ranges (any variant)
         int used = launch_stencil5_spmv(m, x, y, alpha, 0, n, d_dot_partials, d_skip_flag, Stencil5Variant::Auto, shape, stream);
         used += launch_stencil5_spmv(m, x, y, alpha, m.n_local - n, m.n_local, d_dot_partials ? d_dot_partials + used : nullptr,
@@ -1244,15 +1408,20 @@ int launch_stencil5_spmv_first_and_last_gridrow(const SlabCsr& m, const Stencil5
     const dim3 grid((unsigned)((tiles + span - 1) / span * span));
     const int gfirst = m.row_offset / n;
     const ResidualOut res = init ? *init : ResidualOut{nullptr, nullptr, nullptr};
-    if (init)
-        hipLaunchKernelGGL((stencil5_rowlds_kernel<2>), grid, dim3(64), 0, stream, m, x, y, alpha, 0, local_gridrows - 1,
-                           gfirst, head.row_blocks, tiles, head.rows_per_task, 0, d_dot_partials, d_skip_flag, res);
-    else if (d_dot_partials)
-        hipLaunchKernelGGL((stencil5_rowlds_kernel<1>), grid, dim3(64), 0, stream, m, x, y, alpha, 0, local_gridrows - 1,
-                           gfirst, head.row_blocks, tiles, head.rows_per_task, 0, d_dot_partials, d_skip_flag, res);
-    else
-        hipLaunchKernelGGL((stencil5_rowlds_kernel<0>), grid, dim3(64), 0, stream, m, x, y, alpha, 0, local_gridrows - 1,
-                           gfirst, head.row_blocks, tiles, head.rows_per_task, 0, d_dot_partials, d_skip_flag, res);
+    const int mode = init ? 2 : (d_dot_partials ? 1 : 0);
+#define SPMV_AMD_LAUNCH_EDGES(KERNEL, MODE)                                                                             \
+    hipLaunchKernelGGL((KERNEL<MODE, false>), grid, dim3(64), 0, stream, m, x, y, alpha, 0, local_gridrows - 1, gfirst, \
+                       head.row_blocks, tiles, head.rows_per_task, 0, d_dot_partials, d_skip_flag, res)
+    if (head.variant == Stencil5Variant::RowPlanes) {
+        if (mode == 2) SPMV_AMD_LAUNCH_EDGES(stencil5_planes_kernel, 2);
+        else if (mode == 1) SPMV_AMD_LAUNCH_EDGES(stencil5_planes_kernel, 1);
+        else SPMV_AMD_LAUNCH_EDGES(stencil5_planes_kernel, 0);
+    } else {
+        if (mode == 2) SPMV_AMD_LAUNCH_EDGES(stencil5_rowlds_kernel, 2);
+        else if (mode == 1) SPMV_AMD_LAUNCH_EDGES(stencil5_rowlds_kernel, 1);
+        else SPMV_AMD_LAUNCH_EDGES(stencil5_rowlds_kernel, 0);
+    }
+#undef SPMV_AMD_LAUNCH_EDGES
     return tiles;
 }
 

@@ -168,16 +168,22 @@ def test_reference_entry_point_cg_solve_mgpu_partitioned(B, O, fresh_host_matric
     assert np.array_equal(x2, x) and st2.time_spmv_ms > 0 and st2.time_blas1_ms > 0
 
 
+@pytest.mark.parametrize("planes", ["1", "0"])
 @pytest.mark.parametrize("n,rowlds_min_grid,variant", [(256, None, "stencil5/row-direct"), (640, None, "stencil5/row-lds"),
                                                        (130, "2", "stencil5/row-lds"), (260, "2", "stencil5/row-lds"),
                                                        (64, "2", "stencil5/row-lds")])
-def test_slab_spmv_matches_halo_oracle(B, O, fresh_host_matrices, monkeypatch, n, rowlds_min_grid, variant):
+def test_slab_spmv_matches_halo_oracle(B, O, fresh_host_matrices, monkeypatch, n, rowlds_min_grid, variant, planes):
     """Slab-local SpMV with halos for every rank of a 1/2/4-way split, one rank at a time on this
     GPU (staged communicator with trivial callbacks: spmv() fills the halos from the full vector).
     Random coefficients, so a coefficient taken from the wrong CSR position cannot go unnoticed; the
     row-lds kernel is also forced onto small grids (one or two clamped tiles per grid row)."""
     if rowlds_min_grid is not None:
         monkeypatch.setenv("SPMV_AMD_ROWLDS_MIN_GRID", rowlds_min_grid)
+    # planes = "1": slabs that would run row-lds keep a five-plane copy of the coefficients and run row-planes instead
+    # (a measured, not adopted layout); "0" (default): the CSR-only row-lds path. Both bit-identical to the oracle.
+    monkeypatch.setenv("SPMV_AMD_SLAB_PLANES", planes)
+    if planes == "1" and variant == "stencil5/row-lds":
+        variant = "stencil5/row-planes"
     e = O.stencil5_coo(n)
     rng = np.random.default_rng(1)
     e["value"] = rng.uniform(-3, 3, len(e))
