@@ -9,8 +9,9 @@
 // What is organised differently, for the hardware:
 //  * the direction vector p lives in ONE allocation [prev halo | local rows | next halo], so the
 //    +-grid_size neighbours of the first/last grid row are ordinary addresses and the slab kernel
-//    is the single-GPU wave-tile kernel with a row offset; RCCL receives straight into the halos;
-//  * SpMV is fused with the p.Ap partial sums; r -= a Ap carries the r.r partials; the direction update
+//    is the single-GPU row-lds kernel with a row offset; RCCL receives straight into the halos;
+//  * the first SpMV of a solve writes r0 = b - A x0, p0 and the r0.r0 partials itself; every later SpMV is fused
+//    with the p.Ap partial sums; r -= a Ap carries the r.r partials; the direction update
 //    p' = r + b p is written out of place into a ring of direction buffers and x = x0 + sum a_k p_k is
 //    evaluated by one flush pass per ring length (deferred x update; the in-place form, where x += a p
 //    rides with the direction update, remains for short rings);
@@ -18,10 +19,13 @@
 //  * consecutive streaming kernels sweep the vectors in alternating directions (Infinity-Cache reuse);
 //  * scalars (alpha, beta, the norms, the convergence flag, the iteration counter) stay in HBM;
 //    kernels of iterations enqueued past convergence see the flag and return, so the host reads
-//    one 8-byte record per iteration while the GPU is already busy with the next SpMV;
+//    one 16-byte record per iteration while the GPU is already busy with the next SpMV; the scalar step -- and,
+//    with a peer mailbox (comm.hpp), the all-reduce across the ranks -- runs in the tail of the reduction's
+//    single-block last stage, so a multi-rank iteration issues the launches of a single-rank one;
 //  * the halo exchange of iteration k+1 runs on a side stream under the interior rows' SpMV; the
 //    first and last grid row of the slab are launched once the halo has landed. Each row is
-//    computed by the same code whichever launch it falls in, so overlap cannot change results.
+//    computed by the same code whichever launch it falls in, so overlap cannot change results;
+//  * every wait on another rank is bounded (watchdog.hpp): a wedged peer becomes a report and a non-zero exit.
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
