@@ -37,6 +37,40 @@ def test_spmv_full_size_checksums(B, mode, n):
     op.free()
 
 
+MAX_GRID = 20724  # largest n with 5 n^2 - 4 n = 2 147 337 984 <= 2^31 - 1: the reference's int CSR ends here
+
+
+@pytest.mark.parametrize("mode", ["stencil5-csr", "cusparse-csr", "stencil5-ellpack"])
+def test_largest_grid_32_bit_csr_indices_allow(B, mode):
+    """Maximum size: n = 20 724 (4.29e8 rows, nnz 145 663 short of 2^31). Every byte offset and CSR position must be
+    computed in 64 bits and still land in int32 arrays; y = A*1 has its exact closed-form checksums. One more column
+    (n = 20 725) does not fit and must be refused with an error code, not attempted."""
+    n = MAX_GRID
+    assert 5 * n * n - 4 * n <= 2**31 - 1 < 5 * (n + 1) ** 2 - 4 * (n + 1)
+    op = B.Operator(mode)
+    assert op.init_synthetic(n) == 0
+    y = device_checks(B, op, n)
+    assert y.sum() == n * n + 4 * n
+    counts = np.bincount(y.astype(np.int64), minlength=4)
+    assert list(counts[:4]) == [0, (n - 2) ** 2, 4 * (n - 2), 4]
+    assert y[0] == 3 and y[-1] == 3 and y[n * n - n] == 3 and y[n * n - 2] == 2 and y[n * (n - 1) - 1] == 2
+    op.free()
+    assert op.init_synthetic(n + 1) != 0
+
+
+def test_largest_grid_through_the_slab_solver(B):
+    """The same maximum through the CG slab solver (in-HBM generator, launch plans, reductions over 3.36 M partials):
+    five iterations, residuals strictly decreasing from ||b|| = n, and the generator refuses n + 1."""
+    n = MAX_GRID
+    slab = B.CgSlab.stencil5(n)
+    st = slab.solve(max_iters=5)
+    h = slab.history()
+    assert st.iterations == 5 and h[0] == float(n) and np.all(np.diff(h) < 0)
+    slab.destroy()
+    with pytest.raises(RuntimeError):
+        B.CgSlab.stencil5(n + 1)
+
+
 def test_spmv_full_size_linearity_and_operator_agreement(B):
     """A(a*u + b*v) == a*A(u) + b*A(v) to rounding, and stencil5-csr == cusparse-csr == ellpack on the
     same random x at 10k (the reference's own cross-check, tests/test_wrapper_basic.cpp:159-193)."""
