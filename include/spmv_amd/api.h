@@ -281,7 +281,7 @@ int spmv_amd_comm_transport_ranks(const SpmvAmdComm* comm);
  * cg_solver_mgpu_partitioned.cu:583,645) as direct stores between the GPUs of one node: every rank owns a small
  * mailbox in uncached device memory that all ranks map through hipIpc. spmv_amd_comm_mailbox_enable() does the
  * whole set-up over the communicator's own transport (collective; returns 1 when EVERY rank has a mailbox that
- * passed the self-test, else 0 and the communicator keeps all-reducing through RCCL / the staged callbacks).
+ * passed a self-test of 2048 checked all-reduces, else 0 and the communicator keeps all-reducing through RCCL / the staged callbacks).
  * The three steps are also available one by one for callers that exchange the handles themselves. */
 #define SPMV_AMD_MAILBOX_HANDLE_BYTES 64
 int spmv_amd_comm_mailbox_enable(SpmvAmdComm* comm);
