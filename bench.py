@@ -490,6 +490,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t[0])
     hist = slab.history()
+    if multi:
+        # every rank computes its scalars from the same all-reduced values: the histories must agree bit for bit
+        box = [None] * world
+        dist.all_gather_object(box, [float(v).hex() for v in hist])
+        if any(b != box[0] for b in box):
+            slab.destroy()
+            give_up(f"ranks hold different residual histories after the timed solves: the {allreduce} all-reduce does not "
+                    "deliver the same sums everywhere")
     # template arguments: <kMode = 1 (SpMV + p.Ap partials), kWeLds = W/E neighbours from LDS (the default)>
     rowlds = "stencil5_rowlds_kernel<1, true>" if os.environ.get("SPMV_AMD_ROWLDS_WE_LDS", "1") != "0" else "stencil5_rowlds_kernel<1, false>"
     kernel_symbol = {"stencil5/row-lds": rowlds, "stencil5/row-planes": rowlds.replace("rowlds", "planes"),
@@ -550,7 +558,7 @@ def main():
                            "grid": n, "unknowns": rows, "nnz": nnz, "partition": f"{world} row slab(s)", "transport": transport,
                            "iterations_per_solve": iterations, "converged": bool(st.converged), "final_residual": st.residual_norm,
                            "residual_history": [float(v) for v in hist]},
-                   transport=transport, allreduce=allreduce, rccl_ranks=rccl_ranks, devices=devices, rank_ms_per_step=rank_ms,
+                   transport=transport, allreduce=allreduce, ranks_agree_on_history=True if multi else None, rccl_ranks=rccl_ranks, devices=devices, rank_ms_per_step=rank_ms,
                    launched_by="bench.py (self-launched ranks)" if os.environ.get("SPMV_AMD_BENCH_SELF_LAUNCHED") == "1" else
                    ("external launcher (RANK/WORLD_SIZE in the environment)" if "RANK" in os.environ else "single process"),
                    roofline=roofline)
