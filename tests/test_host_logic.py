@@ -132,6 +132,21 @@ def test_symmetric_reader_matches_reference_symtogen(B, O, name):
     assert m.c.grid_size == (8 if name == "sym_stencil8.mtx" else -1)
 
 
+def test_plain_c_program_binds_the_boundary(B, tmp_path):
+    """include/spmv_amd/api.h is valid C11 and the library links from plain C: the situation of a cgo / JNI / N-API
+    binding. tests/abi/c_caller.c calls the integer helpers, the operator table and the
+    Matrix Market entry points under their reference names; no GPU is needed for those."""
+    import subprocess
+    exe = tmp_path / "c_caller"
+    lib_dir = os.path.dirname(B.LIB_PATH)
+    build = subprocess.run(["gcc", "-std=c11", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                            os.path.join(ROOT, "tests", "abi", "c_caller.c"), "-L", lib_dir, "-lspmv_amd",
+                            f"-Wl,-rpath,{lib_dir}", "-o", str(exe)], capture_output=True, text=True)
+    assert build.returncode == 0, build.stderr
+    run = subprocess.run([str(exe), str(tmp_path / "s3.mtx")], capture_output=True, text=True, timeout=60)
+    assert run.returncode == 0 and "c caller ok" in run.stdout, (run.returncode, run.stdout, run.stderr)
+
+
 def test_only_the_declared_api_leaves_the_library(B):
     """csrc/exports.map: exactly the declared symbols are dynamic exports; no spmv_amd::launch_* or kernel stub leaks."""
     import subprocess
