@@ -13,7 +13,7 @@ configuration of reference docs/PROBLEM_SIZE_SCALING_RESULTS.md:40-47, on N row 
   value     CG iterations per second, whole job = K * iterations / (max over ranks of the time
             of K steps, bracketed by barrier + torch.cuda.synchronize() on both sides).
   scaling   strong: the 400 M-unknown problem is fixed, slabs shrink as N grows.
-  roofline  the dominant kernel of the timed region, the solver's STENCIL5 SpMV (row-planes kernel, fused with the
+  roofline  the dominant kernel of the timed region, the solver's STENCIL5 SpMV (row-lds kernel, fused with the
             p.Ap partials): algorithmic bytes of one launch (8*nnz + 8*cols + 8*rows of the slab,
             SURVEY.md 8d) / its average duration, from HIP events recorded on the solver's stream
             around every in-loop launch of the timed steps. Peak 8 TB/s (MI355X_MICROARCH.md).
@@ -33,6 +33,18 @@ configuration of reference docs/PROBLEM_SIZE_SCALING_RESULTS.md:40-47, on N row 
             (10 000 x 10 000 = 1/4 of the rows): its CG, scaled by rows to the 400 M-unknown problem
             (~10 s), and `spmv` = its STENCIL5 and CSR SpMV (1 warm-up + 3 runs, median) in the reference's
             effective-GB/s formula and in algorithmic GB/s; `all_cores` = the same loops under OpenMP.
+
+  parity_vs_golden  every run, every N: the residual history of the timed solves against the committed CPU-oracle
+            history of the same grid (tests/golden/known_answers.json: 3, 81, 512, 2000, 10000, 20000); above 1e-10
+            relative, or on another iteration count, the run is UNMEASURED (exit 3), whatever it timed.
+  breakdown per rank, from ONE extra solve after the timed region with HIP events at the stage boundaries of every
+            iteration and around every halo exchange (no host syncs, overlap intact): interior SpMV, wait for the halo +
+            boundary rows, p.Ap sum + all-reduce, r update, r.r sum + all-reduce + scalar step, direction update, gap
+            before the next iteration; max / min over the ranks as the reference reports its timers (mgpu :748-800).
+  allreduce_ab  (N > 1) `value` is north_star's path: RCCL send/recv halos + ncclAllReduce on the two dot products.
+            The same K steps are then repeated with the peer-mailbox all-reduce (csrc/mailbox.hip) in CHILD processes,
+            one per rank, after the headline leg's slabs are freed: {"rccl": ms, "mailbox": ms | null, "other_leg": {...}}.
+            SPMV_AMD_BENCH_ALLREDUCE=mailbox swaps the two legs; --no-allreduce-ab skips the second.
 
 Multi-GPU: one process per GPU. Either the driver starts the ranks (`python -m torch.distributed.run
 --nproc-per-node N bench.py --gpus N ...`, RANK / WORLD_SIZE in the environment) or `python bench.py --gpus N`
@@ -67,6 +79,9 @@ A100_CG_ITERS_PER_S = {1: 14 / 0.5314, 2: 14 / 0.2693, 4: 14 / 0.1363, 8: 14 / 0
 A100_SPMV_EFFECTIVE_GBS_PUBLISHED_FORMULA = 2364.16
 HBM_PEAK_GBS = 8000.0
 EXIT_UNMEASURED = 3
+PARITY_TOL = 1e-10  # north_star: fp64 CG residuals within 1e-10 relative of the CPU path
+# SPMV_AMD_BENCH_GOLDEN (test hook): another fixture file, to show that the parity gate closes
+GOLDEN_ANSWERS = os.environ.get("SPMV_AMD_BENCH_GOLDEN") or os.path.join(ROOT, "tests", "golden", "known_answers.json")
 KERNEL_SOURCE = os.path.join(ROOT, "cuda-spmv-benchmark_amd", "csrc", "spmv_kernels.hip")
 
 
@@ -274,17 +289,22 @@ def self_launch(args):
     """`python bench.py --gpus N` with no RANK / WORLD_SIZE around: start the N ranks ourselves. Nothing in this
     process imports torch or touches the GPU (a process that has initialised the GPU must not be replaced by or
     turned into a launcher on this pool); the ranks are ordinary children, never an exec."""
+    import tempfile
+
     n = args.gpus
     port = free_port()
     argv = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
     procs = []
+    # rank 0's stdout goes to a file, not a pipe: a pipe nobody reads until the ranks have exited would block rank 0 in
+    # write() as soon as its line outgrows the pipe buffer (64 KiB: a long residual history would do)
+    out0_file = tempfile.TemporaryFile()
     for rank in range(n):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SPMV_AMD_BENCH_SELF_LAUNCHED="1")
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL's intra-node transport needs it on this host driver
         env.setdefault("OMP_NUM_THREADS", "4")
         # rank 0's stdout carries the JSON line; the other ranks have nothing to say there
-        procs.append(subprocess.Popen(argv, env=env, stdout=subprocess.PIPE if rank == 0 else sys.stderr.fileno()))
+        procs.append(subprocess.Popen(argv, env=env, stdout=out0_file if rank == 0 else sys.stderr.fileno()))
     deadline = time.monotonic() + args.launch_timeout
     failed_at = None
     while any(p.poll() is None for p in procs):
@@ -297,8 +317,10 @@ def self_launch(args):
                 if p.poll() is None:
                     p.kill()  # exactly the children started above
             break
-    out0 = procs[0].stdout.read().decode(errors="replace") if procs[0].stdout else ""
     codes = [p.wait() for p in procs]
+    out0_file.seek(0)
+    out0 = out0_file.read().decode(errors="replace")
+    out0_file.close()
     lines = [l for l in out0.splitlines() if l.startswith("{")]
     worst = max(codes, key=abs) if codes else 1
     if lines:
@@ -313,6 +335,236 @@ def self_launch(args):
     return worst
 
 
+def parity_vs_golden(n, hist, iterations):
+    """The residual history of the timed solves against the committed oracle fixture (tests/golden/known_answers.json, written
+    by tests/golden/make_golden.py from oracle/spmv_oracle.c on a CPU: data, not code). north_star's bar: 1e-10 relative on
+    every ||r_k||, and the reference's "14 iterations on every GPU count" (docs/scaling_summary.md:17)."""
+    try:
+        case = json.load(open(GOLDEN_ANSWERS))["cases"].get(f"{n}:5.0")
+    except (OSError, ValueError) as e:
+        return {"available": False, "note": f"golden fixture unreadable: {e!r}"}
+    if case is None:
+        return {"available": False, "note": f"no committed golden history for grid {n} (fixtures exist for 3, 81, 512, 2000, 10000, 20000)"}
+    g = np.asarray(case["cg"]["history"], dtype=np.float64)
+    h = np.asarray(hist, dtype=np.float64)
+    k = min(len(g), len(h))
+    err = float(np.max(np.abs(h[:k] - g[:k]) / np.abs(g[:k]))) if k else float("inf")
+    ok = bool(len(h) == len(g) and iterations == case["cg"]["iterations"] and err <= PARITY_TOL)
+    return {"available": True, "max_rel_err": err, "iterations": int(iterations), "golden_iterations": int(case["cg"]["iterations"]),
+            "entries_compared": int(k), "tolerance": PARITY_TOL, "ok": ok,
+            "fixture": f"tests/golden/known_answers.json cases[{n}:5.0].cg.history (CPU oracle)"}
+
+
+class Unmeasured(Exception):
+    """A leg cannot produce a number every rank stands behind; the reason is the same text on all ranks."""
+
+
+class Ctx:
+    """What every leg of this process shares: rank, the gloo group, the binding, the device."""
+
+
+def setup_process(args):
+    """Rendezvous (gloo), library, device. Returns a Ctx; calls nothing that needs another rank's data path."""
+    c = Ctx()
+    c.args = args
+    c.rank = int(os.environ.get("RANK", "0"))
+    c.world = int(os.environ.get("WORLD_SIZE", "1"))
+    if os.environ.get("SPMV_AMD_BENCH_TEST_CRASH_RANK") == str(c.rank):  # test hook: a rank that dies before the rendezvous
+        print(f"bench.py: rank {c.rank} exiting with status 7 on request (SPMV_AMD_BENCH_TEST_CRASH_RANK)", file=sys.stderr)
+        os._exit(7)
+    c.local_rank = int(os.environ.get("LOCAL_RANK", str(c.rank)))
+    if c.world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={c.world}: running {c.world} rank(s)", file=sys.stderr)
+        args.gpus = c.world
+
+    import datetime
+
+    import torch  # first: libspmv_amd then shares the HIP runtime torch has loaded
+    import torch.distributed as dist
+
+    c.torch, c.dist = torch, dist
+    c.B = B = load_binding()
+    if not os.path.exists(B.LIB_PATH):
+        if c.rank == 0:
+            B.build()
+    # SPMV_AMD_BENCH_FORCE_DIST=1 (test hook): take the distributed path with one rank too, i.e.
+    # rendezvous, unique-id broadcast and an RCCL communicator, so a 1-GPU box exercises it.
+    c.multi = c.world > 1 or os.environ.get("SPMV_AMD_BENCH_FORCE_DIST") == "1"
+    if c.multi:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=c.rank, world_size=c.world, timeout=datetime.timedelta(seconds=600))
+        dist.barrier()
+    c.L = B.lib()
+    return c
+
+
+def agree(c, ok, reason):
+    """All ranks learn whether every rank is fine; returns the failing ranks' reasons, or None."""
+    if not c.multi:
+        return None if ok else reason
+    box = [None] * c.world
+    c.dist.all_gather_object(box, None if ok else f"rank {c.rank}: {reason}")
+    bad = [b for b in box if b is not None]
+    return "; ".join(bad) if bad else None
+
+
+def gather(c, value):
+    if not c.multi:
+        return [value]
+    box = [None] * c.world
+    c.dist.all_gather_object(box, value)
+    return box
+
+
+def pick_device(c):
+    # SPMV_AMD_BENCH_DEVICE (test hook): put every rank on one device, so a 1-GPU box can walk the N > 1 control flow
+    forced = os.environ.get("SPMV_AMD_BENCH_DEVICE")
+    device = int(forced) if forced is not None else c.local_rank
+    visible = c.L.spmv_amd_device_count()
+    why = agree(c, visible > device, f"device {device} wanted, {visible} HIP device(s) visible")
+    if why:
+        raise Unmeasured(why)
+    c.torch.cuda.set_device(device)
+    c.L.spmv_amd_set_device(device)
+    c.device_index, c.pci = c.B.current_device()
+
+
+def measure_leg(c, allreduce_kind):
+    """One complete measurement with one all-reduce path: communicator, slab, warm-ups, K timed solves between barriers,
+    agreement of the ranks' histories, parity against the golden history, one extra solve with the stage timeline.
+    allreduce_kind: "rccl" (north_star: ncclAllReduce) or "mailbox" (peer stores, csrc/mailbox.hip). Raises Unmeasured."""
+    args, B, dist, torch, rank, world, multi = c.args, c.B, c.dist, c.torch, c.rank, c.world, c.multi
+    n = args.grid
+    allow_staged = os.environ.get("SPMV_AMD_BENCH_ALLOW_STAGED") == "1"
+    comm, transport, degraded = None, "single rank (no communicator)", None
+    if multi:
+        box = [B.Comm.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        comm = B.Comm.rccl(rank, world, box[0])
+        # every rank must have its RCCL communicators, see all `world` ranks in them and pass the collective
+        # self-test (all-reduce, neighbour send/recv, loopback on a side stream, barrier)
+        why = agree(c, comm is not None, "RCCL communicator creation failed (see the [comm/rccl] line on stderr)")
+        if why is None:
+            got = comm.transport_ranks()
+            why = agree(c, got == world, f"RCCL communicators span {got} rank(s), {world} wanted")
+        if why is None:
+            why = agree(c, comm.selftest() == 0, "RCCL self-test (all-reduce / neighbour send-recv / barrier) returned wrong data")
+        if why is None:
+            transport = "rccl"
+        elif allow_staged:
+            if comm is not None:
+                comm.destroy()
+            comm = B.Comm.staged_over_torch(rank, world, dist)
+            transport = "staged over torch.distributed/gloo"
+            degraded = f"host-staged transport instead of RCCL (SPMV_AMD_BENCH_ALLOW_STAGED=1): {why}"
+            if rank == 0:
+                print(f"bench.py: {degraded}", file=sys.stderr)
+        else:
+            raise Unmeasured(f"RCCL unusable, and the host-staged transport is not a substitute for the headline number: {why}")
+    # The two 8-byte all-reduces per iteration. Default and headline: the transport's own, ncclAllReduce on the device scalars
+    # (north_star). "mailbox": stores between the GPUs' hipIpc-mapped memory inside the reduction kernel -- set up
+    # all-or-nothing behind a 2048-round self-test; the line says which one ran.
+    allreduce = "none (single rank)"
+    if comm is not None:
+        allreduce = "ncclAllReduce" if transport == "rccl" else "host callbacks (staged)"
+        if allreduce_kind == "mailbox":
+            if not comm.mailbox_enable():
+                comm.destroy()
+                raise Unmeasured("the peer mailbox could not be set up on every rank, or failed its self-test (see the [mailbox] lines on stderr)")
+            allreduce = "peer mailbox (system-scope stores into hipIpc-mapped device memory)"
+        if rank == 0:
+            print(f"bench.py: dot-product all-reduce: {allreduce}", file=sys.stderr)
+    slab = B.CgSlab.stencil5(n, comm)
+
+    def barrier():
+        if multi:
+            dist.barrier()
+
+    try:
+        for _ in range(args.warmup):
+            st = slab.solve()
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        spmv_ms, spmv_launches = 0.0, 0
+        for _ in range(args.steps):
+            st = slab.solve()
+            spmv_ms += st.time_spmv_ms
+            spmv_launches += st.iterations
+        torch.cuda.synchronize()
+        barrier()
+        dt = time.perf_counter() - t0
+        rank_ms = [float(v) for v in gather(c, dt / args.steps * 1e3)]  # every rank's own wall time per step: the spread is load imbalance
+        if multi:
+            t = torch.tensor([dt], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t[0])
+        hist = slab.history()
+        # every rank computes its scalars from the same all-reduced values: the histories must agree bit for bit
+        hexes = gather(c, [float(v).hex() for v in hist])
+        if any(h != hexes[0] for h in hexes):
+            raise Unmeasured(f"ranks hold different residual histories after the timed solves: the {allreduce} all-reduce does not "
+                             "deliver the same sums everywhere")
+        parity = parity_vs_golden(n, hist, st.iterations)
+        if parity["available"] and not parity["ok"]:
+            raise Unmeasured(f"residual history of the timed solves differs from the committed golden history: max relative error "
+                             f"{parity['max_rel_err']:.3e} (bar {PARITY_TOL:g}), {parity['iterations']} iterations against {parity['golden_iterations']}")
+        # one more solve with stage-boundary events (outside the timed region): where an iteration's time goes on this rank
+        st_t, tl = slab.timeline_solve()
+        breakdown = gather(c, dict(tl, rank=rank, rows=slab.n_local, timeline_solve_ms=st_t.time_total_ms))
+        leg = {"allreduce": allreduce, "allreduce_kind": allreduce_kind if comm is not None else "none", "transport": transport, "degraded": degraded,
+               "dt": dt, "ms_per_step": dt / args.steps * 1e3, "iterations": st.iterations, "converged": bool(st.converged),
+               "final_residual": st.residual_norm, "history": [float(v) for v in hist], "rank_ms": rank_ms, "parity_vs_golden": parity,
+               "ranks_agree_on_history": True if multi else None, "breakdown": breakdown, "variant": slab.variant(),
+               "local_rows": slab.n_local, "local_nnz": slab.local_nnz, "spmv_ms": spmv_ms, "spmv_launches": spmv_launches,
+               "rccl_ranks": comm.transport_ranks() if (comm is not None and transport == "rccl") else 0}
+    finally:
+        slab.destroy()
+        if comm is not None:
+            comm.destroy()
+    return leg
+
+
+def breakdown_summary(per_rank):
+    """max / min over the ranks of every stage (the reference reduces its six timers with MPI_MAX / MPI_MIN,
+    cg_solver_mgpu_partitioned.cu:748-800), next to the per-rank records."""
+    keys = [k for k in per_rank[0] if k not in ("rank", "rows", "iterations")]
+    return {"unit": "us per iteration, average over the counted iterations of ONE extra solve with stage-boundary HIP events (no host "
+                    "syncs, outside the timed region); solve_ms / timeline_solve_ms in ms; a stage runs from the end of the previous "
+                    "stage to the end of its own last kernel, so waiting is inside the stage that waits",
+            "max_over_ranks": {k: max(r[k] for r in per_rank) for k in keys}, "min_over_ranks": {k: min(r[k] for r in per_rank) for k in keys},
+            "per_rank": per_rank}
+
+
+def other_allreduce_leg(c, kind, timeout_s):
+    """The same K steps with the OTHER all-reduce path, in child processes (one per rank, fresh rendezvous on a new port):
+    whatever happens there -- a failed set-up, a watchdog exit, a GPU fault in an unproven path -- the headline measured
+    above is still printed. Returns rank 0's record of the child leg (or the reason there is none)."""
+    port = [free_port() if c.rank == 0 else None]
+    if c.multi:
+        c.dist.broadcast_object_list(port, src=0)
+    env = dict(os.environ, RANK=str(c.rank), LOCAL_RANK=str(c.local_rank), WORLD_SIZE=str(c.world), MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(port[0]))
+    env.pop("SPMV_AMD_BENCH_TEST_CRASH_RANK", None)
+    argv = [sys.executable, os.path.abspath(__file__), "--gpus", str(c.world), "--steps", str(c.args.steps), "--warmup", str(c.args.warmup),
+            "--grid", str(c.args.grid), "--leg-only", kind]
+    rec = None
+    try:
+        child = subprocess.run(argv, env=env, capture_output=True, text=True, timeout=timeout_s)
+        lines = [l for l in child.stdout.splitlines() if l.startswith("{")]
+        if lines:
+            rec = json.loads(lines[-1])
+        if rec is None or child.returncode != 0:
+            rec = dict(rec or {}, error=(rec or {}).get("error") or f"child leg exited with {child.returncode}", stderr_tail=child.stderr[-600:])
+    except subprocess.TimeoutExpired:
+        rec = {"error": f"child leg did not finish within {timeout_s:.0f} s"}
+    except Exception as e:  # evidence only
+        rec = {"error": repr(e)}
+    if c.multi:
+        c.dist.barrier()
+    return rec
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -324,11 +576,14 @@ def main():
     ap.add_argument("--no-spmv", action="store_true", help="skip the N=1 SpMV headline leg")
     ap.add_argument("--no-scaling-probe", action="store_true", help="skip the N=1 one-GPU strong-scaling probe")
     ap.add_argument("--no-ceiling", action="store_true", help="skip the in-run stream-ceiling probe")
+    ap.add_argument("--no-allreduce-ab", action="store_true", help="multi-rank runs: skip the second leg with the other all-reduce path")
     ap.add_argument("--launch-timeout", type=float, default=1500.0, help="self-launch only: seconds before the parent ends the ranks")
     ap.add_argument("--launch-grace", type=float, default=90.0,
                     help="self-launch only: seconds the other ranks get to report after one rank has exited non-zero")
     ap.add_argument("--scaling-probe-only", nargs=2, metavar=("FULL_MS", "FULL_ITERATIONS"), default=None,
                     help="(internal) run only the scaling probe and print its JSON object")
+    ap.add_argument("--leg-only", choices=["rccl", "mailbox"], default=None,
+                    help="(internal) run one measurement leg with that all-reduce path and print its record")
     args = ap.parse_args()
 
     if args.scaling_probe_only is None and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -354,161 +609,71 @@ def main():
         emit(scaling_probe(B, torch, args.grid, float(args.scaling_probe_only[0]), int(args.scaling_probe_only[1])))
         return
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if os.environ.get("SPMV_AMD_BENCH_TEST_CRASH_RANK") == str(rank):  # test hook: a rank that dies before the rendezvous
-        print(f"bench.py: rank {rank} exiting with status 7 on request (SPMV_AMD_BENCH_TEST_CRASH_RANK)", file=sys.stderr)
-        os._exit(7)
-    local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
-    if world != args.gpus:
-        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: running {world} rank(s)", file=sys.stderr)
-        args.gpus = world
-
-    import datetime
-
-    import torch  # first: libspmv_amd then shares the HIP runtime torch has loaded
-    import torch.distributed as dist
-
-    B = load_binding()
-    if not os.path.exists(B.LIB_PATH):
-        if rank == 0:
-            B.build()
-    # SPMV_AMD_BENCH_FORCE_DIST=1 (test hook): take the distributed path with one rank too, i.e.
-    # rendezvous, unique-id broadcast and an RCCL communicator, so a 1-GPU box exercises it.
-    multi = world > 1 or os.environ.get("SPMV_AMD_BENCH_FORCE_DIST") == "1"
-    if multi:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=600))
-        dist.barrier()
-    L = B.lib()
-
+    c = setup_process(args)
+    rank, world, multi, B, dist = c.rank, c.world, c.multi, c.B, c.dist
     n = args.grid
     rows, nnz = n * n, 5 * n * n - 4 * n
     base = {"metric": "cg_iterations_per_second", "unit": "CG iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "higher_is_better": True, "scaling": "strong", "dtype": "f64", "data": "synthetic"}
 
-    def agree(ok, reason):
-        """All ranks learn whether every rank is fine; returns the first failing rank's reason, or None."""
-        if not multi:
-            return None if ok else reason
-        box = [None] * world
-        dist.all_gather_object(box, None if ok else f"rank {rank}: {reason}")
-        bad = [b for b in box if b is not None]
-        return "; ".join(bad) if bad else None
-
-    def give_up(reason):
-        """No measurement: say so on the one line the driver reads and leave with a non-zero status."""
-        if rank == 0:
-            print(f"bench.py: UNMEASURED -- {reason}", file=sys.stderr)
-            emit(dict(base, value=None, ms_per_step=None, vs_baseline=None, unmeasured=reason,
-                      config={"workload": f"CG on the {n}x{n} 5-point stencil, b=1, x0=0, tol 1e-6", "grid": n, "partition": f"{world} row slab(s)"}))
+    def leave(status):
         if multi:
             try:
                 dist.barrier()
                 dist.destroy_process_group()
             except Exception:
                 pass
-        sys.exit(EXIT_UNMEASURED)
+        sys.exit(status)
 
-    # SPMV_AMD_BENCH_DEVICE (test hook): put every rank on one device, so a 1-GPU box can walk the N > 1 control flow
-    forced_device = os.environ.get("SPMV_AMD_BENCH_DEVICE")
-    device = int(forced_device) if forced_device is not None else local_rank
-    visible = L.spmv_amd_device_count()
-    why = agree(visible > device, f"device {device} wanted, {visible} HIP device(s) visible")
-    if why:
-        give_up(why)
-    torch.cuda.set_device(device)
-    L.spmv_amd_set_device(device)
-    dev_index, pci = B.current_device()
+    def give_up(reason):
+        """No measurement: say so on the one line the driver reads and leave with a non-zero status."""
+        if rank == 0:
+            print(f"bench.py: UNMEASURED -- {reason}", file=sys.stderr)
+            if args.leg_only:
+                emit({"error": reason})
+            else:
+                emit(dict(base, value=None, ms_per_step=None, vs_baseline=None, unmeasured=reason,
+                          config={"workload": f"CG on the {n}x{n} 5-point stencil, b=1, x0=0, tol 1e-6", "grid": n, "partition": f"{world} row slab(s)"}))
+        leave(EXIT_UNMEASURED)
 
-    def barrier():
-        if multi:
-            dist.barrier()
+    try:
+        pick_device(c)
+    except Unmeasured as e:
+        give_up(str(e))
+
+    if args.leg_only:  # child of other_allreduce_leg(): one leg, one record, nothing else
+        try:
+            leg = measure_leg(c, args.leg_only)
+        except Unmeasured as e:
+            give_up(str(e))
+        if rank == 0:
+            emit({k: leg[k] for k in ("allreduce", "ms_per_step", "iterations", "rank_ms", "parity_vs_golden", "ranks_agree_on_history", "rccl_ranks")}
+                 | {"breakdown": breakdown_summary(leg["breakdown"])})
+        leave(0)
 
     spmv = None
     if world == 1 and not args.no_spmv:
         spmv = spmv_headline(B, n)
 
-    allow_staged = os.environ.get("SPMV_AMD_BENCH_ALLOW_STAGED") == "1"
-    comm, transport, degraded = None, "single rank (no communicator)", None
-    if multi:
-        box = [B.Comm.unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(box, src=0)
-        comm = B.Comm.rccl(rank, world, box[0])
-        # every rank must have its RCCL communicators, see all `world` ranks in them and pass the collective
-        # self-test (all-reduce, neighbour send/recv, loopback on a side stream, barrier)
-        why = agree(comm is not None, "RCCL communicator creation failed (see the [comm/rccl] line on stderr)")
-        if why is None:
-            got = comm.transport_ranks()
-            why = agree(got == world, f"RCCL communicators span {got} rank(s), {world} wanted")
-        if why is None:
-            why = agree(comm.selftest() == 0, "RCCL self-test (all-reduce / neighbour send-recv / barrier) returned wrong data")
-        if why is None:
-            transport = "rccl"
-        elif allow_staged:
-            if comm is not None:
-                comm.destroy()
-            comm = B.Comm.staged_over_torch(rank, world, dist)
-            transport = "staged over torch.distributed/gloo"
-            degraded = f"host-staged transport instead of RCCL (SPMV_AMD_BENCH_ALLOW_STAGED=1): {why}"
-            if rank == 0:
-                print(f"bench.py: {degraded}", file=sys.stderr)
-        else:
-            give_up(f"RCCL unusable, and the host-staged transport is not a substitute for the headline number: {why}")
-    # The two 8-byte all-reduces per iteration: peer mailbox (stores between the GPUs' hipIpc-mapped memory, one small
-    # launch each) when every rank's mailbox passes its self-test, else the transport's own (ncclAllReduce). Both are
-    # device-side paths over xGMI; the line says which one ran. SPMV_AMD_BENCH_ALLREDUCE=rccl keeps the mailbox off.
-    allreduce = "none (single rank)"
-    if comm is not None:
-        allreduce = "ncclAllReduce" if transport == "rccl" else "host callbacks (staged)"
-        if os.environ.get("SPMV_AMD_BENCH_ALLREDUCE", "auto") != "rccl" and comm.mailbox_enable():
-            allreduce = "peer mailbox (system-scope stores into hipIpc-mapped device memory)"
-        if rank == 0:
-            print(f"bench.py: dot-product all-reduce: {allreduce}", file=sys.stderr)
-    slab = B.CgSlab.stencil5(n, comm)
+    # headline leg: north_star's path (RCCL send/recv halos + ncclAllReduce); SPMV_AMD_BENCH_ALLREDUCE=mailbox swaps the legs
+    headline_kind = "mailbox" if os.environ.get("SPMV_AMD_BENCH_ALLREDUCE", "rccl") == "mailbox" else "rccl"
+    try:
+        leg = measure_leg(c, headline_kind)
+    except Unmeasured as e:
+        give_up(str(e))
+    transport, allreduce, degraded, dt, iterations = leg["transport"], leg["allreduce"], leg["degraded"], leg["dt"], leg["iterations"]
 
-    for _ in range(args.warmup):
-        st = slab.solve()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    spmv_ms, spmv_launches = 0.0, 0
-    for _ in range(args.steps):
-        st = slab.solve()
-        spmv_ms += st.time_spmv_ms
-        spmv_launches += st.iterations
-    torch.cuda.synchronize()
-    barrier()
-    dt = time.perf_counter() - t0
-    iterations = st.iterations
-    rank_ms = [dt / args.steps * 1e3]
-    if multi:
-        box = [None] * world
-        dist.all_gather_object(box, rank_ms[0])
-        rank_ms = [float(v) for v in box]  # every rank's own wall time per step: the spread shows load imbalance
-        t = torch.tensor([dt], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t[0])
-    hist = slab.history()
-    if multi:
-        # every rank computes its scalars from the same all-reduced values: the histories must agree bit for bit
-        box = [None] * world
-        dist.all_gather_object(box, [float(v).hex() for v in hist])
-        if any(b != box[0] for b in box):
-            slab.destroy()
-            give_up(f"ranks hold different residual histories after the timed solves: the {allreduce} all-reduce does not "
-                    "deliver the same sums everywhere")
     # template arguments: <kMode = 1 (SpMV + p.Ap partials), kWeLds = W/E neighbours from LDS (the default)>
     rowlds = "stencil5_rowlds_kernel<1, true>" if os.environ.get("SPMV_AMD_ROWLDS_WE_LDS", "1") != "0" else "stencil5_rowlds_kernel<1, false>"
     kernel_symbol = {"stencil5/row-lds": rowlds, "stencil5/row-planes": rowlds.replace("rowlds", "planes"),
-                     "stencil5/row-direct": "stencil5_rowdirect_kernel<1, true>"}.get(slab.variant(), slab.variant())
+                     "stencil5/row-direct": "stencil5_rowdirect_kernel<1, true>"}.get(leg["variant"], leg["variant"])
 
     # dominant kernel: STENCIL5 SpMV of this rank's slab, average over the launches of the timed steps
-    local_rows, local_nnz = slab.n_local, slab.local_nnz if slab.local_nnz > 0 else None
+    local_rows, local_nnz = leg["local_rows"], leg["local_nnz"] if leg["local_nnz"] > 0 else None
     if local_nnz is None:  # nnz of the slab does not fit the int the info call returns (single rank, 20k)
         local_nnz = nnz // world
     alg_bytes = 8 * local_nnz + 8 * local_rows + 8 * local_rows
-    avg_spmv_ms = spmv_ms / max(spmv_launches, 1)
+    avg_spmv_ms = leg["spmv_ms"] / max(leg["spmv_launches"], 1)
     achieved = alg_bytes / (avg_spmv_ms / 1e3) / 1e9 if avg_spmv_ms > 0 else 0.0
     # fabric bytes per launch from the committed PMC passes -- only if they were taken on THIS kernel source
     traffic, traffic_note = None, None
@@ -529,7 +694,7 @@ def main():
     roofline = {
         "bound": "hbm", "kernel": kernel_symbol + " (SpMV + p.Ap partials)", "achieved": achieved, "peak": HBM_PEAK_GBS,
         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
-        "avg_launch_ms": avg_spmv_ms, "launches_timed": spmv_launches, "traffic_note": traffic_note,
+        "avg_launch_ms": avg_spmv_ms, "launches_timed": leg["spmv_launches"], "traffic_note": traffic_note,
     }
     if rank == 0 and not args.no_ceiling and local_rows >= 1_000_000:
         try:
@@ -540,12 +705,18 @@ def main():
         except Exception as e:
             roofline["ceiling_probe"] = {"error": repr(e)}
 
-    devices = [{"rank": rank, "device": dev_index, "pci_bus_id": pci}]
-    if multi:
-        box = [None] * world
-        dist.all_gather_object(box, devices[0])
-        devices = box
-    rccl_ranks = comm.transport_ranks() if (comm is not None and transport == "rccl") else 0
+    devices = gather(c, {"rank": rank, "device": c.device_index, "pci_bus_id": c.pci})
+
+    # second leg, multi-rank runs only: the same K steps with the other all-reduce path, in child processes
+    allreduce_ab = None
+    if multi and not args.no_allreduce_ab and transport == "rccl":
+        other = "mailbox" if headline_kind == "rccl" else "rccl"
+        child = other_allreduce_leg(c, other, timeout_s=max(300.0, 20.0 * (args.steps + args.warmup)))
+        allreduce_ab = {headline_kind: leg["ms_per_step"], other: child.get("ms_per_step"), "headline": headline_kind,
+                        "unit": "ms per step (one CG solve), max over ranks, same K steps after the same warm-ups",
+                        "other_leg": child,
+                        "note": "the other leg runs in child processes after the headline leg has been measured and its slabs freed: "
+                                "its failure cannot touch `value`"}
 
     out = None
     if rank == 0:
@@ -556,19 +727,19 @@ def main():
                    baseline_note="reference's published CG iters/s on the same problem at the same GPU count, A100-SXM4-80GB (BASELINE.md); no MI355X number is published",
                    config={"workload": f"CG on the {n}x{n} 5-point stencil ({rows} unknowns, {nnz} nnz), b=1, x0=0, tol 1e-6",
                            "grid": n, "unknowns": rows, "nnz": nnz, "partition": f"{world} row slab(s)", "transport": transport,
-                           "iterations_per_solve": iterations, "converged": bool(st.converged), "final_residual": st.residual_norm,
-                           "residual_history": [float(v) for v in hist]},
-                   transport=transport, allreduce=allreduce, ranks_agree_on_history=True if multi else None, rccl_ranks=rccl_ranks, devices=devices, rank_ms_per_step=rank_ms,
+                           "iterations_per_solve": iterations, "converged": leg["converged"], "final_residual": leg["final_residual"],
+                           "residual_history": leg["history"]},
+                   transport=transport, allreduce=allreduce, ranks_agree_on_history=leg["ranks_agree_on_history"], parity_vs_golden=leg["parity_vs_golden"],
+                   rccl_ranks=leg["rccl_ranks"], devices=devices, rank_ms_per_step=leg["rank_ms"], breakdown=breakdown_summary(leg["breakdown"]),
                    launched_by="bench.py (self-launched ranks)" if os.environ.get("SPMV_AMD_BENCH_SELF_LAUNCHED") == "1" else
                    ("external launcher (RANK/WORLD_SIZE in the environment)" if "RANK" in os.environ else "single process"),
                    roofline=roofline)
+        if allreduce_ab is not None:
+            out["allreduce_ab"] = allreduce_ab
         if degraded:
             out["degraded"] = degraded
         if spmv is not None:
             out["spmv"] = spmv
-    slab.destroy()
-    if comm is not None:
-        comm.destroy()
 
     if rank == 0 and world == 1 and not multi and not args.no_scaling_probe and n >= 8192:
         # evidence only, in a child process: whatever happens to it, the benchmark line above is printed
@@ -584,9 +755,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline(args.cpu_sample_grid, rows)
     if rank == 0:
         emit(out)
-    if multi:
-        dist.barrier()
-        dist.destroy_process_group()
+    leave(0)
 
 
 if __name__ == "__main__":

@@ -93,7 +93,7 @@ DECLARED_SYMBOLS = [
     "spmv_amd_comm_mailbox_disable", "spmv_amd_comm_mailbox_ready",
     "spmv_amd_cg_slab_create", "spmv_amd_cg_slab_create_stencil5", "spmv_amd_cg_slab_create_stencil5_as", "spmv_amd_cg_slab_set_vectors", "spmv_amd_cg_slab_solve",
     "spmv_amd_cg_slab_gather", "spmv_amd_cg_slab_history", "spmv_amd_cg_slab_spmv", "spmv_amd_cg_slab_info",
-    "spmv_amd_cg_slab_time_spmv", "spmv_amd_cg_slab_variant", "spmv_amd_cg_slab_destroy", "spmv_amd_version", "spmv_amd_write_stencil5_values",
+    "spmv_amd_cg_slab_time_spmv", "spmv_amd_cg_slab_set_timeline", "spmv_amd_cg_slab_timeline_names", "spmv_amd_cg_slab_timeline", "spmv_amd_cg_slab_variant", "spmv_amd_cg_slab_destroy", "spmv_amd_version", "spmv_amd_write_stencil5_values",
     "spmv_amd_blas1_axpy", "spmv_amd_blas1_axpby", "spmv_amd_blas1_axpy_dev", "spmv_amd_blas1_update_p_dev", "spmv_amd_blas1_dot",
     "spmv_amd_cg_fused_step",
 ]
@@ -193,6 +193,10 @@ def lib():
     L.spmv_amd_cg_slab_info.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.spmv_amd_cg_slab_time_spmv.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float)]
     L.spmv_amd_cg_slab_destroy.argtypes = [C.c_void_p]
+    L.spmv_amd_cg_slab_set_timeline.argtypes = [C.c_void_p, C.c_int]
+    L.spmv_amd_cg_slab_set_timeline.restype = None
+    L.spmv_amd_cg_slab_timeline_names.restype = C.c_char_p
+    L.spmv_amd_cg_slab_timeline.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     L.spmv_amd_cg_slab_variant.restype = C.c_char_p
     L.spmv_amd_cg_slab_variant.argtypes = [C.c_void_p]
     L.load_matrix_market.argtypes = [C.c_char_p, C.POINTER(MatrixData)]
@@ -587,6 +591,18 @@ class CgSlab:
 
     def variant(self):
         return lib().spmv_amd_cg_slab_variant(self.h).decode()
+
+    def timeline_solve(self, max_iters=1000, tol=1e-6):
+        """One solve with stage-boundary events (no host syncs); returns (stats, {name: value})."""
+        lib().spmv_amd_cg_slab_set_timeline(self.h, 1)
+        try:
+            st = self.solve(max_iters=max_iters, tol=tol)
+        finally:
+            lib().spmv_amd_cg_slab_set_timeline(self.h, 0)
+        names = lib().spmv_amd_cg_slab_timeline_names().decode().split(",")
+        v = np.zeros(len(names), dtype=np.float64)
+        count = lib().spmv_amd_cg_slab_timeline(self.h, v.ctypes.data, len(v))
+        return st, ({k: float(x) for k, x in zip(names, v)} if count == len(names) else {})
 
     def time_spmv(self, reps):
         ms = (C.c_float * reps)()

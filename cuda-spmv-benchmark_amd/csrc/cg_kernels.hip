@@ -237,63 +237,6 @@ __global__ __launch_bounds__(kBlock) void reduce_partials_kernel(const double* _
     }
 }
 
-// Both stages of the wide reduction in ONE launch: block b sums its slice exactly as
-// reduce_slices_kernel does and publishes stage[b]; the block that draws the last ticket then sums
-// the stage values exactly as reduce_partials_kernel does (thread-strided, 256-wide tree), so the
-// result is bit-identical to the two-launch form and independent of which block finishes last.
-// Cross-XCD visibility: stage values and the ticket counter are agent-scope atomics (the L2s of the
-// eight XCDs are not coherent for plain accesses); the acq_rel ticket orders a block's stage store
-// before its ticket and the last block's stage loads after the final ticket.
-// step_scalars != nullptr (single-rank solves: no all-reduce between the sum and the step): the
-// last block also runs the CG scalar step on the freshly written sum.
-__global__ __launch_bounds__(kBlock) void reduce_fused_kernel(const double* __restrict__ partials, int count,
-                                                              int slice, double* stage, unsigned* ticket,
-                                                              double* __restrict__ out,
-                                                              const int* __restrict__ skip_flag, StepArgs step) {
-    __shared__ double s[kBlock];
-    __shared__ int last_block;
-    if (skip_flag != nullptr && *skip_flag != 0) {
-        // converged: nothing to sum, but a pending status record must still be published
-        if (step.scalars != nullptr && blockIdx.x == 0 && threadIdx.x == 0)
-            cg_scalars_step(step.scalars, step.tol, step.history, step.host_record, step.sequence, step.alpha_ring,
-                            step.ring_slots);
-        return;
-    }
-    const int lo = blockIdx.x * slice;
-    const int hi = min(lo + slice, count);
-    double acc = 0.0;
-    for (int i = lo + threadIdx.x; i < hi; i += kBlock) acc += partials[i];
-    s[threadIdx.x] = acc;
-    __syncthreads();
-    for (int stride = kBlock / 2; stride > 0; stride >>= 1) {
-        if ((int)threadIdx.x < stride) s[threadIdx.x] += s[threadIdx.x + stride];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        __hip_atomic_store(&stage[blockIdx.x], s[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        last_block = (t == gridDim.x - 1) ? 1 : 0;
-    }
-    __syncthreads();
-    if (!last_block) return;
-    acc = 0.0;
-    for (int i = threadIdx.x; i < (int)gridDim.x; i += kBlock)
-        acc += __hip_atomic_load(&stage[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s[threadIdx.x] = acc;
-    __syncthreads();
-    for (int stride = kBlock / 2; stride > 0; stride >>= 1) {
-        if ((int)threadIdx.x < stride) s[threadIdx.x] += s[threadIdx.x + stride];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        *out = s[0];
-        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
-        if (step.scalars != nullptr)
-            cg_scalars_step(step.scalars, step.tol, step.history, step.host_record, step.sequence, step.alpha_ring,
-                            step.ring_slots);
-    }
-}
-
 __global__ void scalar_divide_kernel(const double* num, const double* den, double* out) {
     if (threadIdx.x == 0 && blockIdx.x == 0) *out = (*num) / (*den);
 }
@@ -373,6 +316,14 @@ __global__ __launch_bounds__(kStream) void cg_update_r_kernel(size_t n, const Cg
     if (threadIdx.x == 0) partials[block] = acc;
 }
 
+// The direction update p' = r + beta p exists in two roundings upstream: the multi-GPU solver's axpby_kernel
+// evaluates 1.0*r + beta*p, i.e. fma(1.0, r, beta*p) with beta*p rounded first (cg_solver_mgpu_partitioned.cu:136-140,
+// :682), the single-GPU device solver's update_p_kernel evaluates r + beta*p as one fma(beta, p, r)
+// (cg_solver.cu:90-95). fma_form selects the second; each solver keeps its own reference's arithmetic.
+__device__ __forceinline__ double direction(double r, double beta, double p, int fma_form) {
+    return fma_form ? fma(beta, p, r) : fma(1.0, r, beta * p);
+}
+
 // x += alpha*p of iteration `iteration` and, unless that iteration converged, p = 1.0*r + beta*p, in
 // one pass over p (the reference reads p twice: axpy_kernel(alpha, p, x) :598 and axpby_kernel :682).
 // Same per-element arithmetic, so results are unchanged. A launch enqueued for an iteration beyond
@@ -383,7 +334,7 @@ __global__ __launch_bounds__(kStream) void cg_update_px_kernel(size_t n, const C
                                                               const double* __restrict__ r,
                                                               double* __restrict__ p,
                                                               const double* x_in, double* x, int iteration,
-                                                              int reverse) {
+                                                              int reverse, int fma_form) {
     if (s->iterations != iteration) return;
     const bool advance = s->converged == 0;
     const double alpha = s->alpha, beta = s->beta;
@@ -398,8 +349,8 @@ __global__ __launch_bounds__(kStream) void cg_update_px_kernel(size_t n, const C
         store_once(x, i, xv);
         if (advance) {
             const d2 rv = load_once(r, i);
-            pv.x = fma(1.0, rv.x, beta * pv.x);
-            pv.y = fma(1.0, rv.y, beta * pv.y);
+            pv.x = direction(rv.x, beta, pv.x, fma_form);
+            pv.y = direction(rv.y, beta, pv.y, fma_form);
             // plain store: a nontemporal one measured the same (15.89-15.97 ms per solve at 50 M rows either way)
             reinterpret_cast<d2*>(p)[i] = pv;
         }
@@ -407,7 +358,7 @@ __global__ __launch_bounds__(kStream) void cg_update_px_kernel(size_t n, const C
     if ((n & 1) && block == 0 && threadIdx.x == 0) {
         const double pv = p[n - 1];
         x[n - 1] = fma(alpha, pv, x_in[n - 1]);
-        if (advance) p[n - 1] = fma(1.0, r[n - 1], beta * pv);
+        if (advance) p[n - 1] = direction(r[n - 1], beta, pv, fma_form);
     }
 }
 
@@ -435,7 +386,7 @@ __global__ __launch_bounds__(kStream) void cg_update_p_ring_kernel(size_t n, con
                                                                    const double* __restrict__ r,
                                                                    const double* __restrict__ p_in,
                                                                    double* __restrict__ p_out, int iteration,
-                                                                   int reverse) {
+                                                                   int reverse, int fma_form) {
     // Scalars FIRST here, unlike cg_update_r_kernel: this launch is enqueued before the host knows whether the
     // iteration converged, and the launch of the converging iteration must cost nothing (loading first would read
     // 16 B/row for nothing once per solve).
@@ -447,11 +398,11 @@ __global__ __launch_bounds__(kStream) void cg_update_p_ring_kernel(size_t n, con
     if (i < pairs) {
         const d2 rv = load_once(r, i);
         d2 pv = load_once(p_in, i);
-        pv.x = fma(1.0, rv.x, beta * pv.x);
-        pv.y = fma(1.0, rv.y, beta * pv.y);
+        pv.x = direction(rv.x, beta, pv.x, fma_form);
+        pv.y = direction(rv.y, beta, pv.y, fma_form);
         reinterpret_cast<d2*>(p_out)[i] = pv;  // plain: the next SpMV's neighbour loads re-use these lines
     }
-    if ((n & 1) && block == 0 && threadIdx.x == 0) p_out[n - 1] = fma(1.0, r[n - 1], beta * p_in[n - 1]);
+    if ((n & 1) && block == 0 && threadIdx.x == 0) p_out[n - 1] = direction(r[n - 1], beta, p_in[n - 1], fma_form);
 }
 
 // K directions of the ring window for one 16-byte pair: all K loads first, then the fmas in iteration order.
@@ -574,22 +525,15 @@ void launch_cg_update_r(size_t n, const CgScalars* s, const double* Ap, double* 
 }
 
 void launch_cg_update_px(size_t n, const CgScalars* s, const double* r, double* p, const double* x_in,
-                         double* x, int iteration, hipStream_t stream, bool reverse) {
+                         double* x, int iteration, hipStream_t stream, bool reverse, bool fma_form) {
     hipLaunchKernelGGL(cg_update_px_kernel, dim3(stream_grid(n)), dim3(kStream), 0, stream, n, s, r, p, x_in, x,
-                       iteration, reverse ? 1 : 0);
+                       iteration, reverse ? 1 : 0, fma_form ? 1 : 0);
 }
 
-// Two launches by default. SPMV_AMD_REDUCE_ONE_LAUNCH=1 selects reduce_fused_kernel (same result bits):
-// measured on MI355X it is the SLOWER form -- 16.07 vs 15.98 ms per 15-iteration solve at 50 M rows, i.e.
-// ~6 us per iteration worse although it removes three launches: the agent-scope release / acquire of 256
-// blocks (L2 write-back + invalidate each) costs more than the ~2 us kernel boundaries it saves.
-static bool reduce_in_two_launches() {
-    static const bool two = [] {
-        const char* v = getenv("SPMV_AMD_REDUCE_ONE_LAUNCH");
-        return !(v != nullptr && v[0] == '1');
-    }();
-    return two;
-}
+// Two launches. A one-launch form (every block publishes its slice sum with agent-scope atomics, the block that draws
+// the last ticket finishes) was built in round 2 and measured SLOWER on MI355X -- 16.07 vs 15.98 ms per 15-iteration
+// solve at 50 M rows, ~6 us per iteration, although it removes three launches: the agent-scope release / acquire of 256
+// blocks (L2 write-back + invalidate each) costs more than the ~2 us kernel boundaries it saves. Removed in round 3.
 
 namespace {
 const StepArgs kNoStep{nullptr, 0.0, nullptr, nullptr, 0, nullptr, 0};
@@ -601,15 +545,10 @@ void reduce_impl(const double* partials, int count, double* d_out, const int* d_
     if (stage != nullptr && count > 4 * kBlock) {
         const int slice = (count + kReduceStageBlocks - 1) / kReduceStageBlocks;
         const int blocks = (count + slice - 1) / slice;
-        if (reduce_in_two_launches() || mailbox != nullptr) {
-            hipLaunchKernelGGL(reduce_slices_kernel, dim3(blocks), dim3(kBlock), 0, stream, partials, count, slice,
-                               stage, d_skip_flag);
-            hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(kBlock), 0, stream, stage, blocks, d_out,
-                               d_skip_flag, host_progress, progress_value, mailbox, step);
-            return;
-        }
-        hipLaunchKernelGGL(reduce_fused_kernel, dim3(blocks), dim3(kBlock), 0, stream, partials, count, slice, stage,
-                           reinterpret_cast<unsigned*>(stage + kReduceStageBlocks), d_out, d_skip_flag, step);
+        hipLaunchKernelGGL(reduce_slices_kernel, dim3(blocks), dim3(kBlock), 0, stream, partials, count, slice,
+                           stage, d_skip_flag);
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(kBlock), 0, stream, stage, blocks, d_out,
+                           d_skip_flag, host_progress, progress_value, mailbox, step);
         return;
     }
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(kBlock), 0, stream, partials, count, d_out,
@@ -645,9 +584,9 @@ void launch_cg_scalars_step(CgScalars* s, double tol, double* history, int* host
 }
 
 void launch_cg_update_p_ring(size_t n, const CgScalars* s, const double* r, const double* p_in, double* p_out,
-                             int iteration, hipStream_t stream, bool reverse) {
+                             int iteration, hipStream_t stream, bool reverse, bool fma_form) {
     hipLaunchKernelGGL(cg_update_p_ring_kernel, dim3(stream_grid(n)), dim3(kStream), 0, stream, n, s, r, p_in, p_out,
-                       iteration, reverse ? 1 : 0);
+                       iteration, reverse ? 1 : 0, fma_form ? 1 : 0);
 }
 
 void launch_cg_flush_x(size_t n, const double* alphas, const RingSlots& ring, int slots, int first_slot, int count,

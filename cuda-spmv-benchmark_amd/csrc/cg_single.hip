@@ -3,7 +3,10 @@
 //   cg_solve        <- reference src/solvers/cg_solver.cu:154-378  (host scalars; SpMV through
 //                      run_timed with the direction vector travelling host<->device each iteration)
 //   cg_solve_device <- reference src/solvers/cg_solver.cu:436-706  (device scalars; SpMV through
-//                      run_device; one 4-byte flag read-back per iteration)
+//                      run_device). Round 3: no longer a restatement of the reference's loop -- 10 kernels, a blocking
+//                      4-byte read-back and a D2D copy per iteration, 152 B/row -- but the slab solver's loop
+//                      (cg_slab.hip) around the caller's operator: fused r update + r.r partials, direction ring with the
+//                      deferred x update, scalar step in the reduction's tail, status record in host-coherent memory.
 //
 // Same algebra, stopping rule (||r_k|| / ||r_0|| < tol, strict, the converging iteration is
 // counted), statistics and verbose output as the reference. Differences: the BLAS1 kernels move
@@ -22,6 +25,9 @@ std::vector<double>& last_cg_history() {
     static std::vector<double> h;
     return h;
 }
+// cg_slab.hip
+int cg_solve_on_operator(SpmvOperator* op, int n, const double* b, double* x, const CGConfig& config, CGStats* stats,
+                         std::vector<double>* history);
 }  // namespace spmv_amd
 
 namespace {
@@ -82,7 +88,11 @@ int cg_solve(SpmvOperator* spmv_op, MatrixData* mat, const double* b, double* x,
     double* d_scalar = device_alloc<double>(1);
     upload(v.x, x, (size_t)n);
     upload(v.b, b, (size_t)n);
-    std::vector<double> h_in((size_t)n), h_out((size_t)n);
+    // staging buffers of the host-interface SpMV: pinned, so that the two 8n-byte copies per iteration the interface
+    // imposes (here and inside run_timed) run at the link's rate instead of through pageable bounce buffers
+    double *h_in = nullptr, *h_out = nullptr;
+    HIP_CHECK(hipHostMalloc((void**)&h_in, (size_t)n * sizeof(double), hipHostMallocDefault));
+    HIP_CHECK(hipHostMalloc((void**)&h_out, (size_t)n * sizeof(double), hipHostMallocDefault));
     std::vector<double>& hist = last_cg_history();
     hist.clear();
 
@@ -100,9 +110,9 @@ int cg_solve(SpmvOperator* spmv_op, MatrixData* mat, const double* b, double* x,
     auto host_spmv = [&](const double* d_in, double* d_out) {
         double kernel_ms = 0.0;
         part.begin(kStream);
-        download(h_in.data(), d_in, (size_t)n);
-        spmv_op->run_timed(h_in.data(), h_out.data(), &kernel_ms);
-        upload(d_out, h_out.data(), (size_t)n);
+        download(h_in, d_in, (size_t)n);
+        spmv_op->run_timed(h_in, h_out, &kernel_ms);
+        upload(d_out, h_out, (size_t)n);
         part.end(kStream);
         t_spmv += part.elapsed_ms();
     };
@@ -160,6 +170,8 @@ int cg_solve(SpmvOperator* spmv_op, MatrixData* mat, const double* b, double* x,
 
     v.release();
     device_release(d_scalar);
+    (void)hipHostFree(h_in);
+    (void)hipHostFree(h_out);
     return 0;
 }
 
@@ -170,95 +182,10 @@ int cg_solve_device(SpmvOperator* spmv_op, MatrixData* mat, const double* b, dou
                 spmv_op->name);
         return 1;
     }
-    const int n = mat->rows;
-    Vectors v;
-    v.alloc((size_t)n);
-    // device scalars: rr_old, rr_new, pAp, alpha, beta, residual | converged flag | history
-    double* d_s = device_alloc<double>(6);
-    double *d_rr_old = d_s, *d_rr_new = d_s + 1, *d_pAp = d_s + 2, *d_alpha = d_s + 3,
-           *d_beta = d_s + 4, *d_residual = d_s + 5;
-    int* d_converged = device_alloc<int>(1);
-    const int hist_cap = config.max_iters < (1 << 20) ? config.max_iters + 1 : (1 << 20);
-    double* d_hist = device_alloc<double>((size_t)hist_cap);
-    upload(v.x, x, (size_t)n);
-    upload(v.b, b, (size_t)n);
-
-    EventTimer total, part;
-    double t_spmv = 0.0, t_blas = 0.0, t_red = 0.0;
-    const bool detail = config.enable_detailed_timers != 0;
-    auto region = [&](double& bucket, bool always, auto&& launch) {
-        part.begin(kStream);
-        launch();
-        part.end(kStream);
-        if (always || detail) bucket += part.elapsed_ms();
-    };
-
-    total.begin(kStream);
-    region(t_spmv, true, [&] { spmv_op->run_device(v.x, v.Ap); });
-    region(t_blas, true, [&] { launch_axpby((size_t)n, 1.0, v.b, -1.0, v.Ap, v.r, kStream); });
-    HIP_CHECK(hipMemcpyAsync(v.p, v.r, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, kStream));
-    region(t_red, false, [&] { launch_dot((size_t)n, v.r, v.r, v.scratch, d_rr_old, kStream); });
-
-    double h_rr_old = 0.0;
-    download(&h_rr_old, d_rr_old, 1);
-    const double b_norm = sqrt(h_rr_old);
-    upload(d_hist, &b_norm, 1);
-    if (config.verbose >= 1) printf("[CG-DEVICE] Initial residual: %e\n", b_norm);
-
-    int iter;
-    double final_residual_norm = b_norm;
-    for (iter = 0; iter < config.max_iters; iter++) {
-        region(t_spmv, false, [&] { spmv_op->run_device(v.p, v.Ap); });
-        region(t_red, false, [&] { launch_dot((size_t)n, v.Ap, v.p, v.scratch, d_pAp, kStream); });
-        launch_scalar_divide(d_rr_old, d_pAp, d_alpha, kStream);
-        region(t_blas, false, [&] { launch_axpy_dev((size_t)n, d_alpha, v.p, v.x, false, kStream); });
-        region(t_blas, false, [&] { launch_axpy_dev((size_t)n, d_alpha, v.Ap, v.r, true, kStream); });
-        region(t_red, false, [&] { launch_dot((size_t)n, v.r, v.r, v.scratch, d_rr_new, kStream); });
-        launch_check_convergence(d_rr_new, b_norm, config.tolerance, d_converged, d_residual, kStream);
-        if (iter + 1 < hist_cap)
-            HIP_CHECK(hipMemcpyAsync(d_hist + iter + 1, d_residual, sizeof(double),
-                                     hipMemcpyDeviceToDevice, kStream));
-
-        int h_converged = 0;
-        download(&h_converged, d_converged, 1);
-        if (config.verbose >= 2) {
-            double h_res = 0.0;
-            download(&h_res, d_residual, 1);
-            printf("[CG-DEVICE] Iter %3d: residual = %e (rel = %e)\n", iter + 1, h_res, h_res / b_norm);
-            final_residual_norm = h_res;
-        }
-        if (h_converged) {
-            if (config.verbose < 2) download(&final_residual_norm, d_residual, 1);
-            iter++;
-            break;
-        }
-        launch_scalar_divide(d_rr_new, d_rr_old, d_beta, kStream);
-        region(t_blas, false, [&] { launch_update_p_dev((size_t)n, v.r, d_beta, v.p, kStream); });
-        HIP_CHECK(hipMemcpyAsync(d_rr_old, d_rr_new, sizeof(double), hipMemcpyDeviceToDevice, kStream));
-    }
-    total.end(kStream);
-    const float total_ms = total.elapsed_ms();
-    HIP_CHECK(hipGetLastError());
-    download(x, v.x, (size_t)n);
-
-    std::vector<double>& hist = last_cg_history();
-    hist.assign((size_t)(iter + 1 < hist_cap ? iter + 1 : hist_cap), 0.0);
-    download(hist.data(), d_hist, hist.size());
-
-    stats->iterations = iter;
-    stats->residual_norm = final_residual_norm;
-    stats->time_total_ms = total_ms;
-    stats->time_spmv_ms = t_spmv;
-    stats->time_blas1_ms = t_blas;
-    stats->time_reductions_ms = t_red;
-    stats->converged = (final_residual_norm / b_norm < config.tolerance) ? 1 : 0;
-    fill_solution_checksums(x, n, &stats->solution_sum, &stats->solution_norm);
+    // the loop lives in cg_slab.hip (cg_solve_on_operator): the slab solver's fused kernels around this operator
+    if (cg_solve_on_operator(spmv_op, mat->rows, b, x, config, stats, &last_cg_history()) != 0) return 1;
+    fill_solution_checksums(x, mat->rows, &stats->solution_sum, &stats->solution_norm);
     if (config.verbose >= 1) print_breakdown("CG-DEVICE", stats);
-
-    v.release();
-    device_release(d_s);
-    device_release(d_converged);
-    device_release(d_hist);
     return 0;
 }
 

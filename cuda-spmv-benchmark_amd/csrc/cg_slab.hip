@@ -50,6 +50,14 @@ struct SpmvAmdCgSlab {
     // (spmv_amd_cg_slab_create_stencil5_as): one self-neighbour rank carrying the slab of rank `part_rank` of a
     // `part_world`-GPU job, so that one GPU can time the real per-rank slab shapes.
     int part_rank = 0, part_world = 1;
+    // Borrowed operator (cg_solve_device, reference src/solvers/cg_solver.cu:436-706): the matrix stays with the caller's
+    // SpmvOperator and every SpMV goes through its vtable's run_device -- or, when the operator is this library's own
+    // stencil5-csr, through its fused launch (FusedSpmv: p.Ap partials / initial residual written by the SpMV itself).
+    // Such a slab is the whole matrix on one rank, has no halos, and runs on the DEFAULT stream, where run_device enqueues.
+    SpmvOperator* op = nullptr;
+    FusedSpmv fused;
+    const char* label = nullptr;  // verbose prefix of the reference entry point that owns the solve ("CG-DEVICE")
+    bool device_form = false;     // direction update rounded as update_p_kernel does (cg_solver.cu:90-95), see cg_kernels.hip
     int n = 0, grid = -1, row_offset = 0, n_local = 0, halo = 0;
     bool has_prev = false, has_next = false;
     DeviceCsr A;
@@ -84,7 +92,15 @@ struct SpmvAmdCgSlab {
     const char* enqueued_stage = "";  // the last piece of work the host put on the streams
     int enqueued_iteration = -1;
     hipStream_t compute = nullptr, side = nullptr;
+    bool owns_streams = true;
     hipEvent_t ev_p_ready = nullptr, ev_halo_done = nullptr;
+    // Timeline of a solve (spmv_amd_cg_slab_set_timeline): events at the stage boundaries of every iteration, recorded
+    // without any host sync and resolved after the loop. kTimelineMarks per iteration on the compute stream, two on the
+    // side stream around the halo exchange.
+    bool timeline_on = false;
+    std::vector<hipEvent_t> tl_compute, tl_side;
+    hipEvent_t tl_after_interior = nullptr;  // where slab_spmv marks the end of the interior launch (split SpMV)
+    std::vector<double> timeline_us;         // result of the last timeline solve, order = kTimelineNames
     LaunchShape shape;
     // launch plans, made once at creation: the whole slab, the rows that need no halo, the first / last grid row
     Stencil5Plan plan_whole, plan_interior, plan_head, plan_tail;
@@ -115,6 +131,32 @@ struct SpmvAmdCgSlab {
 };
 
 namespace {
+// marks per iteration on the compute stream: iteration start | interior SpMV enqueued-and-done | boundary rows |
+// p.Ap sum (+ all-reduce) | r update | r.r sum (+ all-reduce) + scalar step | direction update
+constexpr int kTimelineMarks = 7;
+const char* const kTimelineNames =
+    "iterations,solve_ms,initial_residual_us,spmv_interior_us,halo_wait_and_boundary_rows_us,reduce_pAp_and_allreduce_us,"
+    "update_r_us,reduce_rr_allreduce_and_scalar_step_us,direction_update_us,gap_before_next_iteration_us,iteration_us,"
+    "halo_exchange_on_side_stream_us,final_x_flush_us";
+}  // namespace
+
+namespace {
+
+// (Re)binds a borrowed-operator slab to `op`: asks for the operator's fused launch and sizes the partial buffer for it.
+// Called at creation and at the start of every cg_solve_device (the operator may have been re-initialised in between).
+void adopt_operator(SpmvAmdCgSlab* s, SpmvOperator* op) {
+    s->op = op;
+    s->fused = fused_spmv_of(op);
+    s->fused_dot = s->fused.partials > 0;
+    s->fuse_init_residual = s->fused_dot && s->fused.can_init;
+    s->variant_name = s->fused_dot ? "operator/fused-launch" : "operator/run_device+dot";
+    if (s->fused.partials > s->partials_cap) {
+        device_release(s->partials_spmv);
+        s->partials_cap = s->fused.partials;
+        s->partials_spmv = device_alloc<double>((size_t)s->partials_cap);
+        HIP_CHECK(hipMemset(s->partials_spmv, 0, (size_t)s->partials_cap * sizeof(double)));
+    }
+}
 
 void make_common(SpmvAmdCgSlab* s) {
     const size_t nl = (size_t)s->n_local;
@@ -127,22 +169,21 @@ void make_common(SpmvAmdCgSlab* s) {
     s->halo = s->comm->exchanges_halos() ? s->grid : 0;
     s->A.view.halo_before = s->has_prev ? s->halo : 0;
     s->A.view.halo_after = s->has_next ? s->halo : 0;
-    HIP_CHECK(hipStreamCreateWithFlags(&s->compute, hipStreamNonBlocking));
-    {
+    if (s->op != nullptr) {
+        // borrowed operator: its run_device enqueues on the default stream (reference spmv_stencil_csr_direct.cu:267-271),
+        // so the whole solve runs there; one rank, no halo exchange, no side stream
+        s->compute = nullptr;
+        s->side = nullptr;
+        s->owns_streams = false;
+    } else {
+        HIP_CHECK(hipStreamCreateWithFlags(&s->compute, hipStreamNonBlocking));
         // The side stream has the DEFAULT priority. A highest-priority side stream (so that the halo exchange
         // gets CUs at once while the interior SpMV saturates the chip) was measured with the rank as its own
-        // neighbour (SPMV_AMD_SELF_NEIGHBOUR=1, 50 M rows): every kernel of the normal-priority compute stream
-        // slows down while such a queue exists -- SpMV 0.50 -> 0.66 ms, 5 us kernels -> 50 us, a solve
-        // 15.7 -> 25.3 ms -- whether the exchange is RCCL send/recv or a plain copy. At equal priority the
-        // exchange kernel starts 50-90 us into the interior SpMV and ends long before it (rocprofv3 trace).
-        const char* pr = getenv("SPMV_AMD_SIDE_PRIORITY");  // "high" re-creates the measured configuration
-        if (pr && pr[0] == 'h') {
-            int least = 0, greatest = 0;
-            HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
-            HIP_CHECK(hipStreamCreateWithPriority(&s->side, hipStreamNonBlocking, greatest));
-        } else {
-            HIP_CHECK(hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking));
-        }
+        // neighbour (SPMV_AMD_SELF_NEIGHBOUR=1, 50 M rows; profiles/r01_multirank_pipeline.txt): every kernel of the
+        // normal-priority compute stream slows down while such a queue exists -- SpMV 0.50 -> 0.66 ms, 5 us kernels ->
+        // 50 us, a solve 15.7 -> 25.3 ms -- whether the exchange is RCCL send/recv or a plain copy. At equal priority
+        // the exchange kernel starts 50-90 us into the interior SpMV and ends long before it (rocprofv3 trace).
+        HIP_CHECK(hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking));
     }
     HIP_CHECK(hipEventCreateWithFlags(&s->ev_p_ready, hipEventDisableTiming));
     HIP_CHECK(hipEventCreateWithFlags(&s->ev_halo_done, hipEventDisableTiming));
@@ -199,13 +240,20 @@ void make_common(SpmvAmdCgSlab* s) {
     if (const char* v = getenv("SPMV_AMD_ROCTX")) s->roctx_always = v[0] == '1';
     s->partials_blas = device_alloc<double>(dot_scratch_doubles(nl));
     s->reduce_stage = device_alloc<double>((size_t)reduce_stage_doubles());
-    // both end in the ticket counter of the one-launch reduction, which starts at zero
+    // (their last slot was the ticket counter of round 2's one-launch reduction; kept zeroed, unused)
     HIP_CHECK(hipMemset(s->partials_blas, 0, dot_scratch_doubles(nl) * sizeof(double)));
     HIP_CHECK(hipMemset(s->reduce_stage, 0, (size_t)reduce_stage_doubles() * sizeof(double)));
     s->d_s = device_alloc<CgScalars>(1);
     HIP_CHECK(hipMemset(s->d_s, 0, sizeof(CgScalars)));
     HIP_CHECK(hipHostMalloc((void**)&s->h_poll, sizeof(*s->h_poll), hipHostMallocCoherent | hipHostMallocMapped));
     memset(s->h_poll, 0, sizeof(*s->h_poll));
+    if (s->op != nullptr) {
+        adopt_operator(s, s->op);
+        launch_fill(s->b, nl, 1.0, s->compute);
+        launch_fill(s->x0, nl, 0.0, s->compute);
+        HIP_CHECK(hipDeviceSynchronize());
+        return;
+    }
     s->A.verify_stencil(s->compute);
     // SPMV_AMD_SLAB_PLANES=1 (off by default: measured slower in the loop, spmv_kernels.hip): a verified stencil slab
     // made of whole grid rows also keeps its coefficients as five planes and runs the row-planes kernel (+40 B/row
@@ -236,7 +284,6 @@ void make_common(SpmvAmdCgSlab* s) {
         const auto tiled = [](const Stencil5Plan& p) { return p.variant == Stencil5Variant::RowLds || p.variant == Stencil5Variant::RowPlanes; };
         const auto rowlds = [&](const Stencil5Plan& p) { return p.last_row <= p.first_row || tiled(p); };
         s->fuse_init_residual = tiled(s->plan_whole) && rowlds(s->plan_interior) && rowlds(s->plan_head) && rowlds(s->plan_tail);
-        if (const char* v = getenv("SPMV_AMD_FUSE_INIT")) s->fuse_init_residual = s->fuse_init_residual && v[0] != '0';
     }
     launch_fill(s->b, nl, 1.0, s->compute);   // default right-hand side b = 1
     launch_fill(s->x0, nl, 0.0, s->compute);  // default initial guess x0 = 0
@@ -292,15 +339,26 @@ int slab_spmv(SpmvAmdCgSlab* s, bool with_dot, bool overlap, const int* skip,
     const int lo = s->has_prev ? s->halo : 0;
     const int hi = s->n_local - (s->has_next ? s->halo : 0);
     int used = 0;
-    if (!overlap || hi <= lo || (lo == 0 && hi == s->n_local)) {
+    if (s->op != nullptr) {
+        // the caller's operator: its fused launch when it has one (this library's stencil5-csr), else the vtable
+        if (part != nullptr) {
+            used = s->fused.launch(in, s->Ap, part, skip, s->shape.reverse, init, s->compute);
+        } else if (s->op->run_device(in, s->Ap) != 0) {
+            fprintf(stderr, "[cg] operator '%s': run_device failed\n", s->op->name);
+            exit(EXIT_FAILURE);
+        }
+        if (s->tl_after_interior) HIP_CHECK(hipEventRecord(s->tl_after_interior, s->compute));
+    } else if (!overlap || hi <= lo || (lo == 0 && hi == s->n_local)) {
         if (overlap) HIP_CHECK(hipStreamWaitEvent(s->compute, s->ev_halo_done, 0));
         used = launch_stencil5_spmv(A, s->plan_whole, in, s->Ap, 1.0, part, skip, s->shape.reverse, s->compute, init);
+        if (s->tl_after_interior) HIP_CHECK(hipEventRecord(s->tl_after_interior, s->compute));
     } else {
         // rows whose north and south neighbours are local run under the halo exchange; the first / last grid
         // row of the slab once the halo rows have landed. (Launching those two rows behind the exchange on the
         // side stream instead, so that this stream only waits for an event, measured slower: 15.77 vs 15.59 ms
         // per solve at 50 M rows with the rank as its own neighbour.)
         used = launch_stencil5_spmv(A, s->plan_interior, in, s->Ap, 1.0, part, skip, s->shape.reverse, s->compute, init);
+        if (s->tl_after_interior) HIP_CHECK(hipEventRecord(s->tl_after_interior, s->compute));
         HIP_CHECK(hipStreamWaitEvent(s->compute, s->ev_halo_done, 0));
         used += slab_boundary_spmv(s, in, part, skip, s->compute, init);
     }
@@ -351,7 +409,8 @@ void wait_for_status(SpmvAmdCgSlab* s) {
     volatile int* seq = &s->h_poll->sequence;
     long spins = 0;
     while (__atomic_load_n(seq, __ATOMIC_ACQUIRE) != s->poll_sequence) {
-        if (++spins % (1L << 22) == 0) {
+        __builtin_ia32_pause();  // the record arrives within one iteration; the spinning core at least yields its pipeline
+        if (++spins % (1L << 20) == 0) {
             // surface a faulted stream at once instead of waiting for the watchdog
             const hipError_t e = hipStreamQuery(s->compute);
             if (e != hipSuccess && e != hipErrorNotReady) HIP_CHECK(e);
@@ -509,6 +568,23 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
         if (bucket2) *bucket2 += ms;
     };
 
+    // timeline: stage-boundary events, no host sync (spmv_amd_cg_slab_set_timeline); `detail` has its own per-stage syncs
+    const bool timeline = s->timeline_on && !detail;
+    s->timeline_us.clear();
+    auto tl_event = [](std::vector<hipEvent_t>& pool, size_t index) {
+        while (pool.size() <= index) {
+            hipEvent_t e;
+            HIP_CHECK(hipEventCreate(&e));
+            pool.push_back(e);
+        }
+        return pool[index];
+    };
+    // compute-stream marks: [0] solve start, [1] initial residual done, then kTimelineMarks per iteration, then the flush
+    auto mark = [&](int iteration, int k) {
+        if (timeline) HIP_CHECK(hipEventRecord(tl_event(s->tl_compute, 2 + (size_t)iteration * kTimelineMarks + k), s->compute));
+    };
+    int tl_exchanges = 0;  // halo exchanges marked on the side stream (exchange j precedes the SpMV of iteration j)
+
     s->p = s->ring[0];
     const int slots = s->ring_slots;
     RingSlots ring_view;
@@ -522,6 +598,7 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
         comm->barrier(s->compute);
     }
     total.begin(s->compute);
+    if (timeline) HIP_CHECK(hipEventRecord(tl_event(s->tl_compute, 0), s->compute));
 
     // ---- r0 = b - A x0 ; p0 = r0 ; rr0 ----
     // x0 is read where it lies: its allocation carries the halo rows the first / last grid row need
@@ -564,6 +641,13 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
     if (separate) allreduce_scalar(s, &s->d_s->rr_new, "all-reduce of the initial r.r");
     s->reduce_mailbox = s->fused_dot ? mailbox : nullptr;  // the in-loop SpMVs' p.Ap reduction
     launch_cg_scalars_init(s->d_s, s->d_hist, s->compute);
+    if (timeline) HIP_CHECK(hipEventRecord(tl_event(s->tl_compute, 1), s->compute));
+    if (s->label && config->verbose >= 1) {  // the reference prints ||r0|| before its loop (cg_solver.cu:529-531); verbose runs only
+        CgScalars now;
+        HIP_CHECK(hipStreamSynchronize(s->compute));
+        HIP_CHECK(hipMemcpy(&now, s->d_s, sizeof now, hipMemcpyDeviceToHost));
+        printf("[%s] Initial residual: %e\n", s->label, now.b_norm);
+    }
     bool halo_in_flight = false;
     auto start_p_halo = [&] {  // halo rows of the new p: side stream, under the interior SpMV
         if (!multi) return;
@@ -575,7 +659,10 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
         }
         HIP_CHECK(hipEventRecord(s->ev_p_ready, s->compute));
         HIP_CHECK(hipStreamWaitEvent(s->side, s->ev_p_ready, 0));
+        if (timeline) HIP_CHECK(hipEventRecord(tl_event(s->tl_side, 2 * (size_t)tl_exchanges), s->side));
         exchange_p_halo(s, s->side);
+        if (timeline) HIP_CHECK(hipEventRecord(tl_event(s->tl_side, 2 * (size_t)tl_exchanges + 1), s->side));
+        if (timeline) ++tl_exchanges;
         HIP_CHECK(hipEventRecord(s->ev_halo_done, s->side));
         halo_in_flight = true;
     };
@@ -596,7 +683,14 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
         trace.push("SpMV");
         s->spmv_progress = &s->h_poll->progress;
         s->spmv_progress_value = 4 * (s->poll_sequence + 1) + 1;
-        if (detail) {
+        mark(enqueued, 0);
+        s->tl_after_interior = timeline ? tl_event(s->tl_compute, 2 + (size_t)enqueued * kTimelineMarks + 1) : nullptr;
+        if (timeline) {
+            // [1] is recorded inside slab_spmv behind the interior launch, [2] here behind the boundary rows;
+            // the reduction of the partials is issued by slab_spmv too, so [3] follows directly
+            slab_spmv(s, true, halo_in_flight, skip, nullptr, tl_event(s->tl_compute, 2 + (size_t)enqueued * kTimelineMarks + 2));
+            s->tl_after_interior = nullptr;
+        } else if (detail) {
             timed(&stats->time_spmv_ms, nullptr, [&] { slab_spmv(s, true, halo_in_flight, skip); });
         } else {
             const bool sample = s->spmv_event_stride > 0 && enqueued % s->spmv_event_stride == 0;
@@ -621,12 +715,14 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
             TraceScope r(trace, "AllReduce");
             timed(&stats->time_allreduce_ms, nullptr, [&] { allreduce_scalar(s, &s->d_s->pAp, "all-reduce of p.Ap"); });
         }
+        mark(enqueued, 3);
         s->enqueued_stage = "r update";
         trace.push("BLAS_AXPY");
         timed(&stats->time_blas1_ms, &stats->time_axpy_update_r_ms, [&] {
             launch_cg_update_r(nl, s->d_s, s->Ap, s->r, s->partials_blas, s->compute, s->pingpong && !backward);
         });
         trace.pop();
+        mark(enqueued, 4);
         // the scalar step publishes {sequence, converged, iterations} straight into host-coherent pinned
         // memory: no copy command sits between it and the p update on the stream. Without an all-reduce
         // between the sum and the step, the step runs in the tail of the reduction's launch.
@@ -654,6 +750,7 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
             });
         }
         trace.pop();
+        mark(enqueued, 5);
         ++enqueued;
         trace.push("BLAS_AXPBY");
 
@@ -661,7 +758,7 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
         // looks at the status: the GPU works on these while the host waits for the record.
         if (slots == 1) {
             timed(&stats->time_blas1_ms, &stats->time_axpby_update_p_ms, [&] {
-                launch_cg_update_px(nl, s->d_s, s->r, s->p, enqueued == 1 ? s->x0 : s->x, s->x, enqueued, s->compute, backward);
+                launch_cg_update_px(nl, s->d_s, s->r, s->p, enqueued == 1 ? s->x0 : s->x, s->x, enqueued, s->compute, backward, s->device_form);
             });
         } else {
             // the slot the new direction goes to still holds p of iteration enqueued - slots: fold the whole
@@ -675,11 +772,12 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
             }
             double* p_next = s->ring[(size_t)(enqueued % slots)];
             timed(&stats->time_blas1_ms, &stats->time_axpby_update_p_ms, [&] {
-                launch_cg_update_p_ring(nl, s->d_s, s->r, s->p, p_next, enqueued, s->compute, backward);
+                launch_cg_update_p_ring(nl, s->d_s, s->r, s->p, p_next, enqueued, s->compute, backward, s->device_form);
             });
             s->p = p_next;
         }
         trace.pop();
+        mark(enqueued - 1, 6);
         s->enqueued_stage = "direction update and halo exchange";
         {
             TraceScope r(trace, "Halo_Exchange");
@@ -691,12 +789,17 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
         if (config->verbose >= 2 && comm->rank == 0) {
             CgScalars now;
             HIP_CHECK(hipMemcpy(&now, s->d_s, sizeof now, hipMemcpyDeviceToHost));
-            printf("[Iter %3d] Residual: %.6e (rel: %.6e, alpha: %.4e)\n", now.iterations, now.residual,
-                   now.residual / now.b_norm, now.alpha);
+            if (s->label)  // cg_solve_device's line (reference cg_solver.cu:604-607)
+                printf("[%s] Iter %3d: residual = %e (rel = %e)\n", s->label, now.iterations, now.residual, now.residual / now.b_norm);
+            else
+                printf("[Iter %3d] Residual: %.6e (rel: %.6e, alpha: %.4e)\n", now.iterations, now.residual,
+                       now.residual / now.b_norm, now.alpha);
         }
     }
     s->shape.reverse = false;
     s->reduce_mailbox = nullptr;
+    const size_t tl_flush = 2 + (size_t)enqueued * kTimelineMarks;  // [+0] before, [+1] after the final flush
+    if (timeline) HIP_CHECK(hipEventRecord(tl_event(s->tl_compute, tl_flush), s->compute));
     if (slots > 1 && enqueued > window_start)  // x <- x + the directions of the last window
         timed(&stats->time_blas1_ms, nullptr, [&] {
             launch_cg_flush_x(nl, s->d_alpha_ring, ring_view, slots, window_start % slots, enqueued - window_start,
@@ -705,6 +808,7 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
     s->p = s->ring[0];
     if (enqueued == 0)  // no iteration ran (max_iters == 0): the solution is the initial guess
         HIP_CHECK(hipMemcpyAsync(s->x, s->x0, vbytes, hipMemcpyDeviceToDevice, s->compute));
+    if (timeline) HIP_CHECK(hipEventRecord(tl_event(s->tl_compute, tl_flush + 1), s->compute));
     total.end(s->compute);
     float total_ms = 0.f;
     {
@@ -716,7 +820,36 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
 
     CgScalars fin;
     HIP_CHECK(hipMemcpy(&fin, s->d_s, sizeof fin, hipMemcpyDeviceToHost));
-    if (!detail) {  // timed SpMV launches that did real work (one per counted iteration), scaled to all of them
+    if (timeline) {
+        // averages over the counted iterations; order = kTimelineNames
+        auto us = [&](hipEvent_t a, hipEvent_t b) {
+            float ms = 0.f;
+            HIP_CHECK(hipEventElapsedTime(&ms, a, b));
+            return (double)ms * 1e3;
+        };
+        const std::vector<hipEvent_t>& E = s->tl_compute;
+        const int its = fin.iterations < enqueued ? fin.iterations : enqueued;
+        double stage[kTimelineMarks] = {0, 0, 0, 0, 0, 0, 0};  // [k] = mark k -> mark k+1; [6] = mark 6 -> next iteration's mark 0
+        double iteration_us = 0.0;
+        for (int it = 0; it < its; ++it) {
+            const size_t base = 2 + (size_t)it * kTimelineMarks;
+            for (int k = 0; k < kTimelineMarks - 1; ++k) stage[k] += us(E[base + k], E[base + k + 1]);
+            // the last counted iteration ends at the flush mark
+            const hipEvent_t next = it + 1 < enqueued ? E[base + kTimelineMarks] : E[tl_flush];
+            stage[6] += us(E[base + 6], next);
+            iteration_us += us(E[base], next);
+        }
+        double side_us = 0.0;
+        const int exchanges = tl_exchanges < its ? tl_exchanges : its;  // exchange j feeds the SpMV of iteration j
+        for (int j = 0; j < exchanges; ++j) side_us += us(s->tl_side[2 * (size_t)j], s->tl_side[2 * (size_t)j + 1]);
+        const double per = its > 0 ? 1.0 / its : 0.0;
+        s->timeline_us = {(double)its, (double)total_ms, us(E[0], E[1]), stage[0] * per, stage[1] * per, stage[2] * per, stage[3] * per,
+                          stage[4] * per, stage[5] * per, stage[6] * per, iteration_us * per,
+                          exchanges > 0 ? side_us / exchanges : 0.0, us(E[tl_flush], E[tl_flush + 1])};
+    }
+    if (timeline) {
+        stats->time_spmv_ms = (s->timeline_us[3] + s->timeline_us[4]) * s->timeline_us[0] / 1e3;
+    } else if (!detail) {  // timed SpMV launches that did real work (one per counted iteration), scaled to all of them
         double ms_sum = 0.0;
         int used = 0;
         for (int k = 0; k < sampled; ++k) {
@@ -735,7 +868,7 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
     // not converged: the reference reports sqrt(rs_old) of the last completed iteration (:720-725)
     stats->residual_norm = fin.converged ? fin.residual : sqrt(fin.rr_old);
     stats->time_total_ms = total_ms;
-    if (!fin.converged && comm->rank == 0) printf("\nMax iterations reached without convergence\n");
+    if (!fin.converged && comm->rank == 0 && s->label == nullptr) printf("\nMax iterations reached without convergence\n");
     if (detail && stats->iterations > 0) {
         stats->time_dot_rs_new_ms /= stats->iterations;
         stats->time_axpy_update_r_ms /= stats->iterations;
@@ -788,6 +921,14 @@ extern "C" void spmv_amd_cg_slab_info(const SpmvAmdCgSlab* s, int* row_offset, i
 
 extern "C" const char* spmv_amd_cg_slab_variant(const SpmvAmdCgSlab* s) { return s->variant_name; }
 
+extern "C" void spmv_amd_cg_slab_set_timeline(SpmvAmdCgSlab* s, int on) { s->timeline_on = on != 0; }
+extern "C" const char* spmv_amd_cg_slab_timeline_names(void) { return kTimelineNames; }
+extern "C" int spmv_amd_cg_slab_timeline(const SpmvAmdCgSlab* s, double* out, int cap) {
+    const int count = (int)s->timeline_us.size();
+    for (int i = 0; i < count && i < cap; ++i) out[i] = s->timeline_us[i];
+    return count;
+}
+
 extern "C" int spmv_amd_cg_slab_time_spmv(SpmvAmdCgSlab* s, int reps, float* ms_each) {
     HIP_CHECK(hipMemsetAsync(&s->d_s->converged, 0, sizeof(int), s->compute));
     EventTimer t;
@@ -823,12 +964,81 @@ extern "C" void spmv_amd_cg_slab_destroy(SpmvAmdCgSlab* s) {
     device_release(s->d_hist);
     if (s->h_poll) (void)hipHostFree(s->h_poll);
     for (hipEvent_t e : s->spmv_ev) (void)hipEventDestroy(e);
+    for (hipEvent_t e : s->tl_compute) (void)hipEventDestroy(e);
+    for (hipEvent_t e : s->tl_side) (void)hipEventDestroy(e);
     (void)hipEventDestroy(s->ev_p_ready);
     (void)hipEventDestroy(s->ev_halo_done);
-    (void)hipStreamDestroy(s->compute);
-    (void)hipStreamDestroy(s->side);
+    if (s->owns_streams) {
+        (void)hipStreamDestroy(s->compute);
+        (void)hipStreamDestroy(s->side);
+    }
     delete s;
 }
+
+// ---------------------------------------------------------------------------------------
+// cg_solve_device on a borrowed operator (reference src/solvers/cg_solver.cu:436-706)
+// ---------------------------------------------------------------------------------------
+namespace {
+SpmvAmdCgSlab* g_workspace = nullptr;  // vectors, direction ring, scalars of cg_solve_device, kept between calls
+int g_workspace_device = -1;
+}  // namespace
+
+namespace spmv_amd {
+
+void release_cg_workspace() {
+    if (g_workspace == nullptr) return;
+    spmv_amd_cg_slab_destroy(g_workspace);
+    g_workspace = nullptr;
+}
+
+// The loop of spmv_amd_cg_slab_solve driven through the caller's operator: the same fused kernels, direction ring,
+// deferred x update, status record in host-coherent memory (no blocking read-back per iteration, no event pairs unless
+// detailed timers ask for them), one rank, default stream. What stays the reference's: run_device(d_x, d_y) is the only
+// thing asked of an operator this library does not own; b / x are host arrays, uploaded before and downloaded after the
+// timed region (:458-474, :646-649); ||r0|| is the stopping test's denominator; the direction update is rounded as
+// update_p_kernel rounds it. The reference allocates and frees its vectors in every call; here they are kept until an
+// operator's free() (the harness solves the same system 13 times: 3 warm-ups + 10 runs, src/main/cg_solver.cu:154-178).
+int cg_solve_on_operator(SpmvOperator* op, int n, const double* b, double* x, const CGConfig& config, CGStats* stats,
+                         std::vector<double>* history) {
+    int device = 0;
+    HIP_CHECK(hipGetDevice(&device));
+    if (g_workspace != nullptr && (g_workspace->n != n || g_workspace_device != device)) release_cg_workspace();
+    if (g_workspace == nullptr) {
+        SpmvAmdCgSlab* s = new SpmvAmdCgSlab();
+        s->comm = self_comm();
+        s->op = op;
+        s->n = s->n_local = n;
+        s->grid = -1;
+        s->label = "CG-DEVICE";
+        s->device_form = true;
+        make_common(s);
+        g_workspace = s;
+        g_workspace_device = device;
+    } else {
+        adopt_operator(g_workspace, op);
+    }
+    SpmvAmdCgSlab* s = g_workspace;
+    upload(s->b, b, (size_t)n);
+    upload(s->x0, x, (size_t)n);
+    const CGConfigMultiGPU cfg = {config.max_iters, config.tolerance, config.verbose, config.enable_detailed_timers};
+    CGStatsMultiGPU st;
+    if (spmv_amd_cg_slab_solve(s, &cfg, &st) != 0) return 1;
+    download(x, s->x, (size_t)n);
+    *history = s->history;
+    stats->iterations = st.iterations;
+    // not converged: the reference's final_residual_norm is whatever it last copied back -- the residual of the last
+    // iteration under verbose >= 2, else still ||r0|| (:535, :601-619)
+    const double r0 = s->history.empty() ? 0.0 : s->history.front();
+    stats->residual_norm = st.converged ? st.residual_norm : (config.verbose >= 2 && !s->history.empty() ? s->history.back() : r0);
+    stats->time_total_ms = st.time_total_ms;
+    stats->time_spmv_ms = st.time_spmv_ms + (config.enable_detailed_timers ? st.time_initial_r_ms : 0.0);
+    stats->time_blas1_ms = st.time_blas1_ms;
+    stats->time_reductions_ms = st.time_reductions_ms + st.time_dot_rs_initial_ms;
+    stats->converged = (r0 > 0.0 && stats->residual_norm / r0 < config.tolerance) ? 1 : 0;
+    return 0;
+}
+
+}  // namespace spmv_amd
 
 // ---------------------------------------------------------------------------------------
 // reference entry point

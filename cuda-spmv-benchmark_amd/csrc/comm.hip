@@ -110,6 +110,9 @@ struct RcclComm final : SpmvAmdComm {
             d_barrier = device_alloc<double>(1);
             HIP_CHECK(hipMemset(d_barrier, 0, sizeof(double)));
         }
+        // a caller without a stream of its own (spmv_amd_comm_barrier) gets the communicator's private stream: `coll` is
+        // never driven from the null stream
+        if (stream == nullptr) stream = gather_stream();
         RCCL_CHECK(ncclAllReduce(d_barrier, d_barrier, 1, ncclDouble, ncclSum, coll, stream));
         HIP_CHECK(hipStreamSynchronize(stream));
     }

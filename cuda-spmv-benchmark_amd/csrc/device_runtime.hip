@@ -34,7 +34,7 @@ Tunables read_tunables() {
     k.csr_stream_rows = env_int("SPMV_AMD_CSR_STREAM_ROWS", 0);
     k.ell_shape = env_int("SPMV_AMD_ELL_SHAPE", k.ell_shape);
     k.xcd_group = env_int("SPMV_AMD_XCD_GROUP", k.xcd_group);
-    if (k.xcd_group < 0 || k.xcd_group > 64) k.xcd_group = 0;
+    if (k.xcd_group < 0 || k.xcd_group > 512) k.xcd_group = 0;
     return k;
 }
 }  // namespace

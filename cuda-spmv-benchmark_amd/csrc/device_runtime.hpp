@@ -59,6 +59,21 @@ struct EventTimer {
     }
 };
 
+// What cg_solve_device may ask of an operator BEYOND the vtable (reference include/spmv.h:125-134 has run_device(d_x, d_y)
+// only). This library's own stencil5-csr operator can write the p.Ap partial sums -- and, for the first SpMV of a solve,
+// r0 = b - A x0, p0 and the r0.r0 partials -- from inside its SpMV launch, which saves a 16 B/row dot-product pass per
+// iteration; any other operator (the CSR / ELLPACK ones, a table supplied by the caller) reports partials == 0 and is
+// driven through run_device followed by a dot kernel. Defined in operators.hip.
+struct FusedSpmv {
+    int partials = 0;       // dot-partial slots one launch writes; 0 = the operator has no fused form
+    bool can_init = false;  // the launch can produce the initial residual (ResidualOut)
+    int (*launch)(const double* d_x, double* d_y, double* d_partials, const int* d_skip, bool reverse, const ResidualOut* init,
+                  hipStream_t stream) = nullptr;
+};
+FusedSpmv fused_spmv_of(const SpmvOperator* op);
+// Frees the vectors cg_solve_device keeps between calls (cg_slab.hip); called by every operator's free().
+void release_cg_workspace();
+
 // Device-resident CSR of one operator or one slab (owning).
 struct DeviceCsr {
     int* row_ptr = nullptr;

@@ -212,13 +212,15 @@ void launch_cg_update_r(size_t n, const CgScalars* s, const double* Ap, double* 
 // x += alpha p (the update of iteration `iteration`), then p = 1.0*r + beta*p unless that iteration
 // converged; one pass over p (axpy + axpby of cg_solver_mgpu_partitioned.cu:598,682 fused).
 // x = x_in + alpha p: x_in is x, or the stored initial guess in the first iteration of a solve.
+// fma_form: p = fma(beta, p, r) (the single-GPU device solver's update_p_kernel, cg_solver.cu:90-95) instead of
+// fma(1.0, r, beta*p) (the multi-GPU solver's axpby_kernel, mgpu :136-140).
 void launch_cg_update_px(size_t n, const CgScalars* s, const double* r, double* p, const double* x_in,
-                         double* x, int iteration, hipStream_t stream, bool reverse = false);
+                         double* x, int iteration, hipStream_t stream, bool reverse = false, bool fma_form = false);
 // ---- deferred x update (cg_slab.hip, "direction ring") ----
 // p_out = 1.0*r + beta*p_in for iteration `iteration` unless it converged: the direction update written out
 // of place, so that p_in stays available for a later x update. Same per-element arithmetic as above.
 void launch_cg_update_p_ring(size_t n, const CgScalars* s, const double* r, const double* p_in, double* p_out,
-                             int iteration, hipStream_t stream, bool reverse = false);
+                             int iteration, hipStream_t stream, bool reverse = false, bool fma_form = false);
 // x = x_in + sum_j alpha[slot_j] * p[slot_j], slot_j = (first_slot + j) % slots for j = 0..count-1, added in that
 // order with one fma each: element for element the x the per-iteration updates x += alpha_j p_j produce.
 constexpr int kMaxRingSlots = 16;

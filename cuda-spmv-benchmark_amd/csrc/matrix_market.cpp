@@ -173,6 +173,18 @@ extern "C" void read_matrix_symtogen(MatrixData* mat, const char* filename, int*
     if (csr_val) *csr_val = nullptr;
     *nnz_general = 0;
     if (tri.entries == nullptr) return;
+    // A symmetric file describes a square matrix and every index must lie inside it: the mirrored entry uses the
+    // column as a row, and the CSR arrays below are indexed by row. (The reference indexes its arrays unchecked,
+    // io.cu:259-307; an index of 0, or one beyond the declared size, would write outside them.)
+    for (int k = 0; k < tri.nnz; ++k) {
+        const Entry& e = tri.entries[k];
+        if (tri.rows != tri.cols || e.row < 0 || e.row >= tri.rows || e.col < 0 || e.col >= tri.cols) {
+            fprintf(stderr, "Error reading matrix entry: index (%d, %d) outside the %d x %d symmetric matrix\n", e.row + 1, e.col + 1,
+                    tri.rows, tri.cols);
+            free(tri.entries);
+            return;
+        }
+    }
     size_t diag = 0;
     for (int k = 0; k < tri.nnz; ++k) diag += tri.entries[k].row == tri.entries[k].col;
     const size_t full = 2 * (size_t)tri.nnz - diag;

@@ -127,7 +127,14 @@ int run_timed_generic(const double* x, double* y, double* kernel_time_ms) {
 
 void stencil_free() {
     printf("[stencil5-csr] Cleaning up\n");
+    release_cg_workspace();  // the single-GPU CG solver's vectors live as long as an operator does
     g_stencil.drop();
+}
+
+// The launch cg_solve_device uses when the operator it is handed is this one (device_runtime.hpp, FusedSpmv).
+int stencil_fused_launch(const double* d_x, double* d_y, double* d_partials, const int* d_skip, bool reverse,
+                         const ResidualOut* init, hipStream_t stream) {
+    return launch_stencil5_spmv(g_stencil.A.view, g_stencil.plan, d_x, d_y, /*alpha=*/1.0, d_partials, d_skip, reverse, stream, init);
 }
 
 // ---- cusparse-csr ----------------------------------------------------------------
@@ -165,6 +172,7 @@ int csr_run_device(const double* d_x, double* d_y) {
 
 void csr_free() {
     printf("[CSR] Cleaning up\n");
+    release_cg_workspace();
     g_csr.drop();
 }
 
@@ -300,11 +308,17 @@ int ell_run_timed(EllOperator& op, const double* x, double* y, double* kernel_ti
 int ellg_init(MatrixData* m) { return ell_init_common(g_ell, m); }
 int ellg_run_timed(const double* x, double* y, double* ms) { return ell_run_timed(g_ell, x, y, ms); }
 int ellg_run_device(const double* x, double* y) { return ell_run(g_ell, x, y); }
-void ellg_free() { g_ell.drop(); }
+void ellg_free() {
+    release_cg_workspace();
+    g_ell.drop();
+}
 int ells_init(MatrixData* m) { return ell_init_common(g_ell_stencil, m); }
 int ells_run_timed(const double* x, double* y, double* ms) { return ell_run_timed(g_ell_stencil, x, y, ms); }
 int ells_run_device(const double* x, double* y) { return ell_run(g_ell_stencil, x, y); }
-void ells_free() { g_ell_stencil.drop(); }
+void ells_free() {
+    release_cg_workspace();
+    g_ell_stencil.drop();
+}
 
 // ---- name table ------------------------------------------------------------------
 
@@ -335,6 +349,20 @@ SpmvOperator SPMV_STENCIL5_ELLPACK = {"stencil5-ellpack", ells_init, ells_run_ti
 SpmvOperator SPMV_STENCIL_HALO_MGPU = {"stencil5-halo-mgpu", stencil_init,
                                        run_timed_generic<stencil_run_device, &g_stencil>,
                                        stencil_run_device, stencil_free};
+
+namespace spmv_amd {
+FusedSpmv fused_spmv_of(const SpmvOperator* op) {
+    FusedSpmv f;
+    // (the row-generic kernel of small or unverified matrices keeps the plain dot kernel, as in the slab solver)
+    if ((op == &SPMV_STENCIL5_CSR || op == &SPMV_STENCIL_HALO_MGPU) && g_stencil.ready && g_stencil.plan.partials > 0 &&
+        g_stencil.plan.variant != Stencil5Variant::RowGeneric) {
+        f.partials = g_stencil.plan.partials;
+        f.can_init = g_stencil.plan.variant == Stencil5Variant::RowLds || g_stencil.plan.variant == Stencil5Variant::RowPlanes;
+        f.launch = stencil_fused_launch;
+    }
+    return f;
+}
+}  // namespace spmv_amd
 
 extern "C" SpmvOperator* get_operator(const char* mode) {
     switch (which_operator(mode)) {

@@ -1463,7 +1463,7 @@ void launch_csr_spmv(const SlabCsr& m, const double* x, double* y, double alpha,
             if (per_block > threads) per_block = threads;
             const long long blocks = (rows + per_block - 1) / per_block;
             // dispatch order: relabelling blocks so that an XCD takes runs of consecutive blocks measured SLOWER here
-            // (10 000^2: 1.35 ms plain, 1.40-1.45 ms for runs of 2-16; profiles/r02_xcd_group_ab.txt)
+            // (10 000^2: 1.35 ms plain, 1.40-1.45 ms for runs of 2-16; profiles/r02_xcd_group.txt)
             const int group = knobs.xcd_group > 0 ? knobs.xcd_group : 1;
             const long long span = group > 1 ? 8LL * group : 1;
             const dim3 grid((unsigned)((blocks + span - 1) / span * span));

@@ -15,6 +15,7 @@ namespace {
 using Clock = std::chrono::steady_clock;
 
 struct Frame {
+    unsigned long long id;  // handed to the scope that armed it: scopes of different host threads leave in any order
     const char* stage;
     int rank;
     int iteration;
@@ -30,6 +31,7 @@ struct State {
     std::mutex lock;
     Frame frames[kMaxDepth];
     int depth = 0;
+    unsigned long long next_id = 1;
     double limit_s = 60.0;
     bool thread_started = false;
 };
@@ -72,10 +74,13 @@ void patrol() {
         bool found = false;
         {
             std::lock_guard<std::mutex> g(st.lock);
-            // the innermost scope names where the rank is actually stuck; outer scopes are at least as old
-            if (st.depth > 0) {
-                const Frame& f = st.frames[st.depth - 1];
-                waited = std::chrono::duration<double>(Clock::now() - f.since).count();
+            // Within one thread the innermost scope names where the rank is actually stuck and outer scopes are at least
+            // as old; with scopes of several threads armed, any overdue frame is a finding: report the most recently
+            // armed one that is overdue.
+            const Clock::time_point now = Clock::now();
+            for (int k = st.depth - 1; k >= 0 && !found; --k) {
+                const Frame& f = st.frames[k];
+                waited = std::chrono::duration<double>(now - f.since).count();
                 if (waited > st.limit_s) {
                     overdue = f;
                     found = true;
@@ -95,7 +100,8 @@ WatchdogScope::WatchdogScope(const char* stage, int rank, int iteration, Watchdo
     if (!(st.limit_s > 0.0)) return;
     std::lock_guard<std::mutex> g(st.lock);
     if (st.depth >= kMaxDepth) return;
-    st.frames[st.depth++] = Frame{stage, rank, iteration, report, user, Clock::now()};
+    id_ = st.next_id++;
+    st.frames[st.depth++] = Frame{id_, stage, rank, iteration, report, user, Clock::now()};
     armed_ = true;
     if (!st.thread_started) {
         st.thread_started = true;
@@ -107,7 +113,13 @@ WatchdogScope::~WatchdogScope() {
     if (!armed_) return;
     State& st = state();
     std::lock_guard<std::mutex> g(st.lock);
-    if (st.depth > 0) --st.depth;
+    // remove THIS scope's frame, wherever it sits: another host thread may have armed a scope after it
+    for (int k = st.depth - 1; k >= 0; --k) {
+        if (st.frames[k].id != id_) continue;
+        for (int j = k; j + 1 < st.depth; ++j) st.frames[j] = st.frames[j + 1];
+        --st.depth;
+        break;
+    }
 }
 
 }  // namespace spmv_amd

@@ -29,6 +29,7 @@ public:
 
 private:
     bool armed_ = false;
+    unsigned long long id_ = 0;  // the frame this scope armed; frames are removed by id, so scopes of several host threads may overlap
 };
 
 double watchdog_limit_seconds();

@@ -321,6 +321,17 @@ const char* spmv_amd_cg_slab_variant(const SpmvAmdCgSlab* s);
 /* Average duration (HIP events on the solver's stream) of `reps` launches of the
  * slab SpMV kernel pair on the current direction vector. */
 int spmv_amd_cg_slab_time_spmv(SpmvAmdCgSlab* s, int reps, float* ms_each);
+/* Per-rank timeline of a solve: what the reference reports as max / min of six timers per rank
+ * (cg_solver_mgpu_partitioned.cu:748-800), taken here WITHOUT the per-stage host syncs its detailed timers need:
+ * with the timeline on, a solve records HIP events at the stage boundaries of every iteration (compute stream) and
+ * around every halo exchange (side stream) and resolves them after the loop, so the overlap of the exchange with the
+ * interior rows stays as it is in a timed solve. spmv_amd_cg_slab_timeline() returns the values of the last such
+ * solve -- averages per counted iteration, microseconds -- in the order of the comma-separated names
+ * spmv_amd_cg_slab_timeline_names() returns; 0 values if the last solve ran without the timeline. Each stage runs from
+ * the end of the previous stage's last kernel to the end of its own, so queue gaps are inside the stage that waits. */
+void spmv_amd_cg_slab_set_timeline(SpmvAmdCgSlab* s, int on);
+const char* spmv_amd_cg_slab_timeline_names(void);
+int spmv_amd_cg_slab_timeline(const SpmvAmdCgSlab* s, double* out, int cap);
 void spmv_amd_cg_slab_destroy(SpmvAmdCgSlab* s);
 
 /* write_matrix_market_stencil5 with other value texts (e.g. "-4.0", "-1.0": the convention

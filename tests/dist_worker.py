@@ -8,6 +8,9 @@ MASTER_ADDR / MASTER_PORT set, rendezvous over gloo on 127.0.0.1.
   mode gpu    : (GPU) libspmv_amd's slab solver, one rank per process sharing the box's single
                 GPU, over the staged communicator whose host callbacks are these gloo calls;
                 rank 0 checks against the oracle's partitioned CG.
+  mode gpu-rccl / gpu-rccl-mailbox : (>= WORLD_SIZE GPUs) one rank per DEVICE over the RCCL communicator -- ncclSend /
+                ncclRecv of the halo rows and ncclAllReduce (or the peer mailbox) between distinct devices, the path
+                of BASELINE config 4; rank 0 checks against the oracle's partitioned CG at 1e-10.
 """
 import ctypes as C
 import os
@@ -132,6 +135,48 @@ def run_gpu(n, rank, world, synthetic, mailbox=False):
     print(f"rank {rank}: slab solver over staged/gloo communicator ok")
 
 
+def run_gpu_rccl(n, rank, world, mailbox):
+    B = load_binding()
+    L = B.lib()
+    assert L.spmv_amd_device_count() >= world, "needs one device per rank"
+    L.spmv_amd_set_device(rank)
+    box = [B.Comm.unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    comm = B.Comm.rccl(rank, world, box[0])
+    assert comm is not None and comm.transport() == "rccl" and comm.transport_ranks() == world
+    assert comm.selftest() == 0  # all-reduce, neighbour send / recv, loopback, barrier -- between the devices
+    if mailbox:
+        assert comm.mailbox_enable() and comm.mailbox_ready()  # hipIpc mapping + 2048-round self-test across xGMI
+        assert comm.mailbox_selftest(3000) == 0
+    N = n * n
+    slab = B.CgSlab.stencil5(n, comm)
+    assert (slab.row_offset, slab.n_local) == O.partition_rows(N, world, rank)
+    rp, ci, va = O.stencil5_csr(n)
+    xo, ho, ro = O.cg_partitioned(rp, ci, va, n, np.ones(N), np.zeros(N), world=world) if rank == 0 else (None, None, None)
+    hists = []
+    for timers in (0, 1, 0):
+        st = slab.solve(timers=timers)
+        hist = slab.history()
+        hists.append(hist)
+        x = slab.gather()
+        if rank == 0:
+            assert st.iterations == ro.iterations and st.converged == 1, (st.iterations, ro.iterations)
+            assert hist_err(hist, ho) < 1e-10
+            assert np.max(np.abs(x - xo)) <= 1e-10 * np.max(np.abs(xo))
+    assert np.array_equal(hists[0], hists[2])  # fixed-shape reductions + rank-ordered sums: bit-reproducible
+    # every rank holds the same bits (the scalars come from all-reduced values)
+    everyone = [None] * world
+    dist.all_gather_object(everyone, [float(v).hex() for v in hists[0]])
+    assert all(e == everyone[0] for e in everyone)
+    # stage timeline with the overlap intact
+    st_t, tl = slab.timeline_solve()
+    assert tl and tl["iterations"] == st_t.iterations and tl["halo_exchange_on_side_stream_us"] > 0
+    slab.destroy()
+    comm.destroy()
+    print(f"rank {rank}: slab solver over RCCL between devices ok ({'peer mailbox' if mailbox else 'ncclAllReduce'}), "
+          f"halo exchange {tl['halo_exchange_on_side_stream_us']:.1f} us, iteration {tl['iteration_us']:.1f} us")
+
+
 def main():
     mode, n = sys.argv[1], int(sys.argv[2])
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
@@ -148,6 +193,10 @@ def main():
             run_gpu(n, rank, world, synthetic=False, mailbox=True)
         elif mode == "gpu-synthetic-mailbox":
             run_gpu(n, rank, world, synthetic=True, mailbox=True)
+        elif mode == "gpu-rccl":
+            run_gpu_rccl(n, rank, world, mailbox=False)
+        elif mode == "gpu-rccl-mailbox":
+            run_gpu_rccl(n, rank, world, mailbox=True)
         else:
             raise SystemExit(f"unknown mode {mode}")
     finally:

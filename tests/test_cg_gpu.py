@@ -1,5 +1,6 @@
 """Parity of the CG solvers with the CPU oracle: iteration counts equal, per-iteration ||r_k||
 within 1e-10 relative (BASELINE.json north_star), solution within 1e-10 of the oracle's."""
+import ctypes as C
 import os
 
 import numpy as np
@@ -135,18 +136,90 @@ def test_sweep_direction_alternation_changes_nothing(B, O, fresh_host_matrices, 
     assert out["0"][0] == out["1"][0] and np.array_equal(out["0"][1], out["1"][1]) and np.array_equal(out["0"][2], out["1"][2])
 
 
-def test_one_launch_reduction_gives_the_same_bits():
-    """SPMV_AMD_REDUCE_ONE_LAUNCH=1 (last-block reduction + scalar step in one launch; measured slower, kept
-    selectable) sums in the same order as the two-launch default: identical residual history."""
-    import json, subprocess, sys
-    from conftest import ROOT
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--grid", "1024", "--no-cpu-baseline", "--no-spmv"]
-    runs = []
-    for env_extra in ({}, {"SPMV_AMD_REDUCE_ONE_LAUNCH": "1"}):
-        out = subprocess.run(cmd, env=dict(os.environ, **env_extra), capture_output=True, text=True, timeout=600)
-        assert out.returncode == 0, out.stdout + out.stderr
-        runs.append(json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])["config"])
-    assert runs[0]["residual_history"] == runs[1]["residual_history"] and runs[0]["iterations_per_solve"] == runs[1]["iterations_per_solve"]
+@pytest.mark.parametrize("n", [130, 640])
+def test_cg_solve_device_runs_the_slab_solvers_loop(B, O, fresh_host_matrices, n):
+    """cg_solve_device (reference cg_solver.cu:436-706) is the slab solver's loop around the caller's operator. With
+    this library's stencil5-csr it takes the operator's fused launch and differs from the slab solver in ONE rounding
+    per element and iteration -- p = fma(beta, p, r) (update_p_kernel, cg_solver.cu:90-95) instead of
+    fma(1.0, r, beta*p) (mgpu :136-140) -- so the two histories agree far below the 1e-10 bar; with a random
+    right-hand side and a non-zero x0 it equals the oracle's device form; and a second call re-uses the cached vectors."""
+    rng = np.random.default_rng(n)
+    e = O.stencil5_coo(n)
+    m = B.HostMatrix(e, n * n, n * n, n)
+    op = B.Operator("stencil5-csr")
+    assert op.init(m) == 0
+    b, x0 = rng.standard_normal(n * n), 0.1 * rng.standard_normal(n * n)
+    x, hist, st = B.cg_solve(op, m, b, x0, device=True)
+    x2, hist2, st2 = B.cg_solve(op, m, b, x0, device=True)  # cached workspace, same bits
+    assert st2.iterations == st.iterations and np.array_equal(hist2, hist) and np.array_equal(x2, x)
+    rp, ci, va = O.build_csr(e, n * n)
+    xo, ho, ro = O.cg(rp, ci, va, n, b, x0, device_form=True)
+    assert st.iterations == ro.iterations and st.converged == 1 and hist_err(hist, ho) < TOL
+    assert np.max(np.abs(x - xo)) <= TOL * np.max(np.abs(xo))
+    slab = B.CgSlab.from_matrix(m)
+    slab.set_vectors(b, x0)
+    sst = slab.solve()
+    assert sst.iterations == st.iterations and hist_err(hist, slab.history()) < 1e-12
+    assert np.max(np.abs(x - slab.gather())) <= 1e-12 * np.max(np.abs(x))
+    slab.destroy()
+    op.free()
+
+
+def test_cg_solve_device_through_a_callers_own_operator_table(B, O, fresh_host_matrices):
+    """An SpmvOperator table this library does not own (here: a ctypes-made struct whose run_device forwards to the CSR
+    operator) offers nothing beyond run_device(d_x, d_y): the solver drives it through the vtable plus a dot kernel, and
+    still matches the oracle at 1e-10. Detailed timers fill the three categories without changing a bit."""
+    n = 200
+    m = B.HostMatrix(O.stencil5_coo(n), n * n, n * n, n)
+    real = B.Operator("cusparse-csr")
+    assert real.init(m) == 0
+    calls = []
+
+    def run_device(d_x, d_y):
+        calls.append(1)
+        return real.op.contents.run_device(d_x, d_y)
+
+    keep = (B.INIT_FN(lambda mat: 0), B.RUN_TIMED_FN(lambda x, y, ms: 1), B.RUN_DEVICE_FN(run_device), B.FREE_FN(lambda: None))
+    table = B.SpmvOperator(b"callers-own", *keep)
+
+    class Foreign:  # what B.cg_solve needs of an operator: a pointer to the table
+        op = C.pointer(table)
+
+    rp, ci, va = O.stencil5_csr(n)
+    x, hist, st = B.cg_solve(Foreign, m, np.ones(n * n), np.zeros(n * n), device=True)
+    check(O, rp, ci, va, n, hist, x, st)
+    assert len(calls) == st.iterations + 1  # one SpMV per iteration + the initial residual's, all through the vtable
+    x2, hist2, st2 = B.cg_solve(Foreign, m, np.ones(n * n), np.zeros(n * n), device=True, timers=1)
+    assert np.array_equal(hist2, hist) and np.array_equal(x2, x)
+    assert st2.time_spmv_ms > 0 and st2.time_blas1_ms > 0 and st2.time_reductions_ms > 0
+    # switching to the library's own stencil operator on the same workspace picks the fused launch up again
+    own = B.Operator("stencil5-csr")
+    assert own.init(m) == 0
+    x3, hist3, st3 = B.cg_solve(own, m, np.ones(n * n), np.zeros(n * n), device=True)
+    check(O, rp, ci, va, n, hist3, x3, st3)
+    own.free()
+    real.free()
+
+
+def test_slab_timeline_accounts_for_the_solve(B, O, fresh_host_matrices):
+    """spmv_amd_cg_slab_set_timeline: stage-boundary events without host syncs. The stages of an iteration add up to the
+    iteration, the iterations (+ initial residual + flush) to the solve, and the numbers are those of a plain solve."""
+    n = 1024
+    slab = B.CgSlab.stencil5(n)
+    st = slab.solve()
+    hist = slab.history().copy()
+    st_t, t = slab.timeline_solve()
+    names = B.lib().spmv_amd_cg_slab_timeline_names().decode().split(",")
+    assert list(t.keys()) == names and t["iterations"] == st.iterations == st_t.iterations
+    assert np.array_equal(slab.history(), hist)
+    stages = ["spmv_interior_us", "halo_wait_and_boundary_rows_us", "reduce_pAp_and_allreduce_us", "update_r_us",
+              "reduce_rr_allreduce_and_scalar_step_us", "direction_update_us", "gap_before_next_iteration_us"]
+    assert all(t[k] >= 0.0 for k in stages) and t["spmv_interior_us"] > 0 and t["update_r_us"] > 0
+    assert abs(sum(t[k] for k in stages) - t["iteration_us"]) <= 1e-3 * t["iteration_us"] + 1.0
+    whole = t["initial_residual_us"] + t["iterations"] * t["iteration_us"] + t["final_x_flush_us"]
+    assert 0.9 * whole <= t["solve_ms"] * 1e3 <= 1.1 * whole + 50.0
+    assert slab.solve().iterations == st.iterations and B.lib().spmv_amd_cg_slab_timeline(slab.h, None, 0) == 0  # off again
+    slab.destroy()
 
 
 def test_reference_entry_point_cg_solve_mgpu_partitioned(B, O, fresh_host_matrices):

@@ -185,6 +185,105 @@ def _json_lines(text):
     return [json.loads(l) for l in text.splitlines() if l.startswith("{")]
 
 
+TIMELINE_KEYS = ["iterations", "solve_ms", "initial_residual_us", "spmv_interior_us", "halo_wait_and_boundary_rows_us", "reduce_pAp_and_allreduce_us",
+                 "update_r_us", "reduce_rr_allreduce_and_scalar_step_us", "direction_update_us", "gap_before_next_iteration_us", "iteration_us",
+                 "halo_exchange_on_side_stream_us", "final_x_flush_us"]
+
+
+def check_multi_rank_line(line, world):
+    """What a multi-rank bench line must carry so that the number arrives with its own parity statement: the golden
+    comparison, the ranks' agreement, the per-rank stage breakdown and both all-reduce figures."""
+    assert line["value"] is not None and line["n_gpus"] == world and line["transport"] == "rccl"
+    assert line["allreduce"] == "ncclAllReduce"  # north_star's path is the headline
+    p = line["parity_vs_golden"]
+    assert p["available"] and p["ok"] and p["max_rel_err"] <= 1e-10 and p["iterations"] == p["golden_iterations"]
+    assert line["ranks_agree_on_history"] is True
+    b = line["breakdown"]
+    assert len(b["per_rank"]) == world and [r["rank"] for r in b["per_rank"]] == list(range(world))
+    for r in b["per_rank"]:
+        assert all(k in r for k in TIMELINE_KEYS) and r["spmv_interior_us"] > 0 and r["iteration_us"] > 0
+    assert set(TIMELINE_KEYS) - {"iterations"} <= set(b["max_over_ranks"]) and b["max_over_ranks"]["iteration_us"] >= b["min_over_ranks"]["iteration_us"]
+    ab = line["allreduce_ab"]
+    assert ab["headline"] == "rccl" and ab["rccl"] == line["ms_per_step"]
+    assert ab["mailbox"] is not None and ab["mailbox"] > 0, ab  # the child leg ran and passed its own parity gate
+    o = ab["other_leg"]
+    assert "peer mailbox" in o["allreduce"] and o["parity_vs_golden"]["ok"] and len(o["breakdown"]["per_rank"]) == world
+
+
+@pytest.mark.gpu
+def test_bench_multi_rank_line_carries_parity_breakdown_and_both_allreduce_legs():
+    """One GPU, the complete multi-rank pipeline (SPMV_AMD_BENCH_FORCE_DIST + SPMV_AMD_SELF_NEIGHBOUR: RCCL send / recv
+    of the halo rows on the side stream, split SpMV launches, ncclAllReduce of both dot products) on the 2000 x 2000 grid,
+    for which a golden history is committed: the line carries parity_vs_golden, the stage breakdown and allreduce_ab with
+    the mailbox leg measured in a child process."""
+    env = dict(os.environ, SPMV_AMD_BENCH_FORCE_DIST="1", SPMV_AMD_FORCE_COLLECTIVES="1", SPMV_AMD_SELF_NEIGHBOUR="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--grid", "2000",
+                          "--no-cpu-baseline", "--no-spmv"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = _json_lines(out.stdout)
+    assert len(lines) == 1
+    check_multi_rank_line(lines[0], 1)
+    assert lines[0]["breakdown"]["per_rank"][0]["halo_exchange_on_side_stream_us"] > 0
+    assert lines[0]["rccl_ranks"] == 1
+
+
+@pytest.mark.gpu
+def test_bench_refuses_a_history_that_misses_the_golden(tmp_path):
+    """parity gate: the same run against a golden history that is off by 1e-9 in one entry is UNMEASURED (exit 3)."""
+    golden = json.load(open(os.path.join(ROOT, "tests", "golden", "known_answers.json")))
+    golden["cases"]["512:5.0"]["cg"]["history"][3] *= 1.0 + 1e-9
+    bad = tmp_path / "known_answers.json"
+    bad.write_text(json.dumps(golden))
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--grid", "512", "--no-cpu-baseline", "--no-spmv"]
+    good = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert good.returncode == 0 and _json_lines(good.stdout)[-1]["parity_vs_golden"]["ok"], good.stdout + good.stderr
+    out = subprocess.run(cmd, env=dict(os.environ, SPMV_AMD_BENCH_GOLDEN=str(bad)), capture_output=True, text=True, timeout=600)
+    line = _json_lines(out.stdout)[-1]
+    assert out.returncode == 3 and line["value"] is None and "golden" in line["unmeasured"], out.stdout + out.stderr
+
+
+def gpus_visible():
+    from conftest import load_binding
+    B = load_binding()
+    return B.lib().spmv_amd_device_count() if os.path.exists(B.LIB_PATH) else 0
+
+
+def need_gpus(world):
+    have = gpus_visible()
+    if have < world:
+        pytest.skip(f"needs {world} MI355X in one node for RCCL between DISTINCT devices (BASELINE config 4); this box shows {have} -- "
+                    "the same solver, transport calls and bench.py logic run above on one GPU (staged ranks, self-neighbour RCCL rank)")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,n,mode", [(2, 512, "gpu-rccl"), (2, 2000, "gpu-rccl"), (2, 2000, "gpu-rccl-mailbox"), (4, 2000, "gpu-rccl"),
+                                          (4, 2000, "gpu-rccl-mailbox"), (8, 2048, "gpu-rccl"), (8, 2048, "gpu-rccl-mailbox")])
+def test_slab_solver_over_rccl_between_devices(world, n, mode):
+    """BASELINE config 4's data path on real links: one rank per device, halo rows by ncclSend / ncclRecv over xGMI on the
+    side stream, dot products by ncclAllReduce (or the peer mailbox: uncached memory mapped through hipIpc, system-scope
+    stores), against the oracle's partitioned CG at 1e-10, bit-reproducible, all ranks holding the same history."""
+    need_gpus(world)
+    outs = launch(world, mode, n, timeout=600)
+    assert all("slab solver over RCCL between devices ok" in o for o in outs)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_bench_over_rccl_between_devices(world):
+    """`python bench.py --gpus N` as the driver runs it, on N devices, at the 2000 x 2000 grid (golden history committed):
+    rccl_ranks == N, parity_vs_golden green, breakdown for every rank, both all-reduce legs."""
+    need_gpus(world)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("RANK", None), env.pop("WORLD_SIZE", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "3", "--warmup", "1", "--grid", "2000"],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = _json_lines(out.stdout)
+    assert len(lines) == 1 and lines[0]["rccl_ranks"] == world
+    check_multi_rank_line(lines[0], world)
+    assert len({d["pci_bus_id"] for d in lines[0]["devices"]}) == world  # distinct devices
+
+
 def test_bench_self_launches_its_ranks_and_fails_loudly_without_gpus():
     """`python bench.py --gpus 2`, the way the driver invokes it, with no GPU in sight: the parent starts two ranks
     (no torch, no GPU call in the parent), they rendezvous over gloo, agree that nothing can be measured, rank 0 prints

@@ -103,6 +103,20 @@ def test_symmetric_reader_expands(B, tmp_path):
     assert got == [(0, 0, 2.0), (0, 1, -1.0), (1, 0, -1.0), (1, 1, 2.0), (1, 2, -1.0), (2, 1, -1.0)]
 
 
+@pytest.mark.parametrize("body,what", [("3 3 2\n1 1 2.0\n4 1 -1.0\n", "row beyond the declared size"),
+                                       ("3 3 2\n1 1 2.0\n2 0 -1.0\n", "column index 0 in a 1-based file"),
+                                       ("3 4 2\n1 1 2.0\n2 4 -1.0\n", "a 'symmetric' file that is not square: the mirror of (2,4) is row 4 of 3")])
+def test_symmetric_reader_rejects_indices_outside_the_matrix(B, tmp_path, body, what):
+    """The mirrored entry uses the column as a row and the CSR arrays are indexed by row: a malformed file must end in
+    the reader's error (entries NULL, load_matrix_market -> 1), not in a write outside the arrays."""
+    bad = tmp_path / "bad.mtx"
+    bad.write_text("%%MatrixMarket matrix coordinate real symmetric\n" + body)
+    with pytest.raises(IOError):
+        B.load_matrix_market(str(bad))
+    with pytest.raises(IOError):
+        B.read_matrix_symtogen(str(bad))
+
+
 @pytest.mark.parametrize("name", ["sym_hand3.mtx", "sym_spd40.mtx", "sym_stencil8.mtx"])
 def test_symmetric_reader_matches_reference_symtogen(B, O, name):
     """read_matrix_symtogen against the reference's own reader (src/io/io.cu:189-310): against its committed output

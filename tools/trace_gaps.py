@@ -10,12 +10,32 @@ path = sys.argv[1]
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 14
 rows = list(csv.DictReader(open(path)))
 ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows), key=lambda e: e[0])
-# a solve starts with its initial SpMV: find the last kernel named cg_init_residual and back up one SpMV
-idx = [i for i, e in enumerate(ev) if "cg_init_residual" in e[2]]
-start = idx[-1] - 1
-while start > 0 and "stencil5" in ev[start - 1][2]:
-    start -= 1
-solve = ev[start:]
+# A solve starts with its initial SpMV. Anchors, in order of preference: the mode-2 SpMV launches (row-lds / row-planes
+# with the initial residual fused in: the default), else cg_init_residual (slabs that do not run row-lds) backed up
+# over the SpMV launches in front of it, else cg_scalars_init (which directly follows the initial reductions).
+def is_init_spmv(name):
+    return "stencil5_rowlds_kernel<2" in name or "stencil5_planes_kernel<2" in name
+
+
+idx = [i for i, e in enumerate(ev) if is_init_spmv(e[2])]
+if idx:
+    start = idx[-1]
+    while start > 0 and is_init_spmv(ev[start - 1][2]):  # interior + boundary-row launches of a split initial SpMV
+        start -= 1
+else:
+    idx = [i for i, e in enumerate(ev) if "cg_init_residual" in e[2]]
+    if idx:
+        start = idx[-1] - 1
+        while start > 0 and "stencil5" in ev[start - 1][2]:
+            start -= 1
+    else:
+        idx = [i for i, e in enumerate(ev) if "cg_scalars_init" in e[2]]
+        if not idx:
+            sys.exit("trace_gaps: no solve found in this trace (none of: mode-2 SpMV, cg_init_residual, cg_scalars_init)")
+        start = idx[-1]
+        while start > 0 and ("reduce_" in ev[start - 1][2] or "stencil5" in ev[start - 1][2] or "Generic" in ev[start - 1][2]):
+            start -= 1
+solve = ev[max(start, 0):]
 t_begin, t_end = solve[0][0], max(e[1] for e in solve)
 busy = collections.OrderedDict()
 covered, cursor, gaps = 0, solve[0][0], []
