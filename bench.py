@@ -392,7 +392,10 @@ def setup_process(args):
     c.multi = c.world > 1 or os.environ.get("SPMV_AMD_BENCH_FORCE_DIST") == "1"
     if c.multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo", rank=c.rank, world_size=c.world, timeout=datetime.timedelta(seconds=600))
+        if c.world == 1 and "MASTER_PORT" not in os.environ:  # SPMV_AMD_BENCH_FORCE_DIST without a launcher
+            os.environ["MASTER_PORT"] = str(free_port())
+        dist.init_process_group("gloo", rank=c.rank, world_size=c.world,
+                                timeout=datetime.timedelta(seconds=120 if args.leg_only else 600))
         dist.barrier()
     c.L = B.lib()
     return c
@@ -546,6 +549,12 @@ def other_allreduce_leg(c, kind, timeout_s):
     env = dict(os.environ, RANK=str(c.rank), LOCAL_RANK=str(c.local_rank), WORLD_SIZE=str(c.world), MASTER_ADDR="127.0.0.1",
                MASTER_PORT=str(port[0]))
     env.pop("SPMV_AMD_BENCH_TEST_CRASH_RANK", None)
+    # Under torch.distributed.run the ranks carry TORCHELASTIC_* variables; TORCHELASTIC_USE_AGENT_STORE makes env://
+    # rendezvous CONNECT to the launcher's store at MASTER_PORT instead of creating one. The children rendezvous among
+    # themselves on a fresh port, so they must not see any of that.
+    for k in [k for k in env if k.startswith("TORCHELASTIC_") or k in ("GROUP_RANK", "ROLE_RANK", "ROLE_NAME", "ROLE_WORLD_SIZE",
+                                                                        "GROUP_WORLD_SIZE", "TORCH_NCCL_ASYNC_ERROR_HANDLING")]:
+        env.pop(k)
     argv = [sys.executable, os.path.abspath(__file__), "--gpus", str(c.world), "--steps", str(c.args.steps), "--warmup", str(c.args.warmup),
             "--grid", str(c.args.grid), "--leg-only", kind]
     rec = None

@@ -83,7 +83,7 @@ DECLARED_SYMBOLS = [
     "cg_benchmark_with_stats_mgpu_partitioned", "export_cg_json", "export_cg_mgpu_json", "export_cg_csv",
     "spmv_amd_build_csr_struct", "spmv_amd_build_ellpack_from_csr_struct", "spmv_amd_cg_solve", "spmv_amd_cg_solve_device",
     "spmv_amd_cg_solve_mgpu_partitioned", "spmv_amd_reset_host_matrices", "spmv_amd_interior_csr_offset",
-    "spmv_amd_partition_rows", "spmv_amd_device_count", "spmv_amd_set_device", "spmv_amd_current_device", "spmv_amd_stream_ceiling", "spmv_amd_device_alloc", "spmv_amd_device_free",
+    "spmv_amd_partition_rows", "spmv_amd_device_count", "spmv_amd_set_device", "spmv_amd_current_device", "spmv_amd_stream_ceiling", "spmv_amd_stream_ceiling_mix", "spmv_amd_device_alloc", "spmv_amd_device_free",
     "spmv_amd_copy_to_device", "spmv_amd_copy_to_host", "spmv_amd_device_fill_f64", "spmv_amd_device_synchronize",
     "spmv_amd_init_stencil5_synthetic", "spmv_amd_ellpack_run_device_scaled", "spmv_amd_download_device_csr", "spmv_amd_time_run_device", "spmv_amd_operator_variant",
     "spmv_amd_operator_select_variant", "spmv_amd_cg_last_history", "spmv_amd_comm_unique_id", "spmv_amd_comm_create_rccl",
@@ -148,6 +148,8 @@ def lib():
     L.spmv_amd_current_device.argtypes = [C.c_char_p, C.c_int]
     L.spmv_amd_stream_ceiling.restype = C.c_double
     L.spmv_amd_stream_ceiling.argtypes = [C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_float)]
+    L.spmv_amd_stream_ceiling_mix.restype = C.c_double
+    L.spmv_amd_stream_ceiling_mix.argtypes = [C.c_int, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_float)]
     L.spmv_amd_copy_to_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     L.spmv_amd_copy_to_host.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     L.spmv_amd_device_fill_f64.argtypes = [C.c_void_p, C.c_size_t, C.c_double]
@@ -221,11 +223,12 @@ def current_device():
     return dev, buf.value.decode()
 
 
-def stream_ceiling(rows, warmup=3, reps=20):
-    """Per-launch milliseconds and bytes of the 48:8 stream probe (csrc/stream_ceiling.hip)."""
+def stream_ceiling(rows, warmup=3, reps=20, mix="stencil5"):
+    """Per-launch milliseconds and bytes of the stream probe (csrc/stream_ceiling.hip) for a format's byte mix:
+    "stencil5" 48:8 B/row, "csr" 72:8 (values, column indices, row pointers, x : y), "ellpack" 68:8."""
     require_gpu()
     ms = (C.c_float * reps)()
-    nbytes = lib().spmv_amd_stream_ceiling(int(rows), int(warmup), int(reps), ms)
+    nbytes = lib().spmv_amd_stream_ceiling_mix({"stencil5": 0, "csr": 1, "ellpack": 2}[mix], int(rows), int(warmup), int(reps), ms)
     if nbytes <= 0:
         raise RuntimeError("spmv_amd_stream_ceiling failed")
     return np.array(ms[:], dtype=np.float64), nbytes

@@ -23,6 +23,8 @@ Tunables read_tunables() {
     k.rowlds_group = env_int("SPMV_AMD_ROWLDS_GROUP", k.rowlds_group);
     if (k.rowlds_group < 0 || k.rowlds_group > 64) k.rowlds_group = 0;
     k.rowlds_we_lds = env_int("SPMV_AMD_ROWLDS_WE_LDS", k.rowlds_we_lds);
+    k.rowlds_rows = env_int("SPMV_AMD_ROWLDS_ROWS", k.rowlds_rows);
+    if (k.rowlds_rows != 2 && k.rowlds_rows != 4) k.rowlds_rows = 1;
     k.slab_planes = env_int("SPMV_AMD_SLAB_PLANES", k.slab_planes);
     k.direct_rows = env_int("SPMV_AMD_DIRECT_ROWS", k.direct_rows);
     if (k.direct_rows != 2 && k.direct_rows != 4) k.direct_rows = 1;

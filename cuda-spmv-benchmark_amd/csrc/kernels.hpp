@@ -40,6 +40,7 @@ struct Tunables {
     int rowlds_group = 0;         // consecutive row-lds tiles per XCD; 0 = derived from the grid (xcd_run_group())
     int slab_planes = 0;          // 1: solver slabs keep a plane copy of a verified stencil's coefficients and run
                                   // row-planes (measured slower in the CG loop than row-lds, see spmv_kernels.hip; off)
+    int rowlds_rows = 1;          // row-lds march: grid rows a wave walks with x rotating in registers (1 = the one-row kernel, 2, 4)
     int rowlds_we_lds = 1;        // row-lds: W / E neighbours from an LDS copy of the tile's x values (0 = two more global
                                   // loads per row): 20 000^2 3.67-3.71 -> 3.65-3.68 ms, 10 000^2 0.950 -> 0.925 ms, same bits
     int direct_rows = 1;          // grid rows per thread in row-direct (1, 2, 4)
@@ -105,6 +106,7 @@ struct Stencil5Plan {
     int tile_blocks = 0;
     bool oneshot = true;
     bool we_from_lds = false;  // row-lds: W / E neighbours from an LDS copy of the tile's x values
+    int lds_march_rows = 1;    // row-lds: > 1 = the march kernel, a wave walks this many consecutive grid rows
     int partials = 0;        // dot-partial slots one launch writes
     const char* name = "";   // "stencil5/row-lds", ...
 };

@@ -649,6 +649,251 @@ __global__ __launch_bounds__(64) void stencil5_rowlds_kernel(
 }
 
 // ---------------------------------------------------------------------------------
+// STENCIL5, row-lds MARCH (round 3, one bounded attempt at the x[row +- n] re-fetch; SPMV_AMD_ROWLDS_ROWS = 2 / 4).
+// The row-lds tile, but a wave owns the same 128 columns of kRows CONSECUTIVE grid rows and walks down them: the
+// north / centre / south values rotate in registers (xn <- xc <- xs), so a row's x line enters the wave once per
+// kRows + 2 rows instead of three times per row, whatever the XCD-private L2s make of it; the coefficient strip is
+// re-used row after row (LDS operations of one wave retire in order) and the NEXT row's ten coefficient loads and
+// south-row loads are issued before the current row is evaluated. Tile groups -> XCDs by the same run rule.
+// Per row the arithmetic, the clamped edge tiles, the LDS copy for W / E and the partial slot (one per row and
+// column tile, the slot the one-row kernel writes) are row-lds's: results and dot products are bit-identical.
+// Groups that are not kRows interior rows inside the launch's range (the grid's first / last row, the remainder at
+// the end of a range) fall back to row-lds's own per-row evaluation with fresh loads.
+// ---------------------------------------------------------------------------------
+template <int kMode, int kRows>
+__global__ __launch_bounds__(64) void stencil5_rowlds_march_kernel(
+    SlabCsr m, const double* __restrict__ x, double* __restrict__ y, double alpha, int gi_lo, int gi_hi, int gfirst,
+    int col_tiles, int total_groups, int group, int reverse, double* __restrict__ dot_partials,
+    const int* __restrict__ skip_flag, ResidualOut res) {
+    constexpr bool kDot = kMode == 1;
+    constexpr bool kInit = kMode == 2;
+    __shared__ double strip[5 * kLdsTileCols];
+    __shared__ double xrow[kLdsTileCols + 2];
+    const int skip = skip_flag != nullptr ? __builtin_nontemporal_load(skip_flag) : 0;
+    const int lane = (int)threadIdx.x;
+    const int b = (int)blockIdx.x;
+    const int span = 8 * group;
+    int tg = (b / span) * span + (b & 7) * group + ((b >> 3) % group);
+    if (tg >= total_groups) return;
+    if (reverse) tg = total_groups - 1 - tg;
+    const int n = m.grid_size;
+    const int row_group = tg / col_tiles;
+    const int col_tile = tg - row_group * col_tiles;
+    const int li0 = gi_lo + row_group * kRows;
+    const int j0 = col_tile * kLdsTileCols;
+    const int rows_here = min(kRows, gi_hi - li0);
+    const bool pure = rows_here == kRows && gfirst + li0 > 0 && gfirst + li0 + kRows - 1 < n - 1;
+    const bool edge_tile = j0 == 0 || j0 + kLdsTileCols > n - 1;
+    const double* __restrict__ vals = m.values;
+    const long long hi = m.nnz_local - 1;
+    const int ja = j0 + lane, jb = j0 + lane + 64;
+
+    // coefficient run of grid row gi for this tile: ten coalesced nontemporal loads (clamped on the row's edge tiles)
+    auto load_coefficients = [&](int gi, double (&c)[10]) {
+        const long long e = stencil_gridrow_base(gi, n) + 5LL * j0 - 1 - m.nnz_base + lane;
+        if (edge_tile) {
+#pragma unroll
+            for (int k = 0; k < 10; ++k) {
+                long long idx = e + 64 * k;
+                idx = idx < 0 ? 0 : (idx > hi ? hi : idx);
+                c[k] = __builtin_nontemporal_load(vals + idx);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 10; ++k) c[k] = __builtin_nontemporal_load(vals + e + 64 * k);
+        }
+    };
+    auto load_row = [&](int li, double (&v)[2]) {  // x of local grid row li at this lane's two columns (0 beyond n)
+        const double* __restrict__ xl = x + (long long)li * n;
+        v[0] = ja < n ? xl[ja] : 0.0;
+        v[1] = jb < n ? xl[jb] : 0.0;
+    };
+
+    if (pure) {
+        double c[10], cn[10], xn[2], xc[2], xs[2], xsn[2] = {0.0, 0.0};
+        load_coefficients(gfirst + li0, c);
+        load_row(li0 - 1, xn);
+        load_row(li0, xc);
+        load_row(li0 + 1, xs);
+        if (skip != 0) return;
+#pragma unroll
+        for (int r = 0; r < kRows; ++r) {
+            const int li = li0 + r;
+            const double* __restrict__ xl = x + (long long)li * n;
+            double bv[2] = {0.0, 0.0}, xw0 = 0.0, xe1 = 0.0;
+            // the tile's two outer neighbours and (mode 2) b: this row's only other loads
+            if (lane == 0 && ja > 0) xw0 = xl[ja - 1];
+            if (lane == 63 && jb < n - 1) xe1 = xl[jb + 1];
+            if (kInit) {
+                if (ja < n) bv[0] = __builtin_nontemporal_load(res.b + ((long long)li * n + ja));
+                if (jb < n) bv[1] = __builtin_nontemporal_load(res.b + ((long long)li * n + jb));
+            }
+            if (r + 1 < kRows) {  // next row's streams go out before this row is evaluated
+                load_coefficients(gfirst + li + 1, cn);
+                load_row(li + 2, xsn);
+            }
+#pragma unroll
+            for (int k = 0; k < 10; ++k) strip[64 * k + lane] = c[k];
+            xrow[1 + lane] = xc[0];
+            xrow[65 + lane] = xc[1];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            double xw[2], xe[2];
+            xw[0] = lane > 0 ? xrow[lane] : xw0;
+            xe[0] = xrow[2 + lane];
+            xw[1] = xrow[64 + lane];
+            xe[1] = lane < 63 ? xrow[66 + lane] : xe1;
+            if (ja == n - 1) xe[0] = 0.0;
+            double dot_acc = 0.0;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int j = j0 + lane + 64 * h;
+                if (j < n) {
+                    const double* __restrict__ v = strip + 5 * (lane + 64 * h);
+                    double sum;
+                    if (j > 0 && j < n - 1) {            // [N,W,C,E,S], evaluated W,C,E,N,S
+                        sum = v[1] * xw[h];
+                        sum = fma(v[2], xc[h], sum);
+                        sum = fma(v[3], xe[h], sum);
+                        sum = fma(v[0], xn[h], sum);
+                        sum = fma(v[4], xs[h], sum);
+                    } else if (j == 0) {                 // [N,C,E,S] at strip positions 1..4, CSR-loop order
+                        sum = fma(v[1], xn[h], 0.0);
+                        sum = fma(v[2], xc[h], sum);
+                        sum = fma(v[3], xe[h], sum);
+                        sum = fma(v[4], xs[h], sum);
+                    } else {                             // j == n-1: [N,W,C,S], CSR-loop order
+                        sum = fma(v[0], xn[h], 0.0);
+                        sum = fma(v[1], xw[h], sum);
+                        sum = fma(v[2], xc[h], sum);
+                        sum = fma(v[3], xs[h], sum);
+                    }
+                    if (kDot) dot_acc = fma(xc[h], sum, dot_acc);
+                    const long long lr = (long long)li * n + j;
+                    if (kInit) {
+                        const double rv = fma(-1.0, alpha * sum, bv[h]);
+                        __builtin_nontemporal_store(rv, res.r + lr);
+                        res.p[lr] = rv;
+                        dot_acc = fma(rv, rv, dot_acc);
+                    } else {
+                        __builtin_nontemporal_store(alpha * sum, y + lr);
+                    }
+                }
+            }
+            if (kDot || kInit) {
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) dot_acc += __shfl_down(dot_acc, off);
+                if (lane == 0) dot_partials[(long long)(li - gi_lo) * col_tiles + col_tile] = dot_acc;
+            }
+            if (r + 1 < kRows) {
+#pragma unroll
+                for (int k = 0; k < 10; ++k) c[k] = cn[k];
+                xn[0] = xc[0], xn[1] = xc[1];
+                xc[0] = xs[0], xc[1] = xs[1];
+                xs[0] = xsn[0], xs[1] = xsn[1];
+                // the strip and the x copy are rewritten next: this wave's reads above have retired (in-order LDS)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        return;
+    }
+
+    // not a full group of interior rows: every row on its own, as the one-row kernel evaluates it
+    if (skip != 0) return;
+    for (int r = 0; r < rows_here; ++r) {
+        const int li = li0 + r;
+        const int gi = gfirst + li;
+        double dot_acc = 0.0;
+        if (gi > 0 && gi < n - 1) {
+            double c[10], xn[2], xc[2], xs[2];
+            load_coefficients(gi, c);
+            load_row(li - 1, xn);
+            load_row(li, xc);
+            load_row(li + 1, xs);
+            const double* __restrict__ xl = x + (long long)li * n;
+            double xw0 = 0.0, xe1 = 0.0;
+            if (lane == 0 && ja > 0) xw0 = xl[ja - 1];
+            if (lane == 63 && jb < n - 1) xe1 = xl[jb + 1];
+#pragma unroll
+            for (int k = 0; k < 10; ++k) strip[64 * k + lane] = c[k];
+            xrow[1 + lane] = xc[0];
+            xrow[65 + lane] = xc[1];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            double xw[2], xe[2];
+            xw[0] = lane > 0 ? xrow[lane] : xw0;
+            xe[0] = xrow[2 + lane];
+            xw[1] = xrow[64 + lane];
+            xe[1] = lane < 63 ? xrow[66 + lane] : xe1;
+            if (ja == n - 1) xe[0] = 0.0;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int j = j0 + lane + 64 * h;
+                if (j < n) {
+                    const double* __restrict__ v = strip + 5 * (lane + 64 * h);
+                    double sum;
+                    if (j > 0 && j < n - 1) {
+                        sum = v[1] * xw[h];
+                        sum = fma(v[2], xc[h], sum);
+                        sum = fma(v[3], xe[h], sum);
+                        sum = fma(v[0], xn[h], sum);
+                        sum = fma(v[4], xs[h], sum);
+                    } else if (j == 0) {
+                        sum = fma(v[1], xn[h], 0.0);
+                        sum = fma(v[2], xc[h], sum);
+                        sum = fma(v[3], xe[h], sum);
+                        sum = fma(v[4], xs[h], sum);
+                    } else {
+                        sum = fma(v[0], xn[h], 0.0);
+                        sum = fma(v[1], xw[h], sum);
+                        sum = fma(v[2], xc[h], sum);
+                        sum = fma(v[3], xs[h], sum);
+                    }
+                    if (kDot) dot_acc = fma(xc[h], sum, dot_acc);
+                    const long long lr = (long long)li * n + j;
+                    if (kInit) {
+                        const double rv = fma(-1.0, alpha * sum, res.b[lr]);
+                        __builtin_nontemporal_store(rv, res.r + lr);
+                        res.p[lr] = rv;
+                        dot_acc = fma(rv, rv, dot_acc);
+                    } else {
+                        __builtin_nontemporal_store(alpha * sum, y + lr);
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        } else {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int j = j0 + lane + 64 * h;
+                if (j < n) {
+                    const long long lr = (long long)li * n + j;
+                    const double sum = row_reference<false>(m, x, (int)lr, gi, j);
+                    if (kDot) dot_acc = fma(x[lr], sum, dot_acc);
+                    if (kInit) {
+                        const double rv = fma(-1.0, alpha * sum, res.b[lr]);
+                        res.r[lr] = rv;
+                        res.p[lr] = rv;
+                        dot_acc = fma(rv, rv, dot_acc);
+                    } else {
+                        y[lr] = alpha * sum;
+                    }
+                }
+            }
+        }
+        if (kDot || kInit) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) dot_acc += __shfl_down(dot_acc, off);
+            if (lane == 0) dot_partials[(long long)(li - gi_lo) * col_tiles + col_tile] = dot_acc;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // STENCIL5, row-planes variant (solver slabs; SlabCsr::planes). Index space, tile -> XCD runs, x handling, the three
 // modes and the arithmetic are row-lds's; the coefficients come from five planes [N | W | C | E | S] instead of the
 // CSR values array, so every coefficient load is a coalesced 8-byte-per-lane stream starting on a 1 KiB boundary and
@@ -851,8 +1096,8 @@ __global__ __launch_bounds__(kBlock) void csr_row_scalar_kernel(SlabCsr m, const
 // consecutive entries (fully coalesced 4- and 8-byte loads, no dependence on the per-row row_ptr),
 // gathers x and parks (value, x) in LDS; phase 2 gives each row to one thread, which folds its
 // entries from LDS with fma in ascending order -- the sequential sum of csr_spmv_kernel, bit for
-// bit. A span that does not fit the LDS strip (very long rows) is walked by the chunked
-// thread-per-row loop instead. This is the shape of the "stream" half of CSR-adaptive
+// bit. A span that does not fit the LDS strip (very long rows) is walked in strip-sized chunks,
+// each thread carrying its row's running sum from chunk to chunk. This is the shape of the "stream" half of CSR-adaptive
 // (Greathouse & Daga, SC'14), without a preprocessing pass: the row count per block is fixed per
 // matrix from its mean row length.
 // kThreads threads fetch kPerThread entries each in phase 1 (LDS: 16 B per entry).
@@ -903,24 +1148,39 @@ __global__ __launch_bounds__(kThreads) void csr_stream_kernel(SlabCsr m, const d
             for (int k = k0 - kb; k < k1 - kb; ++k) sum = fma(sv[k], sx[k], sum);
             y[row] = alpha * sum;
         }
-    } else if (has_row) {
+    } else {
+        // The block's span does not fit the strip (long rows): walk it in strip-sized chunks. Every chunk is fetched like
+        // the single-chunk case -- coalesced index / value loads, gathers, LDS -- and every thread folds the part of ITS
+        // row that lies in the chunk, continuing its running sum: still the sequential sum of csr_spmv_kernel, bit for bit,
+        // but a 20 000-entry row now costs its thread 20 passes over LDS instead of 2 500 dependent trips to memory.
+        // (Round 2 walked such rows with the chunked thread-per-row loop, one thread serialising the whole row.)
         double sum = 0.0;
-        for (int base = k0; base < k1; base += 8) {
-            int cc[8];
-            double vv[8], xx[8];
+        for (int base = kb; base < ke; base += kCsrStreamCap) {
+            const int end = min(base + kCsrStreamCap, ke);
+            int c[kCsrStreamPerThread];
+            double v[kCsrStreamPerThread], xv[kCsrStreamPerThread];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const bool live = base + u < k1;
-                cc[u] = live ? m.col_idx[base + u] : m.row_offset;
-                vv[u] = live ? m.values[base + u] : 0.0;
+            for (int u = 0; u < kCsrStreamPerThread; ++u) {
+                const int e = base + (int)threadIdx.x + u * kThreads;
+                const bool live = e < end;
+                c[u] = live ? m.col_idx[e] : m.row_offset;
+                v[u] = live ? m.values[e] : 0.0;
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) xx[u] = x_at(x, (long long)cc[u] - m.row_offset, lo, hi);
+            for (int u = 0; u < kCsrStreamPerThread; ++u) xv[u] = x_at(x, (long long)c[u] - m.row_offset, lo, hi);
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (base + u < k1) sum = fma(vv[u], xx[u], sum);
+            for (int u = 0; u < kCsrStreamPerThread; ++u) {
+                sv[threadIdx.x + u * kThreads] = v[u];
+                sx[threadIdx.x + u * kThreads] = xv[u];
+            }
+            __syncthreads();
+            if (has_row) {
+                const int from = max(k0, base), to = min(k1, end);
+                for (int k = from; k < to; ++k) sum = fma(sv[k - base], sx[k - base], sum);
+            }
+            __syncthreads();  // the strip is overwritten by the next chunk
         }
-        y[row] = alpha * sum;
+        if (has_row) y[row] = alpha * sum;
     }
 }
 
@@ -1185,6 +1445,9 @@ Stencil5Plan plan_stencil5(const SlabCsr& m, int first_row, int last_row, Stenci
         p.rows_per_task = knobs.rowlds_group > 0 ? knobs.rowlds_group : xcd_run_group(n, kLdsTileCols, 4);
         p.we_from_lds = knobs.rowlds_we_lds != 0;
         if (p.rows_per_task < 1 || p.rows_per_task > 64) p.rows_per_task = 4;
+        // row-lds march (SPMV_AMD_ROWLDS_ROWS = 2 / 4): only where a wave has several grid rows to walk
+        p.lds_march_rows = (variant == Stencil5Variant::RowLds && (knobs.rowlds_rows == 2 || knobs.rowlds_rows == 4) &&
+                            p.gi_hi - p.gi_lo >= knobs.rowlds_rows) ? knobs.rowlds_rows : 1;
     } else if (variant == Stencil5Variant::WaveTile) {
         // one tile per wave in dispatch order by default (4.65 ms at 20 000^2); SPMV_AMD_WAVETILE_ONESHOT=0
         // selects the persistent, XCD-banded walk (5.87 ms), kept for the record
@@ -1313,6 +1576,31 @@ int launch_stencil5_spmv(const SlabCsr& m, const Stencil5Plan& p, const double* 
             else SPMV_AMD_LAUNCH_PLANES(0, false);
         }
 #undef SPMV_AMD_LAUNCH_PLANES
+        return (int)tiles;
+    }
+
+    if (p.variant == Stencil5Variant::RowLds && p.lds_march_rows > 1) {
+        // row-lds march: a wave walks lds_march_rows consecutive grid rows of its 128 columns (same partial slots)
+        const int R = p.lds_march_rows;
+        const long long tiles = (long long)p.row_blocks * (p.gi_hi - p.gi_lo);
+        const long long groups = (long long)p.row_blocks * ((p.gi_hi - p.gi_lo + R - 1) / R);
+        const int span = 8 * p.rows_per_task;
+        const dim3 grid((unsigned)((groups + span - 1) / span * span));
+        const int gfirst = m.row_offset / n;
+        const ResidualOut res = init ? *init : ResidualOut{nullptr, nullptr, nullptr};
+#define SPMV_AMD_LAUNCH_MARCHLDS(MODE, ROWS)                                                                              \
+    hipLaunchKernelGGL((stencil5_rowlds_march_kernel<MODE, ROWS>), grid, dim3(64), 0, stream, m, x, y, alpha, p.gi_lo, p.gi_hi, \
+                       gfirst, p.row_blocks, (int)groups, p.rows_per_task, reverse ? 1 : 0, d_dot_partials, d_skip_flag, res)
+        if (R == 2) {
+            if (init) SPMV_AMD_LAUNCH_MARCHLDS(2, 2);
+            else if (dot) SPMV_AMD_LAUNCH_MARCHLDS(1, 2);
+            else SPMV_AMD_LAUNCH_MARCHLDS(0, 2);
+        } else {
+            if (init) SPMV_AMD_LAUNCH_MARCHLDS(2, 4);
+            else if (dot) SPMV_AMD_LAUNCH_MARCHLDS(1, 4);
+            else SPMV_AMD_LAUNCH_MARCHLDS(0, 4);
+        }
+#undef SPMV_AMD_LAUNCH_MARCHLDS
         return (int)tiles;
     }
 

@@ -174,6 +174,10 @@ int spmv_amd_device_synchronize(void);
  * structure -- on the benchmark's own data. `warmup` untimed launches over `rows` rows, then `reps` launches
  * timed one by one with HIP events on the launch stream (ms_each[reps]). Returns bytes moved per launch. */
 double spmv_amd_stream_ceiling(size_t rows, int warmup, int reps, float* ms_each);
+/* The same probe for the byte mix of another format at five entries per row: mix 0 = STENCIL5 (56 B/row, as above),
+ * 1 = CSR (80 B/row: values, column indices, row pointers, x, y), 2 = ELLPACK width 5 (76 B/row). The index
+ * streams are read, nothing is gathered through them: what the streams alone cost on this GPU. */
+double spmv_amd_stream_ceiling_mix(int mix, size_t rows, int warmup, int reps, float* ms_each);
 
 /* ---- operators on synthetic, device-generated matrices ---- */
 

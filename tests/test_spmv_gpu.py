@@ -108,6 +108,9 @@ def test_csr_operator(B, O, fresh_host_matrices, variant):
     mats.append((e, r, c, -1, np.random.default_rng(3).standard_normal(c)))
     e, r, c = M.random_sparse(1000, 777, 33, seed=9)
     mats.append((e, r, c, -1, np.random.default_rng(4).standard_normal(c)))
+    # rows far longer than the stream kernel's 1024-entry LDS strip (its chunked walk), next to short and empty ones
+    e, r, c = M.random_sparse(300, 6000, lambda row, rng: 3500 if row in (0, 137) else (0 if row % 11 == 0 else int(rng.integers(1, 9))), seed=12)
+    mats.append((e, r, c, -1, np.random.default_rng(6).standard_normal(c)))
     for e, r, c, grid, x in mats:
         B.lib().spmv_amd_reset_host_matrices()
         m = B.HostMatrix(e, r, c, grid)
@@ -250,3 +253,55 @@ def test_ellpack_alpha_beta_contract(B, O, fresh_host_matrices, name):
             assert np.max(np.abs(got - want)) <= 4e-16 * np.max(np.abs(want)) * 4
         dx.free(), dy.free()
     op.free()
+
+
+@pytest.mark.parametrize("rows", [2, 4])
+@pytest.mark.parametrize("n,min_grid", [(640, None), (513, None), (1029, None), (130, "2"), (259, "2"), (7, "2")])
+def test_rowlds_march_is_bit_exact(B, O, fresh_host_matrices, monkeypatch, rows, n, min_grid):
+    """SPMV_AMD_ROWLDS_ROWS = 2 / 4: a wave walks that many consecutive grid rows with north / centre / south x values
+    rotating in registers. Same per-row arithmetic, so bit-exact against the oracle on random coefficients -- grids whose
+    row count is not a multiple of the march (remainder group), whose first / last row falls inside a group, edge tiles
+    that are clamped, and grids narrower than one tile (forced onto row-lds through SPMV_AMD_ROWLDS_MIN_GRID)."""
+    monkeypatch.setenv("SPMV_AMD_ROWLDS_ROWS", str(rows))
+    if min_grid:
+        monkeypatch.setenv("SPMV_AMD_ROWLDS_MIN_GRID", min_grid)
+    e, x = random_stencil(O, n, 100 * rows + n)
+    m = B.HostMatrix(e, n * n, n * n, n)
+    op = B.Operator("stencil5-csr")
+    assert op.init(m) == 0 and op.variant() == "stencil5/row-lds"
+    rp, ci, va = O.build_csr(e, n * n)
+    want = O.spmv_stencil5(rp, ci, va, x, n)
+    got, _ = op.run_timed(x)
+    assert np.array_equal(got, want)
+    op.free()
+
+
+@pytest.mark.parametrize("rows", [2, 4])
+def test_rowlds_march_in_the_solver_changes_no_bit(B, O, fresh_host_matrices, monkeypatch, rows):
+    """The march kernel writes the dot partials into the one-row kernel's slots: residual history and solution of the slab
+    solver (fused p.Ap partials, fused initial residual, alternating sweep direction) are bit-identical with and
+    without it -- on the whole grid and on a stand-in slab whose SpMV is split into interior + halo rows."""
+    def solve(n, as_rank=None, as_world=None):
+        B.lib().spmv_amd_reset_host_matrices()
+        if as_world is None:
+            slab, comm = B.CgSlab.stencil5(n), None
+        else:
+            comm = B.Comm.rccl(0, 1, B.Comm.unique_id())
+            slab = B.CgSlab.stencil5_as(n, as_rank, as_world, comm)
+        st = slab.solve(max_iters=9, tol=0.0) if as_world else slab.solve()
+        out = (st.iterations, slab.history().copy(), slab.gather().copy() if as_world is None else None)
+        slab.destroy()
+        if comm:
+            comm.destroy()
+        return out
+
+    monkeypatch.setenv("SPMV_AMD_SELF_NEIGHBOUR", "1")
+    monkeypatch.setenv("SPMV_AMD_FORCE_COLLECTIVES", "1")
+    for args in ((641,), (1024, 1, 4), (642, 0, 2)):
+        monkeypatch.setenv("SPMV_AMD_ROWLDS_ROWS", "1")
+        base = solve(*args)
+        monkeypatch.setenv("SPMV_AMD_ROWLDS_ROWS", str(rows))
+        got = solve(*args)
+        assert got[0] == base[0] and np.array_equal(got[1], base[1]), args
+        if base[2] is not None:
+            assert np.array_equal(got[2], base[2]), args

@@ -26,6 +26,14 @@ algorithmic = {
     "stencil5-ellpack": rows * 5 * 8 + 16 * rows,
 }
 effective = 12 * nnz + 4 * (rows + 1) + 16 * rows
+# what this GPU sustains for each format's byte mix with ideal accesses (csrc/stream_ceiling.hip), same row count
+MIX = {"stencil5-csr": "stencil5", "stencil5-ellpack": "stencil5", "cusparse-csr": "csr", "ellpack": "ellpack"}
+ceilings = {}
+if os.environ.get("SPMV_AMD_COMPARE_CEILINGS", "1") != "0":
+    for mix in sorted({MIX[m] for m in modes}):
+        ms, nbytes = B.stream_ceiling(rows, warmup=3, reps=10, mix=mix)
+        ceilings[mix] = nbytes / float(np.median(ms)) / 1e6
+        print(f"stream ceiling, {mix:8s} byte mix: {float(np.median(ms)):8.3f} ms  {ceilings[mix]:8.1f} GB/s ({ceilings[mix] / 8000.0:.3f} of 8 TB/s)")
 out = []
 for mode in modes:
     op = B.Operator(mode)
@@ -38,8 +46,12 @@ for mode in modes:
     rec = {"operator": mode, "variant": op.variant(), "grid": n, "median_ms": med, "gflops": 2.0 * nnz / med / 1e6,
            "effective_gbs_reference_formula": effective / med / 1e6, "algorithmic_bytes": algorithmic[mode],
            "algorithmic_gbs": algorithmic[mode] / med / 1e6, "frac_of_8TBs": algorithmic[mode] / med / 1e6 / 8000.0}
+    if MIX[mode] in ceilings:
+        rec["ceiling_gbs"] = ceilings[MIX[mode]]
+        rec["frac_of_ceiling"] = rec["algorithmic_gbs"] / ceilings[MIX[mode]]
     out.append(rec)
     print(f"{mode:18s} {rec['variant']:22s} {med:8.3f} ms  eff {rec['effective_gbs_reference_formula']:8.1f} GB/s  "
-          f"alg {rec['algorithmic_gbs']:8.1f} GB/s ({rec['frac_of_8TBs']:.3f} of 8 TB/s)")
+          f"alg {rec['algorithmic_gbs']:8.1f} GB/s ({rec['frac_of_8TBs']:.3f} of 8 TB/s"
+          + (f", {rec['frac_of_ceiling']:.3f} of the measured {MIX[mode]}-mix ceiling)" if "frac_of_ceiling" in rec else ")"))
     dx.free(), dy.free(), op.free()
 print(json.dumps(out))

@@ -37,4 +37,7 @@ B.lib().spmv_amd_device_synchronize()
 ms = (time.perf_counter() - t0) / solves * 1e3
 print(f"slab {r} of {P} ({slab.n_local} rows), all-reduce {allreduce}: {ms:.3f} ms per 14-iteration solve, "
       f"{ms / 14 * 1e3:.1f} us per iteration, SpMV {st.time_spmv_ms / st.iterations * 1e3:.1f} us per launch")
+# the solver's own stage timeline (HIP events at the stage boundaries, no host syncs): one more solve
+st_t, tl = slab.timeline_solve(max_iters=14, tol=0.0)
+print("stage timeline of one extra solve (us per iteration unless named otherwise): " + ", ".join(f"{k}={v:.1f}" for k, v in tl.items()))
 slab.destroy()
