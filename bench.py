@@ -214,7 +214,7 @@ def cpu_baseline(sample_grid, full_rows):
     return rec
 
 
-def scaling_probe(B, torch, grid, full_ms, full_iterations, steps=5, use_mailbox=True):
+def scaling_probe(B, torch, grid, full_ms, full_iterations, steps=5):
     """What ONE GPU can say about strong scaling (N = 1 only; a projection). For P = 2, 4, 8 the real slab of the
     edge rank (one neighbour) and of a middle rank (two neighbours) of this grid -- rows [r*N/P, (r+1)*N/P), same CSR
     bytes, `grid`-double halos -- is solved for exactly `full_iterations` iterations through the complete multi-rank
@@ -230,8 +230,6 @@ def scaling_probe(B, torch, grid, full_ms, full_iterations, steps=5, use_mailbox
     os.environ["SPMV_AMD_SELF_NEIGHBOUR"] = os.environ["SPMV_AMD_FORCE_COLLECTIVES"] = "1"
     try:
         comm = B.Comm.rccl(0, 1, B.Comm.unique_id())
-        if comm is not None and use_mailbox:
-            out["mailbox"] = bool(comm.mailbox_enable())  # world = 1: the launch cost of the mailbox path, no peer latency
     finally:
         for k, v in saved.items():
             if v is None:
@@ -260,7 +258,8 @@ def scaling_probe(B, torch, grid, full_ms, full_iterations, steps=5, use_mailbox
         slab.destroy()
         return rec
 
-    out["allreduce_path"] = "peer mailbox (one rank: launch cost only)" if out.get("mailbox") else "ncclAllReduce (one rank: launch cost only)"
+    # the headline path of a multi-GPU run: two ncclAllReduce launches per iteration (with one rank: their launch cost only)
+    out["allreduce_path"] = "ncclAllReduce (one rank: launch cost only)"
     for P in (2, 4, 8):
         ranks = sorted({0, min(P - 1, max(1, P // 2 - 1))})  # edge rank and (P > 2) one with two neighbours: 1 of 4, 3 of 8
         roles = [run(P, r) for r in ranks]
@@ -268,11 +267,12 @@ def scaling_probe(B, torch, grid, full_ms, full_iterations, steps=5, use_mailbox
         eff = {f"{lat}us": full_ms / (P * (slowest + out["allreduces_per_solve"] * lat / 1e3)) for lat in (0, 5, 10, 25, 50)}
         out["slabs"].append({"gpus": P, "roles": roles, "slowest_role_ms_per_solve": slowest,
                              "ideal_ms_per_solve": full_ms / P, "projected_efficiency_by_allreduce_latency": eff})
-    if out.get("mailbox"):
-        # the same P = 8 slabs with the mailbox off: what two ncclAllReduce launches per iteration cost on this GPU
-        comm.mailbox_disable()
+    if comm.mailbox_enable():
+        # the same P = 8 slabs with the peer mailbox (world = 1: its launch cost, no peer latency): what folding the two
+        # all-reduces into the reduction kernels saves on this GPU
         roles = [run(8, r) for r in (0, 3)]
-        out["p8_with_nccl_allreduce_launches"] = {"roles": roles, "slowest_role_ms_per_solve": max(v["ms_per_solve"] for v in roles)}
+        out["p8_with_peer_mailbox"] = {"roles": roles, "slowest_role_ms_per_solve": max(v["ms_per_solve"] for v in roles)}
+        comm.mailbox_disable()
     comm.destroy()
     return out
 

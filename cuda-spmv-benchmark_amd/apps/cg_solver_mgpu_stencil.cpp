@@ -69,9 +69,11 @@ int main(int argc, char** argv) {
             fprintf(stderr, "[Rank %d] communicator self-test failed\n", rank);
             return 1;
         }
-        // dot-product all-reduces: peer mailbox when every rank's self-test passes, ncclAllReduce otherwise
+        // dot-product all-reduces: ncclAllReduce on the device scalars (what the reference's MPI_Allreduce becomes,
+        // cg_solver_mgpu_partitioned.cu:531,583,645). SPMV_AMD_ALLREDUCE=mailbox opts into the peer mailbox (stores
+        // between the GPUs; self-tested, all-or-nothing) -- opt-in until a run between distinct devices is on record.
         const char* ar = getenv("SPMV_AMD_ALLREDUCE");
-        const int mailbox = (ar && !strcmp(ar, "rccl")) ? 0 : spmv_amd_comm_mailbox_enable(comm);
+        const int mailbox = (ar && !strcmp(ar, "mailbox")) ? spmv_amd_comm_mailbox_enable(comm) : 0;
         if (rank == 0)
             printf("Transport: %s over %d ranks; dot-product all-reduce: %s\n", spmv_amd_comm_transport(comm),
                    spmv_amd_comm_transport_ranks(comm), mailbox ? "peer mailbox (stores between the GPUs)" : "ncclAllReduce");
