@@ -125,6 +125,7 @@ struct SpmvAmdCgSlab {
     bool pingpong = true;
     bool roctx_always = false;  // SPMV_AMD_ROCTX=1: roctx ranges even without detailed timers
     bool no_overlap = false;  // SPMV_AMD_NO_OVERLAP=1: halo exchange on the compute stream, for A/B runs of the overlap
+    bool early_halo = true;   // SPMV_AMD_EARLY_HALO=0: halo exchange only after the whole direction update (round 2's order)
     int poll_sequence = 0;
     double last_spmv_ms = 0.0;
     int last_spmv_launches = 0;
@@ -237,6 +238,7 @@ void make_common(SpmvAmdCgSlab* s) {
     if (const char* v = getenv("SPMV_AMD_SPMV_EVENT_STRIDE")) s->spmv_event_stride = atoi(v);
     if (const char* v = getenv("SPMV_AMD_PINGPONG")) s->pingpong = v[0] == '1';
     if (const char* v = getenv("SPMV_AMD_NO_OVERLAP")) s->no_overlap = v[0] == '1';
+    if (const char* v = getenv("SPMV_AMD_EARLY_HALO")) s->early_halo = v[0] != '0';
     if (const char* v = getenv("SPMV_AMD_ROCTX")) s->roctx_always = v[0] == '1';
     s->partials_blas = device_alloc<double>(dot_scratch_doubles(nl));
     s->reduce_stage = device_alloc<double>((size_t)reduce_stage_doubles());
@@ -756,9 +758,35 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
 
         // p <- r + beta p, its halo exchange, and (when overlapping) nothing else before the host
         // looks at the status: the GPU works on these while the host waits for the record.
+        // Early halo (round 3): the rows the neighbours need -- the slab's first / last grid row -- are updated by two
+        // small launches FIRST and the halo exchange starts behind them, so that it runs under the rest of the direction
+        // update as well as under the interior SpMV. Measured on the P = 8 middle slab (50 M rows) before this change: the
+        // RCCL send / recv kernel, started together with a SpMV that fills every CU, took as long as that SpMV (480 us) and
+        // the boundary rows waited ~25 us per iteration for it (profiles/r03_slab_timeline_*.txt). Same kernels, same
+        // per-element arithmetic, disjoint row ranges: results cannot change.
+        const size_t head_rows = s->has_prev ? (size_t)s->halo : 0, tail_rows = s->has_next ? (size_t)s->halo : 0;
+        const bool early_halo = multi && !detail && !s->no_overlap && s->early_halo && (s->halo % 2) == 0 && (nl % 2) == 0 &&
+                                nl >= 4 * (size_t)s->halo;
         if (slots == 1) {
+            const double* x_in = enqueued == 1 ? s->x0 : s->x;
+            auto px = [&](size_t off, size_t count, bool reverse) {
+                if (count > 0)
+                    launch_cg_update_px(count, s->d_s, s->r + off, s->p + off, x_in + off, s->x + off, enqueued, s->compute, reverse, s->device_form);
+            };
             timed(&stats->time_blas1_ms, &stats->time_axpby_update_p_ms, [&] {
-                launch_cg_update_px(nl, s->d_s, s->r, s->p, enqueued == 1 ? s->x0 : s->x, s->x, enqueued, s->compute, backward, s->device_form);
+                if (early_halo) {
+                    px(0, head_rows, false);
+                    px(nl - tail_rows, tail_rows, false);
+                    trace.pop();
+                    {
+                        TraceScope r(trace, "Halo_Exchange");
+                        start_p_halo();
+                    }
+                    trace.push("BLAS_AXPBY");
+                    px(head_rows, nl - head_rows - tail_rows, backward);
+                } else {
+                    px(0, nl, backward);
+                }
             });
         } else {
             // the slot the new direction goes to still holds p of iteration enqueued - slots: fold the whole
@@ -771,15 +799,33 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
                 window_start = enqueued;
             }
             double* p_next = s->ring[(size_t)(enqueued % slots)];
+            const double* p_in = s->p;
+            auto ring_update = [&](size_t off, size_t count, bool reverse) {
+                if (count > 0)
+                    launch_cg_update_p_ring(count, s->d_s, s->r + off, p_in + off, p_next + off, enqueued, s->compute, reverse, s->device_form);
+            };
             timed(&stats->time_blas1_ms, &stats->time_axpby_update_p_ms, [&] {
-                launch_cg_update_p_ring(nl, s->d_s, s->r, s->p, p_next, enqueued, s->compute, backward, s->device_form);
+                if (early_halo) {
+                    ring_update(0, head_rows, false);
+                    ring_update(nl - tail_rows, tail_rows, false);
+                    s->p = p_next;  // the exchange sends from / receives into the new direction buffer
+                    trace.pop();
+                    {
+                        TraceScope r(trace, "Halo_Exchange");
+                        start_p_halo();
+                    }
+                    trace.push("BLAS_AXPBY");
+                    ring_update(head_rows, nl - head_rows - tail_rows, backward);
+                } else {
+                    ring_update(0, nl, backward);
+                }
             });
             s->p = p_next;
         }
         trace.pop();
         mark(enqueued - 1, 6);
         s->enqueued_stage = "direction update and halo exchange";
-        {
+        if (!early_halo) {
             TraceScope r(trace, "Halo_Exchange");
             start_p_halo();
         }

@@ -86,6 +86,10 @@ void DeviceCsr::upload_slab(const CSRMatrix& host, int row_offset, int n_local, 
     view.n_global = host.nb_rows;
     view.grid_size = grid_size;
     view.verified_stencil = false;
+    for (int i = 0; i < n_local; ++i) {
+        const int len = host.row_ptr[row_offset + i + 1] - host.row_ptr[row_offset + i];
+        if (len > view.max_row_nnz) view.max_row_nnz = len;
+    }
 }
 
 void DeviceCsr::generate_stencil5(int n, int row_offset, int n_local, double center, double off,
@@ -110,6 +114,7 @@ void DeviceCsr::generate_stencil5(int n, int row_offset, int n_local, double cen
     view.n_global = n * n;
     view.grid_size = n;
     view.verified_stencil = false;
+    view.max_row_nnz = n >= 3 ? 5 : (n == 2 ? 3 : 1);
 }
 
 void DeviceCsr::verify_stencil(hipStream_t stream) {

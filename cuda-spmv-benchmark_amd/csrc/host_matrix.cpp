@@ -7,6 +7,10 @@
 //   convert_csr_to_ellpack        <- reference include/io.h:124-125 (declaration only)
 #include <string.h>
 
+#include <algorithm>
+#include <utility>
+#include <vector>
+
 #include "spmv_amd.h"
 
 CSRMatrix csr_mat = {0, 0, 0, nullptr, nullptr, nullptr};
@@ -52,9 +56,26 @@ int build_csr_struct(struct MatrixData* mat) {
     }
     free(cursor);
 
-    // stable insertion sort of every row by column index
+    // Stable sort of every row by column index. The reference sorts each row by insertion (spmv_cusparse_csr.cu:137-160),
+    // which is quadratic in the row length: a 20 000-entry row costs 10^8 moves, a matrix with 10^4 of them minutes (90 s
+    // measured, tools/generic_matrix_perf.py). A stable sort has ONE possible output -- ascending columns, equal columns
+    // in input order -- so long rows go through std::stable_sort and produce the array insertion would; short rows (every
+    // row of the stencil) keep the insertion loop.
+    constexpr int kInsertionLimit = 64;
+    std::vector<std::pair<int, double>> scratch;
     for (size_t r = 0; r < rows; ++r) {
         const int lo = row_ptr[r], hi = row_ptr[r + 1];
+        if (hi - lo > kInsertionLimit) {
+            scratch.resize((size_t)(hi - lo));
+            for (int a = lo; a < hi; ++a) scratch[(size_t)(a - lo)] = {col[a], val[a]};
+            std::stable_sort(scratch.begin(), scratch.end(),
+                             [](const std::pair<int, double>& x, const std::pair<int, double>& y) { return x.first < y.first; });
+            for (int a = lo; a < hi; ++a) {
+                col[a] = scratch[(size_t)(a - lo)].first;
+                val[a] = scratch[(size_t)(a - lo)].second;
+            }
+            continue;
+        }
         for (int a = lo + 1; a < hi; ++a) {
             const int c = col[a];
             const double v = val[a];

@@ -18,6 +18,7 @@ struct SlabCsr {
     int n_local = 0;                 // rows in the slab
     int row_offset = 0;              // global index of local row 0
     long long nnz_local = 0;
+    int max_row_nnz = 0;             // longest row of the slab (0 = not known): steers csr_auto_variant
     long long nnz_base = 0;          // global CSR position of the slab's first entry
     int n_global = 0;                // rows of the whole matrix
     int grid_size = -1;              // n of the n x n stencil, <= 0 if not a stencil
@@ -147,7 +148,7 @@ int launch_stencil5_spmv_first_and_last_gridrow(const SlabCsr& m, const Stencil5
                                                 const ResidualOut* init = nullptr);
 
 // ---- CSR SpMV ----
-enum class CsrVariant { Auto, Stream, RowScalar, Wavefront, SubWave4, SubWave8, SubWave16, SubWave32 };
+enum class CsrVariant { Auto, Stream, Adaptive, RowScalar, Wavefront, SubWave4, SubWave8, SubWave16, SubWave32 };
 CsrVariant csr_auto_variant(const SlabCsr& m);
 void launch_csr_spmv(const SlabCsr& m, const double* x, double* y, double alpha,
                      CsrVariant variant, const Tunables& knobs, hipStream_t stream);

@@ -143,6 +143,7 @@ const char* csr_variant_name(CsrVariant v, const SlabCsr& m) {
     if (v == CsrVariant::Auto) v = csr_auto_variant(m);
     switch (v) {
         case CsrVariant::Stream: return "csr/stream";
+        case CsrVariant::Adaptive: return "csr/adaptive";
         case CsrVariant::RowScalar: return "csr/row-scalar";
         case CsrVariant::SubWave4: return "csr/subwave4";
         case CsrVariant::SubWave8: return "csr/subwave8";
@@ -459,6 +460,7 @@ extern "C" int spmv_amd_operator_select_variant(const char* mode, const char* va
             CsrVariant v;
             if (automatic) v = CsrVariant::Auto;
             else if (!strcmp(variant, "stream")) v = CsrVariant::Stream;
+            else if (!strcmp(variant, "adaptive")) v = CsrVariant::Adaptive;
             else if (!strcmp(variant, "row-scalar")) v = CsrVariant::RowScalar;
             else if (!strcmp(variant, "wavefront")) v = CsrVariant::Wavefront;
             else if (!strcmp(variant, "subwave4")) v = CsrVariant::SubWave4;

@@ -1101,7 +1101,11 @@ __global__ __launch_bounds__(kBlock) void csr_row_scalar_kernel(SlabCsr m, const
 // (Greathouse & Daga, SC'14), without a preprocessing pass: the row count per block is fixed per
 // matrix from its mean row length.
 // kThreads threads fetch kPerThread entries each in phase 1 (LDS: 16 B per entry).
-template <int kThreads, int kPerThread>
+// kVectorLong ("csr/adaptive", the "vector" half of CSR-adaptive): inside a row that is longer than the strip, a chunk that
+// lies entirely within that row is not staged at all -- every thread folds the entries it fetched into a private partial,
+// and the partials are summed by a fixed tree when the row ends. 20 coalesced passes of 256 threads instead of 20 x 1024
+// sequential fmas by one thread; the price is the summation order of such rows (a tree, like the sub-wavefront kernels).
+template <int kThreads, int kPerThread, bool kVectorLong = false>
 __global__ __launch_bounds__(kThreads) void csr_stream_kernel(SlabCsr m, const double* __restrict__ x,
                                                               double* __restrict__ y, double alpha,
                                                               int rows_per_block, int xcd_group, int total_blocks) {
@@ -1109,6 +1113,8 @@ __global__ __launch_bounds__(kThreads) void csr_stream_kernel(SlabCsr m, const d
     constexpr int kCsrStreamPerThread = kPerThread;
     __shared__ double sv[kCsrStreamCap];
     __shared__ double sx[kCsrStreamCap];
+    __shared__ int s_owner[2];  // by chunk parity: a slot is rewritten two chunks (two barriers) after it was read
+    __shared__ double s_wave[kThreads / 64];
     const int lo = -m.halo_before, hi = m.n_local + m.halo_after;
     const long long blk = logical_block(xcd_group, total_blocks);
     if (blk < 0) return;
@@ -1155,8 +1161,36 @@ __global__ __launch_bounds__(kThreads) void csr_stream_kernel(SlabCsr m, const d
         // but a 20 000-entry row now costs its thread 20 passes over LDS instead of 2 500 dependent trips to memory.
         // (Round 2 walked such rows with the chunked thread-per-row loop, one thread serialising the whole row.)
         double sum = 0.0;
-        for (int base = kb; base < ke; base += kCsrStreamCap) {
+        double vacc = 0.0;    // kVectorLong: this thread's share of the long row the block is walking through
+        int long_owner = -1;  // the thread that owns that row (block-uniform), -1 outside such a row
+        // Adds the block's private partials to the owner's running sum: wave trees, then the wave sums in wave order.
+        auto flush_long_row = [&] {
+            double w = vacc;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) w += __shfl_down(w, off);
+            if ((threadIdx.x & 63) == 0) s_wave[threadIdx.x >> 6] = w;
+            __syncthreads();
+            if ((int)threadIdx.x == long_owner) {
+                double t = s_wave[0];
+                for (int q = 1; q < kThreads / 64; ++q) t += s_wave[q];
+                sum += t;
+            }
+            __syncthreads();
+            vacc = 0.0;
+            long_owner = -1;
+        };
+        int parity = 0;
+        for (int base = kb; base < ke; base += kCsrStreamCap, parity ^= 1) {
             const int end = min(base + kCsrStreamCap, ke);
+            int owner = -1;
+            if (kVectorLong) {  // does ONE row cover this whole chunk? (rows are disjoint: at most one thread says yes)
+                if (threadIdx.x == 0) s_owner[parity] = -1;
+                __syncthreads();
+                if (has_row && k0 <= base && k1 >= end) s_owner[parity] = (int)threadIdx.x;
+                __syncthreads();
+                owner = s_owner[parity];
+                if (long_owner >= 0 && owner != long_owner) flush_long_row();
+            }
             int c[kCsrStreamPerThread];
             double v[kCsrStreamPerThread], xv[kCsrStreamPerThread];
 #pragma unroll
@@ -1168,6 +1202,13 @@ __global__ __launch_bounds__(kThreads) void csr_stream_kernel(SlabCsr m, const d
             }
 #pragma unroll
             for (int u = 0; u < kCsrStreamPerThread; ++u) xv[u] = x_at(x, (long long)c[u] - m.row_offset, lo, hi);
+            if (kVectorLong && owner >= 0) {
+                // the whole chunk belongs to one row: no staging, no barrier (dead slots carry v = 0)
+#pragma unroll
+                for (int u = 0; u < kCsrStreamPerThread; ++u) vacc = fma(v[u], xv[u], vacc);
+                long_owner = owner;
+                continue;
+            }
 #pragma unroll
             for (int u = 0; u < kCsrStreamPerThread; ++u) {
                 sv[threadIdx.x + u * kThreads] = v[u];
@@ -1180,6 +1221,7 @@ __global__ __launch_bounds__(kThreads) void csr_stream_kernel(SlabCsr m, const d
             }
             __syncthreads();  // the strip is overwritten by the next chunk
         }
+        if (kVectorLong && long_owner >= 0) flush_long_row();
         if (has_row) y[row] = alpha * sum;
     }
 }
@@ -1722,6 +1764,11 @@ int launch_stencil5_spmv_first_and_last_gridrow(const SlabCsr& m, const Stencil5
 // Short rows: stream; longer rows: about four entries per lane.
 CsrVariant csr_auto_variant(const SlabCsr& m) {
     const double avg = m.n_local > 0 ? (double)m.nnz_local / m.n_local : 0.0;
+    // Round 3 (tools/generic_matrix_perf.py, profiles/r03_generic_matrix_perf.txt): the mean alone mis-steers skewed
+    // matrices -- 10^7 rows of 1-8 entries with one row in a thousand holding 2 000-20 000 (mean 15.5) went to subwave4,
+    // 7.5 ms, where stream took 4.2 ms and 32 lanes per row 3.1 ms. A matrix with rows longer than the stream kernel's
+    // strip takes the adaptive kernel: stream for the short rows, the whole workgroup for the long ones.
+    if (m.max_row_nnz > 1024) return CsrVariant::Adaptive;
     return avg <= 10.0    ? CsrVariant::Stream
            : avg <= 16.0  ? CsrVariant::SubWave4
            : avg <= 32.0  ? CsrVariant::SubWave8
@@ -1736,13 +1783,14 @@ void launch_csr_spmv(const SlabCsr& m, const double* x, double* y, double alpha,
     if (variant == CsrVariant::Auto) variant = csr_auto_variant(m);
     const long long rows = m.n_local;
     switch (variant) {
+        case CsrVariant::Adaptive:
         case CsrVariant::Stream: {
             // rows per block: the mean span should fill about 90 % of the LDS strip, at most one row per thread
             const double avg = rows > 0 ? (double)m.nnz_local / rows : 1.0;
             // threads x entries per thread; measured on MI355X at 10 000^2 / 15 000^2: 256 x 4 1.43 / 3.13 ms,
             // 64 x 6 1.42 / 3.23-3.40, 64 x 8 1.55 / 3.30, 128 x 5 1.44 / 3.20 -> unlike the dense streams, the
             // one-wave shapes do not pay here (fewer rows per block = more shared edge lines)
-            const int shape = knobs.csr_stream_shape;  // 0: 256 x 4, 1: 64 x 6, 2: 64 x 8, 3: 128 x 5
+            const int shape = variant == CsrVariant::Adaptive ? 0 : knobs.csr_stream_shape;  // 0: 256 x 4, 1: 64 x 6, 2: 64 x 8, 3: 128 x 5
             const int threads = shape == 0 ? 256 : (shape == 3 ? 128 : 64);
             const int cap = shape == 0 ? 1024 : (shape == 1 ? 384 : (shape == 2 ? 512 : 640));
             int per_block = (int)(0.9 * cap / (avg > 1.0 ? avg : 1.0));
@@ -1757,6 +1805,10 @@ void launch_csr_spmv(const SlabCsr& m, const double* x, double* y, double alpha,
             const dim3 grid((unsigned)((blocks + span - 1) / span * span));
 #define SPMV_AMD_CSR_STREAM(T, P) \
     hipLaunchKernelGGL((csr_stream_kernel<T, P>), grid, dim3(T), 0, stream, m, x, y, alpha, per_block, group, (int)blocks)
+            if (variant == CsrVariant::Adaptive) {  // 256 x 4 only
+                hipLaunchKernelGGL((csr_stream_kernel<256, 4, true>), grid, dim3(256), 0, stream, m, x, y, alpha, per_block, group, (int)blocks);
+                break;
+            }
             if (shape == 1) SPMV_AMD_CSR_STREAM(64, 6);
             else if (shape == 2) SPMV_AMD_CSR_STREAM(64, 8);
             else if (shape == 3) SPMV_AMD_CSR_STREAM(128, 5);

@@ -440,3 +440,26 @@ def test_symmetric_matrix_market_file_through_the_operators_and_cg(B, O, fresh_h
     assert st2.iterations == ro.iterations and hist_err(slab.history(), ho) < TOL
     assert np.max(np.abs(slab.gather() - xo)) <= TOL * np.max(np.abs(xo))
     slab.destroy()
+
+
+@pytest.mark.parametrize("ring", ["16", "1"])
+def test_early_halo_exchange_changes_no_bit(B, monkeypatch, ring):
+    """Round 3: the slab's first / last grid row get their direction update first and the halo exchange starts behind them,
+    under the rest of the direction update (SPMV_AMD_EARLY_HALO=0 restores round 2's order). Same kernels on disjoint row
+    ranges: the residual history of a stand-in slab (two neighbours, RCCL send / recv to itself) is bit-identical, with the
+    direction ring and with the in-place x / p update."""
+    monkeypatch.setenv("SPMV_AMD_SELF_NEIGHBOUR", "1")
+    monkeypatch.setenv("SPMV_AMD_FORCE_COLLECTIVES", "1")
+    monkeypatch.setenv("SPMV_AMD_P_RING", ring)
+    out = {}
+    for early in ("0", "1"):
+        monkeypatch.setenv("SPMV_AMD_EARLY_HALO", early)
+        comm = B.Comm.rccl(0, 1, B.Comm.unique_id())
+        slab = B.CgSlab.stencil5_as(1024, 1, 4, comm)
+        st = slab.solve(max_iters=11, tol=0.0)
+        out[early] = (st.iterations, slab.history().copy())
+        st_t, tl = slab.timeline_solve(max_iters=11, tol=0.0)
+        assert np.array_equal(slab.history(), out[early][1]) and tl["halo_exchange_on_side_stream_us"] > 0
+        slab.destroy()
+        comm.destroy()
+    assert out["0"][0] == out["1"][0] == 11 and np.array_equal(out["0"][1], out["1"][1])

@@ -172,9 +172,19 @@ def test_only_the_declared_api_leaves_the_library(B):
     assert listed == declared
 
 
-@pytest.mark.parametrize("case", ["stencil81_old", "stencil40", "random", "unbalanced", "upper"])
+@pytest.mark.parametrize("case", ["stencil81_old", "stencil40", "random", "unbalanced", "upper", "long_rows_with_duplicate_columns"])
 def test_build_csr_struct_bit_exact(B, O, fresh_host_matrices, case):
-    if case == "stencil81_old":
+    if case == "long_rows_with_duplicate_columns":
+        # rows beyond the insertion limit take std::stable_sort: equal columns must stay in input order, as insertion leaves them
+        rng = np.random.default_rng(5)
+        lens = [300, 2, 65, 0, 1000, 64]
+        e = np.zeros(sum(lens), dtype=M.ENTRY_DTYPE)
+        e["row"] = np.repeat(np.arange(len(lens)), lens)
+        e["col"] = rng.integers(0, 40, size=len(e))  # 40 columns: every long row repeats columns many times
+        e["value"] = rng.standard_normal(len(e))
+        e = e[rng.permutation(len(e))]
+        m = B.HostMatrix(e, len(lens), 40)
+    elif case == "stencil81_old":
         m = B.load_matrix_market(os.path.join(GOLDEN, "example81x81.mtx"))
     elif case == "stencil40":
         m = B.HostMatrix(O.stencil5_coo(40), 1600, 1600, 40)

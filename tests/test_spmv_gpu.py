@@ -97,7 +97,7 @@ def test_stencil5_csr_non_stencil_inputs_take_the_csr_loop(B, O, fresh_host_matr
         op.free()
 
 
-@pytest.mark.parametrize("variant", [None, "stream", "row-scalar", "subwave4", "subwave8", "subwave16", "subwave32", "wavefront"])
+@pytest.mark.parametrize("variant", [None, "stream", "adaptive", "row-scalar", "subwave4", "subwave8", "subwave16", "subwave32", "wavefront"])
 def test_csr_operator(B, O, fresh_host_matrices, variant):
     op = B.Operator("cusparse-csr")
     op.select_variant(variant)
