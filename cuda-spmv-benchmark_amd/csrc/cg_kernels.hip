@@ -334,14 +334,16 @@ __global__ __launch_bounds__(kStream) void cg_update_px_kernel(size_t n, const C
                                                               const double* __restrict__ r,
                                                               double* __restrict__ p,
                                                               const double* x_in, double* x, int iteration,
-                                                              int reverse, int fma_form) {
+                                                              int reverse, int fma_form, size_t pairs_first, size_t pair_shift) {
     if (s->iterations != iteration) return;
     const bool advance = s->converged == 0;
     const double alpha = s->alpha, beta = s->beta;
     const unsigned block = reverse ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
     const size_t pairs = n >> 1;
-    const size_t i = (size_t)block * kStream + threadIdx.x;
-    if (i < pairs) {
+    size_t i = (size_t)block * kStream + threadIdx.x;
+    const bool live = i < pairs;
+    if (i >= pairs_first) i += pair_shift;  // two row ranges in one launch (cg_slab.hip, early halo): the second starts pair_shift later
+    if (live) {
         d2 pv = load_once(p, i);
         d2 xv = load_once(x_in, i);
         xv.x = fma(alpha, pv.x, xv.x);
@@ -386,7 +388,7 @@ __global__ __launch_bounds__(kStream) void cg_update_p_ring_kernel(size_t n, con
                                                                    const double* __restrict__ r,
                                                                    const double* __restrict__ p_in,
                                                                    double* __restrict__ p_out, int iteration,
-                                                                   int reverse, int fma_form) {
+                                                                   int reverse, int fma_form, size_t pairs_first, size_t pair_shift) {
     // Scalars FIRST here, unlike cg_update_r_kernel: this launch is enqueued before the host knows whether the
     // iteration converged, and the launch of the converging iteration must cost nothing (loading first would read
     // 16 B/row for nothing once per solve).
@@ -394,8 +396,10 @@ __global__ __launch_bounds__(kStream) void cg_update_p_ring_kernel(size_t n, con
     const double beta = s->beta;
     const unsigned block = reverse ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
     const size_t pairs = n >> 1;
-    const size_t i = (size_t)block * kStream + threadIdx.x;
-    if (i < pairs) {
+    size_t i = (size_t)block * kStream + threadIdx.x;
+    const bool live = i < pairs;
+    if (i >= pairs_first) i += pair_shift;  // two row ranges in one launch (see cg_update_px_kernel)
+    if (live) {
         const d2 rv = load_once(r, i);
         d2 pv = load_once(p_in, i);
         pv.x = direction(rv.x, beta, pv.x, fma_form);
@@ -527,7 +531,20 @@ void launch_cg_update_r(size_t n, const CgScalars* s, const double* Ap, double* 
 void launch_cg_update_px(size_t n, const CgScalars* s, const double* r, double* p, const double* x_in,
                          double* x, int iteration, hipStream_t stream, bool reverse, bool fma_form) {
     hipLaunchKernelGGL(cg_update_px_kernel, dim3(stream_grid(n)), dim3(kStream), 0, stream, n, s, r, p, x_in, x,
-                       iteration, reverse ? 1 : 0, fma_form ? 1 : 0);
+                       iteration, reverse ? 1 : 0, fma_form ? 1 : 0, ~(size_t)0, (size_t)0);
+}
+
+// The same two kernels over TWO row ranges of equal, even length in one launch: [0, count) and [second, second + count),
+// second even -- the slab's first and last grid row, whose new direction values the neighbours are waiting for.
+void launch_cg_update_px_two_ranges(size_t count, size_t second, const CgScalars* s, const double* r, double* p, const double* x_in,
+                                    double* x, int iteration, hipStream_t stream, bool fma_form) {
+    hipLaunchKernelGGL(cg_update_px_kernel, dim3(stream_grid(2 * count)), dim3(kStream), 0, stream, 2 * count, s, r, p, x_in, x,
+                       iteration, 0, fma_form ? 1 : 0, count >> 1, (second - count) >> 1);
+}
+void launch_cg_update_p_ring_two_ranges(size_t count, size_t second, const CgScalars* s, const double* r, const double* p_in,
+                                        double* p_out, int iteration, hipStream_t stream, bool fma_form) {
+    hipLaunchKernelGGL(cg_update_p_ring_kernel, dim3(stream_grid(2 * count)), dim3(kStream), 0, stream, 2 * count, s, r, p_in, p_out,
+                       iteration, 0, fma_form ? 1 : 0, count >> 1, (second - count) >> 1);
 }
 
 // Two launches. A one-launch form (every block publishes its slice sum with agent-scope atomics, the block that draws
@@ -586,7 +603,7 @@ void launch_cg_scalars_step(CgScalars* s, double tol, double* history, int* host
 void launch_cg_update_p_ring(size_t n, const CgScalars* s, const double* r, const double* p_in, double* p_out,
                              int iteration, hipStream_t stream, bool reverse, bool fma_form) {
     hipLaunchKernelGGL(cg_update_p_ring_kernel, dim3(stream_grid(n)), dim3(kStream), 0, stream, n, s, r, p_in, p_out,
-                       iteration, reverse ? 1 : 0, fma_form ? 1 : 0);
+                       iteration, reverse ? 1 : 0, fma_form ? 1 : 0, ~(size_t)0, (size_t)0);
 }
 
 void launch_cg_flush_x(size_t n, const double* alphas, const RingSlots& ring, int slots, int first_slot, int count,

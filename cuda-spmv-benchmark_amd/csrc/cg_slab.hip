@@ -775,8 +775,10 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
             };
             timed(&stats->time_blas1_ms, &stats->time_axpby_update_p_ms, [&] {
                 if (early_halo) {
-                    px(0, head_rows, false);
-                    px(nl - tail_rows, tail_rows, false);
+                    if (head_rows > 0 && tail_rows > 0)  // a rank with two neighbours: both grid rows in one launch
+                        launch_cg_update_px_two_ranges(head_rows, nl - tail_rows, s->d_s, s->r, s->p, x_in, s->x, enqueued, s->compute, s->device_form);
+                    else
+                        px(0, head_rows, false), px(nl - tail_rows, tail_rows, false);
                     trace.pop();
                     {
                         TraceScope r(trace, "Halo_Exchange");
@@ -806,8 +808,10 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
             };
             timed(&stats->time_blas1_ms, &stats->time_axpby_update_p_ms, [&] {
                 if (early_halo) {
-                    ring_update(0, head_rows, false);
-                    ring_update(nl - tail_rows, tail_rows, false);
+                    if (head_rows > 0 && tail_rows > 0)  // a rank with two neighbours: both grid rows in one launch
+                        launch_cg_update_p_ring_two_ranges(head_rows, nl - tail_rows, s->d_s, s->r, p_in, p_next, enqueued, s->compute, s->device_form);
+                    else
+                        ring_update(0, head_rows, false), ring_update(nl - tail_rows, tail_rows, false);
                     s->p = p_next;  // the exchange sends from / receives into the new direction buffer
                     trace.pop();
                     {

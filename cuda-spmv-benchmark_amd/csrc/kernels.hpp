@@ -150,8 +150,11 @@ int launch_stencil5_spmv_first_and_last_gridrow(const SlabCsr& m, const Stencil5
 // ---- CSR SpMV ----
 enum class CsrVariant { Auto, Stream, Adaptive, RowScalar, Wavefront, SubWave4, SubWave8, SubWave16, SubWave32 };
 CsrVariant csr_auto_variant(const SlabCsr& m);
+// d_dot_partials (may be null; stream / adaptive variants of SQUARE matrices only): one partial of x . (A x) per logical block,
+// csr_fused_dot_partials() of them (0 = the variant has no fused form).
 void launch_csr_spmv(const SlabCsr& m, const double* x, double* y, double alpha,
-                     CsrVariant variant, const Tunables& knobs, hipStream_t stream);
+                     CsrVariant variant, const Tunables& knobs, hipStream_t stream, double* d_dot_partials = nullptr);
+int csr_fused_dot_partials(const SlabCsr& m, CsrVariant variant, const Tunables& knobs);
 
 // ---- ELLPACK SpMV (device layout: slot-major, element (r,k) at [k * rows + r]) ----
 void launch_ell_transpose(int rows, int width, const int* idx_rowmajor, const double* val_rowmajor,
@@ -159,11 +162,13 @@ void launch_ell_transpose(int rows, int width, const int* idx_rowmajor, const do
 // grid_hint: n if the matrix is known to be an n x n stencil (block -> XCD relabelling is sized to a grid row), else 0.
 void launch_ell_spmv(int rows, int width, const int* idx, const double* val, const double* x,
                      double* y, double alpha, double beta, const Tunables& knobs, hipStream_t stream,
-                     int grid_hint = 0);
+                     int grid_hint = 0, double* d_dot_partials = nullptr);
+// d_dot_partials (may be null; square matrices): one partial of x . (A x) per workgroup, ell_fused_dot_partials() of them.
+int ell_fused_dot_partials(int rows, const Tunables& knobs);
 // Interior rows take W,C,E,N,S from slots 1,2,3,0,4 with computed columns; others walk slots.
 void launch_ell_stencil5_spmv(int rows, int width, int grid_size, const int* idx,
                               const double* val, const double* x, double* y, double alpha,
-                              double beta, const Tunables& knobs, hipStream_t stream);
+                              double beta, const Tunables& knobs, hipStream_t stream, double* d_dot_partials = nullptr);
 
 // ---- BLAS1 + reductions for CG ----
 // Device scalars of one CG solve, laid out in one small allocation.
@@ -226,6 +231,12 @@ void launch_cg_update_p_ring(size_t n, const CgScalars* s, const double* r, cons
                              int iteration, hipStream_t stream, bool reverse = false, bool fma_form = false);
 // x = x_in + sum_j alpha[slot_j] * p[slot_j], slot_j = (first_slot + j) % slots for j = 0..count-1, added in that
 // order with one fma each: element for element the x the per-iteration updates x += alpha_j p_j produce.
+// Both direction updates over two row ranges of equal even length, [0, count) and [second, second + count) (second even), in
+// ONE launch: the first and last grid row of a slab, ahead of the rest (early halo exchange, cg_slab.hip).
+void launch_cg_update_px_two_ranges(size_t count, size_t second, const CgScalars* s, const double* r, double* p, const double* x_in,
+                                    double* x, int iteration, hipStream_t stream, bool fma_form = false);
+void launch_cg_update_p_ring_two_ranges(size_t count, size_t second, const CgScalars* s, const double* r, const double* p_in,
+                                        double* p_out, int iteration, hipStream_t stream, bool fma_form = false);
 constexpr int kMaxRingSlots = 16;
 struct RingSlots {
     const double* p[kMaxRingSlots];

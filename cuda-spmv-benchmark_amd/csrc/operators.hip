@@ -171,6 +171,15 @@ int csr_run_device(const double* d_x, double* d_y) {
     return EXIT_SUCCESS;
 }
 
+// cg_solve_device's fused launches for the operators other than stencil5-csr: the SpMV kernel also writes the partial sums of
+// x . (A x) (one per workgroup), so the loop needs no 16 B/row dot pass. No skip flag (the loop never enqueues a SpMV past
+// convergence), no sweep direction, no fused initial residual.
+int csr_fused_launch(const double* d_x, double* d_y, double* d_partials, const int*, bool, const ResidualOut* init, hipStream_t stream) {
+    if (init != nullptr) return -1;
+    launch_csr_spmv(g_csr.A.view, d_x, d_y, /*alpha=*/1.0, g_csr.csr_variant, g_csr.shape.knobs, stream, d_partials);
+    return csr_fused_dot_partials(g_csr.A.view, g_csr.csr_variant, g_csr.shape.knobs);
+}
+
 void csr_free() {
     printf("[CSR] Cleaning up\n");
     release_cg_workspace();
@@ -306,6 +315,17 @@ int ell_run_timed(EllOperator& op, const double* x, double* y, double* kernel_ti
     return 0;
 }
 
+template <EllOperator* Op>
+int ell_fused_launch(const double* d_x, double* d_y, double* d_partials, const int*, bool, const ResidualOut* init, hipStream_t stream) {
+    if (init != nullptr || !Op->ready) return -1;
+    if (Op->stencil_fast_path && Op->verified)
+        launch_ell_stencil5_spmv(Op->rows, Op->width, Op->grid_size, Op->idx, Op->val, d_x, d_y, 1.0, 0.0, Op->knobs, stream, d_partials);
+    else
+        launch_ell_spmv(Op->rows, Op->width, Op->idx, Op->val, d_x, d_y, 1.0, 0.0, Op->knobs, stream, Op->verified ? Op->grid_size : 0,
+                        d_partials);
+    return ell_fused_dot_partials(Op->rows, Op->knobs);
+}
+
 int ellg_init(MatrixData* m) { return ell_init_common(g_ell, m); }
 int ellg_run_timed(const double* x, double* y, double* ms) { return ell_run_timed(g_ell, x, y, ms); }
 int ellg_run_device(const double* x, double* y) { return ell_run(g_ell, x, y); }
@@ -360,6 +380,15 @@ FusedSpmv fused_spmv_of(const SpmvOperator* op) {
         f.partials = g_stencil.plan.partials;
         f.can_init = g_stencil.plan.variant == Stencil5Variant::RowLds || g_stencil.plan.variant == Stencil5Variant::RowPlanes;
         f.launch = stencil_fused_launch;
+    } else if (op == &SPMV_CSR && g_csr.ready && g_csr.rows == g_csr.cols) {
+        f.partials = csr_fused_dot_partials(g_csr.A.view, g_csr.csr_variant, g_csr.shape.knobs);
+        f.launch = f.partials > 0 ? csr_fused_launch : nullptr;
+    } else if (op == &SPMV_ELLPACK && g_ell.ready && g_ell.rows == g_ell.cols) {
+        f.partials = ell_fused_dot_partials(g_ell.rows, g_ell.knobs);
+        f.launch = ell_fused_launch<&g_ell>;
+    } else if (op == &SPMV_STENCIL5_ELLPACK && g_ell_stencil.ready && g_ell_stencil.rows == g_ell_stencil.cols) {
+        f.partials = ell_fused_dot_partials(g_ell_stencil.rows, g_ell_stencil.knobs);
+        f.launch = ell_fused_launch<&g_ell_stencil>;
     }
     return f;
 }

@@ -1108,7 +1108,8 @@ __global__ __launch_bounds__(kBlock) void csr_row_scalar_kernel(SlabCsr m, const
 template <int kThreads, int kPerThread, bool kVectorLong = false>
 __global__ __launch_bounds__(kThreads) void csr_stream_kernel(SlabCsr m, const double* __restrict__ x,
                                                               double* __restrict__ y, double alpha,
-                                                              int rows_per_block, int xcd_group, int total_blocks) {
+                                                              int rows_per_block, int xcd_group, int total_blocks,
+                                                              double* __restrict__ dot_partials) {
     constexpr int kCsrStreamCap = kThreads * kPerThread;
     constexpr int kCsrStreamPerThread = kPerThread;
     __shared__ double sv[kCsrStreamCap];
@@ -1128,6 +1129,7 @@ __global__ __launch_bounds__(kThreads) void csr_stream_kernel(SlabCsr m, const d
         k0 = m.row_ptr[row];
         k1 = m.row_ptr[row + 1];
     }
+    double row_sum = 0.0;  // this thread's row, unscaled
     if (ke - kb <= kCsrStreamCap) {
         // phase 1, unrolled: all index and value loads first, then the gathers, then LDS
         int c[kCsrStreamPerThread];
@@ -1150,9 +1152,8 @@ __global__ __launch_bounds__(kThreads) void csr_stream_kernel(SlabCsr m, const d
         }
         __syncthreads();
         if (has_row) {
-            double sum = 0.0;
-            for (int k = k0 - kb; k < k1 - kb; ++k) sum = fma(sv[k], sx[k], sum);
-            y[row] = alpha * sum;
+            for (int k = k0 - kb; k < k1 - kb; ++k) row_sum = fma(sv[k], sx[k], row_sum);
+            y[row] = alpha * row_sum;
         }
     } else {
         // The block's span does not fit the strip (long rows): walk it in strip-sized chunks. Every chunk is fetched like
@@ -1223,6 +1224,22 @@ __global__ __launch_bounds__(kThreads) void csr_stream_kernel(SlabCsr m, const d
         }
         if (kVectorLong && long_owner >= 0) flush_long_row();
         if (has_row) y[row] = alpha * sum;
+        row_sum = sum;
+    }
+    if (dot_partials != nullptr) {
+        // x . (A x) of the block's rows (the CG loop's p.Ap, cg_single / cg_slab): one partial per logical block, wave
+        // trees then the wave sums in wave order -- a fixed shape. Square operators only: x is indexed by the row.
+        double d = has_row ? x[row] * row_sum : 0.0;
+        __syncthreads();  // s_wave may still be read by a flush above
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) d += __shfl_down(d, off);
+        if ((threadIdx.x & 63) == 0) s_wave[threadIdx.x >> 6] = d;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = s_wave[0];
+            for (int q = 1; q < kThreads / 64; ++q) t += s_wave[q];
+            dot_partials[blk] = t;
+        }
     }
 }
 
@@ -1295,6 +1312,26 @@ __device__ __forceinline__ double ell_finish(double alpha, double beta, double s
     return beta == 0.0 ? alpha * sum : fma(alpha, sum, beta * y_old);
 }
 
+// x . (A x) of one workgroup's rows into *out (the CG loop's p.Ap when cg_solve_device drives an ELLPACK operator): wave
+// trees, then the wave sums in wave order. Every thread of the workgroup must call it (it has a barrier).
+template <int kEllBlock>
+__device__ __forceinline__ void ell_block_dot(double d, double* __restrict__ out) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) d += __shfl_down(d, off);
+    if (kEllBlock == 64) {
+        if (threadIdx.x == 0) *out = d;
+        return;
+    }
+    __shared__ double s_wave[kEllBlock / 64];
+    if ((threadIdx.x & 63) == 0) s_wave[threadIdx.x >> 6] = d;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = s_wave[0];
+        for (int q = 1; q < kEllBlock / 64; ++q) t += s_wave[q];
+        *out = t;
+    }
+}
+
 // Workgroup size and nontemporal plane loads / y store are template parameters chosen by the launcher
 // from measurements (see launch_ell_spmv).
 template <int kEllBlock, bool kNt>
@@ -1302,15 +1339,20 @@ __global__ __launch_bounds__(kEllBlock) void ell_spmv_kernel(int rows, int width
                                                              const double* __restrict__ val,
                                                              const double* __restrict__ x,
                                                              double* __restrict__ y, double alpha,
-                                                             double beta, int xcd_group, int total_blocks) {
+                                                             double beta, int xcd_group, int total_blocks,
+                                                             double* __restrict__ dot_partials) {
     const long long blk = logical_block(xcd_group, total_blocks);
     if (blk < 0) return;
     const long long r = blk * kEllBlock + threadIdx.x;
-    if (r >= rows) return;
-    const double sum = ell_row_walk<kNt>(rows, width, idx, val, x, r);
-    const double out = ell_finish(alpha, beta, sum, beta == 0.0 ? 0.0 : y[r]);
-    if (kNt) __builtin_nontemporal_store(out, y + r);
-    else y[r] = out;
+    if (r >= rows && dot_partials == nullptr) return;
+    double sum = 0.0;
+    if (r < rows) {
+        sum = ell_row_walk<kNt>(rows, width, idx, val, x, r);
+        const double out = ell_finish(alpha, beta, sum, beta == 0.0 ? 0.0 : y[r]);
+        if (kNt) __builtin_nontemporal_store(out, y + r);
+        else y[r] = out;
+    }
+    if (dot_partials != nullptr) ell_block_dot<kEllBlock>(r < rows ? x[r] * sum : 0.0, dot_partials + blk);
 }
 
 // Interior rows of a stencil stored as ELL: slots [N,W,C,E,S], columns computed, indices
@@ -1321,31 +1363,39 @@ __global__ __launch_bounds__(kEllBlock) void ell_stencil5_kernel(int rows, int w
                                                                  const double* __restrict__ val,
                                                                  const double* __restrict__ x,
                                                                  double* __restrict__ y, double alpha,
-                                                                 double beta, int xcd_group, int total_blocks) {
+                                                                 double beta, int xcd_group, int total_blocks,
+                                                                 double* __restrict__ dot_partials) {
     const long long blk = logical_block(xcd_group, total_blocks);
     if (blk < 0) return;
     const long long r = blk * kEllBlock + threadIdx.x;
-    if (r >= rows) return;
-    const int i = (int)(r / n), j = (int)(r - (long long)i * n);
-    double sum;
-    if (width >= 5 && stencil_is_interior(i, j, n)) {
-        const double* __restrict__ v = val + r;
-        const long long R = rows;
-        const double v0 = kNt ? __builtin_nontemporal_load(v) : v[0], v1 = kNt ? __builtin_nontemporal_load(v + R) : v[R],
-                     v2 = kNt ? __builtin_nontemporal_load(v + 2 * R) : v[2 * R],
-                     v3 = kNt ? __builtin_nontemporal_load(v + 3 * R) : v[3 * R],
-                     v4 = kNt ? __builtin_nontemporal_load(v + 4 * R) : v[4 * R];
-        sum = v1 * x[r - 1];
-        sum = fma(v2, x[r], sum);
-        sum = fma(v3, x[r + 1], sum);
-        sum = fma(v0, x[r - n], sum);
-        sum = fma(v4, x[r + n], sum);
-    } else {
-        sum = ell_row_walk<kNt>(rows, width, idx, val, x, r);
+    if (r >= rows && dot_partials == nullptr) return;
+    double dot = 0.0;
+    if (r < rows) {
+        const int i = (int)(r / n), j = (int)(r - (long long)i * n);
+        double sum;
+        if (width >= 5 && stencil_is_interior(i, j, n)) {
+            const double* __restrict__ v = val + r;
+            const long long R = rows;
+            const double v0 = kNt ? __builtin_nontemporal_load(v) : v[0], v1 = kNt ? __builtin_nontemporal_load(v + R) : v[R],
+                         v2 = kNt ? __builtin_nontemporal_load(v + 2 * R) : v[2 * R],
+                         v3 = kNt ? __builtin_nontemporal_load(v + 3 * R) : v[3 * R],
+                         v4 = kNt ? __builtin_nontemporal_load(v + 4 * R) : v[4 * R];
+            const double xc = x[r];
+            sum = v1 * x[r - 1];
+            sum = fma(v2, xc, sum);
+            sum = fma(v3, x[r + 1], sum);
+            sum = fma(v0, x[r - n], sum);
+            sum = fma(v4, x[r + n], sum);
+            dot = xc * sum;
+        } else {
+            sum = ell_row_walk<kNt>(rows, width, idx, val, x, r);
+            if (dot_partials != nullptr) dot = x[r] * sum;
+        }
+        const double out = ell_finish(alpha, beta, sum, beta == 0.0 ? 0.0 : y[r]);
+        if (kNt) __builtin_nontemporal_store(out, y + r);
+        else y[r] = out;
     }
-    const double out = ell_finish(alpha, beta, sum, beta == 0.0 ? 0.0 : y[r]);
-    if (kNt) __builtin_nontemporal_store(out, y + r);
-    else y[r] = out;
+    if (dot_partials != nullptr) ell_block_dot<kEllBlock>(dot, dot_partials + blk);  // one call site: every thread of the workgroup arrives
 }
 
 // ---------------------------------------------------------------------------------
@@ -1777,36 +1827,57 @@ CsrVariant csr_auto_variant(const SlabCsr& m) {
                           : CsrVariant::Wavefront;
 }
 
+// Launch geometry of the stream / adaptive kernels: rows per block and logical blocks (= dot partials of a fused launch).
+static void csr_stream_geometry(const SlabCsr& m, CsrVariant variant, const Tunables& knobs, int* threads_out, int* per_block_out,
+                                long long* blocks_out) {
+    const long long rows = m.n_local;
+    // rows per block: the mean span should fill about 90 % of the LDS strip, at most one row per thread
+    const double avg = rows > 0 ? (double)m.nnz_local / rows : 1.0;
+    const int shape = variant == CsrVariant::Adaptive ? 0 : knobs.csr_stream_shape;  // 0: 256 x 4, 1: 64 x 6, 2: 64 x 8, 3: 128 x 5
+    const int threads = shape == 0 ? 256 : (shape == 3 ? 128 : 64);
+    const int cap = shape == 0 ? 1024 : (shape == 1 ? 384 : (shape == 2 ? 512 : 640));
+    int per_block = (int)(0.9 * cap / (avg > 1.0 ? avg : 1.0));
+    per_block = per_block > threads ? threads : (per_block < 16 ? 16 : per_block & ~15);
+    if (knobs.csr_stream_rows > 0) per_block = knobs.csr_stream_rows;
+    if (per_block > threads) per_block = threads;
+    *threads_out = threads;
+    *per_block_out = per_block;
+    *blocks_out = (rows + per_block - 1) / per_block;
+}
+
+int csr_fused_dot_partials(const SlabCsr& m, CsrVariant variant, const Tunables& knobs) {
+    if (variant == CsrVariant::Auto) variant = csr_auto_variant(m);
+    if ((variant != CsrVariant::Stream && variant != CsrVariant::Adaptive) || m.n_local == 0) return 0;
+    int threads = 0, per_block = 0;
+    long long blocks = 0;
+    csr_stream_geometry(m, variant, knobs, &threads, &per_block, &blocks);
+    return blocks <= 0x7fffffffLL ? (int)blocks : 0;
+}
+
 void launch_csr_spmv(const SlabCsr& m, const double* x, double* y, double alpha,
-                     CsrVariant variant, const Tunables& knobs, hipStream_t stream) {
+                     CsrVariant variant, const Tunables& knobs, hipStream_t stream, double* d_dot_partials) {
     if (m.n_local == 0) return;
     if (variant == CsrVariant::Auto) variant = csr_auto_variant(m);
     const long long rows = m.n_local;
     switch (variant) {
         case CsrVariant::Adaptive:
         case CsrVariant::Stream: {
-            // rows per block: the mean span should fill about 90 % of the LDS strip, at most one row per thread
-            const double avg = rows > 0 ? (double)m.nnz_local / rows : 1.0;
             // threads x entries per thread; measured on MI355X at 10 000^2 / 15 000^2: 256 x 4 1.43 / 3.13 ms,
             // 64 x 6 1.42 / 3.23-3.40, 64 x 8 1.55 / 3.30, 128 x 5 1.44 / 3.20 -> unlike the dense streams, the
             // one-wave shapes do not pay here (fewer rows per block = more shared edge lines)
-            const int shape = variant == CsrVariant::Adaptive ? 0 : knobs.csr_stream_shape;  // 0: 256 x 4, 1: 64 x 6, 2: 64 x 8, 3: 128 x 5
-            const int threads = shape == 0 ? 256 : (shape == 3 ? 128 : 64);
-            const int cap = shape == 0 ? 1024 : (shape == 1 ? 384 : (shape == 2 ? 512 : 640));
-            int per_block = (int)(0.9 * cap / (avg > 1.0 ? avg : 1.0));
-            per_block = per_block > threads ? threads : (per_block < 16 ? 16 : per_block & ~15);
-            if (knobs.csr_stream_rows > 0) per_block = knobs.csr_stream_rows;
-            if (per_block > threads) per_block = threads;
-            const long long blocks = (rows + per_block - 1) / per_block;
+            const int shape = variant == CsrVariant::Adaptive ? 0 : knobs.csr_stream_shape;
+            int threads = 0, per_block = 0;
+            long long blocks = 0;
+            csr_stream_geometry(m, variant, knobs, &threads, &per_block, &blocks);
             // dispatch order: relabelling blocks so that an XCD takes runs of consecutive blocks measured SLOWER here
             // (10 000^2: 1.35 ms plain, 1.40-1.45 ms for runs of 2-16; profiles/r02_xcd_group.txt)
             const int group = knobs.xcd_group > 0 ? knobs.xcd_group : 1;
             const long long span = group > 1 ? 8LL * group : 1;
             const dim3 grid((unsigned)((blocks + span - 1) / span * span));
 #define SPMV_AMD_CSR_STREAM(T, P) \
-    hipLaunchKernelGGL((csr_stream_kernel<T, P>), grid, dim3(T), 0, stream, m, x, y, alpha, per_block, group, (int)blocks)
+    hipLaunchKernelGGL((csr_stream_kernel<T, P>), grid, dim3(T), 0, stream, m, x, y, alpha, per_block, group, (int)blocks, d_dot_partials)
             if (variant == CsrVariant::Adaptive) {  // 256 x 4 only
-                hipLaunchKernelGGL((csr_stream_kernel<256, 4, true>), grid, dim3(256), 0, stream, m, x, y, alpha, per_block, group, (int)blocks);
+                hipLaunchKernelGGL((csr_stream_kernel<256, 4, true>), grid, dim3(256), 0, stream, m, x, y, alpha, per_block, group, (int)blocks, d_dot_partials);
                 break;
             }
             if (shape == 1) SPMV_AMD_CSR_STREAM(64, 6);
@@ -1839,8 +1910,14 @@ void launch_ell_transpose(int rows, int width, const int* idx_rowmajor, const do
                        width, idx_rowmajor, val_rowmajor, idx_slotmajor, val_slotmajor);
 }
 
+int ell_fused_dot_partials(int rows, const Tunables& knobs) {
+    const int B = (knobs.ell_shape & 1) ? 64 : 256;
+    return (int)(((long long)rows + B - 1) / B);
+}
+
 void launch_ell_spmv(int rows, int width, const int* idx, const double* val, const double* x,
-                     double* y, double alpha, double beta, const Tunables& knobs, hipStream_t stream, int grid_hint) {
+                     double* y, double alpha, double beta, const Tunables& knobs, hipStream_t stream, int grid_hint,
+                     double* d_dot_partials) {
     if (rows == 0) return;
     // bit 0: one-wave workgroups, bit 1: nontemporal planes / y. Measured on MI355X at 15 000^2 (generic /
     // stencil-aware): 0: 3.22 / 2.32 ms, 1: 3.00 / 2.51, 2: 2.96 / 2.26, 3: 3.00 / 2.47 -> 2.
@@ -1851,7 +1928,7 @@ void launch_ell_spmv(int rows, int width, const int* idx, const double* val, con
     const long long span = group > 1 ? 8LL * group : 1;
 #define SPMV_AMD_ELL(B, NT)                                                                                              \
     hipLaunchKernelGGL((ell_spmv_kernel<B, NT>), dim3((unsigned)(((((long long)rows + B - 1) / B) + span - 1) / span * span)), \
-                       dim3(B), 0, stream, rows, width, idx, val, x, y, alpha, beta, group, (int)(((long long)rows + B - 1) / B))
+                       dim3(B), 0, stream, rows, width, idx, val, x, y, alpha, beta, group, (int)(((long long)rows + B - 1) / B), d_dot_partials)
     if ((shape & 3) == 3) SPMV_AMD_ELL(64, true);
     else if (shape & 1) SPMV_AMD_ELL(64, false);
     else if (shape & 2) SPMV_AMD_ELL(256, true);
@@ -1861,10 +1938,10 @@ void launch_ell_spmv(int rows, int width, const int* idx, const double* val, con
 
 void launch_ell_stencil5_spmv(int rows, int width, int grid_size, const int* idx,
                               const double* val, const double* x, double* y, double alpha,
-                              double beta, const Tunables& knobs, hipStream_t stream) {
+                              double beta, const Tunables& knobs, hipStream_t stream, double* d_dot_partials) {
     if (rows == 0) return;
     if (grid_size < 3 || (long long)grid_size * grid_size != rows) {
-        launch_ell_spmv(rows, width, idx, val, x, y, alpha, beta, knobs, stream, 0);
+        launch_ell_spmv(rows, width, idx, val, x, y, alpha, beta, knobs, stream, 0, d_dot_partials);
         return;
     }
     const int shape = knobs.ell_shape;
@@ -1874,7 +1951,7 @@ void launch_ell_stencil5_spmv(int rows, int width, int grid_size, const int* idx
 #define SPMV_AMD_ELL5(B, NT)                                                                                                 \
     hipLaunchKernelGGL((ell_stencil5_kernel<B, NT>), dim3((unsigned)(((((long long)rows + B - 1) / B) + span - 1) / span * span)), \
                        dim3(B), 0, stream, rows, width, grid_size, idx, val, x, y, alpha, beta, group,                        \
-                       (int)(((long long)rows + B - 1) / B))
+                       (int)(((long long)rows + B - 1) / B), d_dot_partials)
     if ((shape & 3) == 3) SPMV_AMD_ELL5(64, true);
     else if (shape & 1) SPMV_AMD_ELL5(64, false);
     else if (shape & 2) SPMV_AMD_ELL5(256, true);
