@@ -714,6 +714,24 @@ def main():
         except Exception as e:
             roofline["ceiling_probe"] = {"error": repr(e)}
 
+    # every streaming stage of the loop against the same peak, from rank 0's stage timeline (one extra solve, HIP events; a stage
+    # includes the queue gap in front of its kernel): algorithmic bytes per row of the stage / its duration
+    try:
+        t0_ = leg["breakdown"][0]
+        stage_bytes = {"spmv_interior_us": ("SpMV + p.Ap partials (interior rows)", 56.0), "update_r_us": ("r -= alpha Ap + r.r partials", 24.0),
+                       "direction_update_us": ("p' = r + beta p (out of place)", 24.0)}
+        roofline["stages"] = {k: {"what": what, "bytes_per_row": bpr, "us": t0_[k], "gbs": bpr * t0_["rows"] / (t0_[k] * 1e-6) / 1e9,
+                                  "frac": bpr * t0_["rows"] / (t0_[k] * 1e-6) / 1e9 / HBM_PEAK_GBS}
+                              for k, (what, bpr) in stage_bytes.items() if t0_.get(k, 0) > 0}
+        its = max(int(t0_["iterations"]), 1)
+        if t0_.get("final_x_flush_us", 0) > 0:
+            bpr = 8.0 * its + 16.0  # one read of every direction of the window + x in + x out
+            roofline["stages"]["final_x_flush_us"] = {"what": f"x = x0 + sum of {its} alpha_k p_k (deferred x update)", "bytes_per_row": bpr, "us": t0_["final_x_flush_us"],
+                                                      "gbs": bpr * t0_["rows"] / (t0_["final_x_flush_us"] * 1e-6) / 1e9,
+                                                      "frac": bpr * t0_["rows"] / (t0_["final_x_flush_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS}
+    except Exception as e:  # evidence only
+        roofline["stages"] = {"error": repr(e)}
+
     devices = gather(c, {"rank": rank, "device": c.device_index, "pci_bus_id": c.pci})
 
     # second leg, multi-rank runs only: the same K steps with the other all-reduce path, in child processes
