@@ -278,11 +278,24 @@ def scaling_probe(B, torch, grid, full_ms, full_iterations, steps=5):
 
 
 def free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    return port
+    """A TCP port for a rendezvous on 127.0.0.1, taken BELOW the kernel's ephemeral range (32768-60999). A port handed out by
+    bind(0) lies inside that range: a rank that starts connecting before rank 0 listens can be given the very same number as
+    its source port, connects to itself, and rank 0 then fails with EADDRINUSE (seen once in a round-3 test run)."""
+    import random
+
+    rng = random.Random(os.getpid() ^ int(time.time() * 1e6))
+    for _ in range(200):
+        port = rng.randrange(12000, 32000)
+        s = socket.socket()
+        try:
+            s.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            s.bind(("127.0.0.1", port))
+            return port
+        except OSError:
+            continue
+        finally:
+            s.close()
+    raise RuntimeError("no free port found below the ephemeral range")
 
 
 def self_launch(args):
