@@ -84,3 +84,67 @@ def stencil_random_values(n, seed=3):
             if i < n - 1:
                 t.append((idx, idx + n, float(rng.uniform(-2.0, 2.0))))
     return entries(t), n * n, n * n
+
+
+# ---- structured fixtures after the ideas of reference tests/helpers/matrix_fixtures.cpp:181-338 (own code, own values) ----
+def from_arrays(rows, cols, vals, shuffle_seed=None):
+    e = np.zeros(len(rows), dtype=ENTRY_DTYPE)
+    e["row"], e["col"], e["value"] = rows, cols, vals
+    if shuffle_seed is not None:
+        e = e[np.random.default_rng(shuffle_seed).permutation(len(e))]
+    return e
+
+
+def stencil_9point(n, center=8.0, off=-1.0):
+    """9-point stencil of an n x n grid (all eight neighbours). Carries grid_size = n, but is NOT the 5-point pattern:
+    the stencil operators must notice and take the CSR loop. y = A * 1: sum = n^2*center + off*(number of neighbour pairs)."""
+    i, j = np.divmod(np.arange(n * n), n)
+    rows, cols, vals = [np.arange(n * n)], [np.arange(n * n)], [np.full(n * n, center)]
+    for di in (-1, 0, 1):
+        for dj in (-1, 0, 1):
+            if di == 0 and dj == 0:
+                continue
+            ok = (i + di >= 0) & (i + di < n) & (j + dj >= 0) & (j + dj < n)
+            rows.append(np.arange(n * n)[ok])
+            cols.append(((i + di) * n + (j + dj))[ok])
+            vals.append(np.full(int(ok.sum()), off))
+    e = from_arrays(np.concatenate(rows), np.concatenate(cols), np.concatenate(vals), shuffle_seed=3)
+    neighbours = len(e) - n * n
+    return e, n * n, n * n, float(n * n * center + off * neighbours)
+
+
+def banded(size, bandwidth, diagonal=4.0):
+    """|i - j| <= bandwidth; diagonal value `diagonal`, off-diagonals -1 / (1 + |i - j|) -- strictly diagonally dominant for
+    diagonal > 2 * H(bandwidth), hence SPD (symmetric). Returns entries, rows, cols, sum(A * 1)."""
+    rows, cols, vals = [], [], []
+    for d in range(-bandwidth, bandwidth + 1):
+        r = np.arange(max(0, -d), min(size, size - d))
+        rows.append(r)
+        cols.append(r + d)
+        vals.append(np.full(len(r), diagonal if d == 0 else -1.0 / (1 + abs(d))))
+    e = from_arrays(np.concatenate(rows), np.concatenate(cols), np.concatenate(vals), shuffle_seed=4)
+    return e, size, size, float(np.sum(e["value"]))
+
+
+def dense_blocks(size, block, fill=0.5):
+    """Dense block x block squares along the diagonal (the last one cut off at the matrix edge)."""
+    rows, cols = [], []
+    for b0 in range(0, size, block):
+        b1 = min(b0 + block, size)
+        r, c = np.meshgrid(np.arange(b0, b1), np.arange(b0, b1), indexing="ij")
+        rows.append(r.ravel())
+        cols.append(c.ravel())
+    rows, cols = np.concatenate(rows), np.concatenate(cols)
+    e = from_arrays(rows, cols, np.full(len(rows), fill), shuffle_seed=5)
+    return e, size, size, float(fill * len(rows))
+
+
+def ill_conditioned(size, decades=12):
+    """Tridiagonal, symmetric, diagonal falling exponentially over `decades` orders of magnitude, off-diagonals a fixed small
+    fraction of the smaller neighbouring diagonal entry (so every row stays diagonally dominant)."""
+    d = 10.0 ** (-decades * np.arange(size) / max(size - 1, 1))
+    off = -0.25 * np.minimum(d[:-1], d[1:])
+    rows = np.concatenate([np.arange(size), np.arange(size - 1), np.arange(1, size)])
+    cols = np.concatenate([np.arange(size), np.arange(1, size), np.arange(size - 1)])
+    vals = np.concatenate([d, off, off])
+    return from_arrays(rows, cols, vals, shuffle_seed=6), size, size, float(np.sum(vals))

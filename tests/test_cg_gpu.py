@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 from conftest import GOLDEN, rel_err, hist_err
+import matrices as M
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-10  # the north_star's bar on fp64 CG residuals
@@ -463,3 +464,20 @@ def test_early_halo_exchange_changes_no_bit(B, monkeypatch, ring):
         slab.destroy()
         comm.destroy()
     assert out["0"][0] == out["1"][0] == 11 and np.array_equal(out["0"][1], out["1"][1])
+
+
+@pytest.mark.parametrize("mode", ["cusparse-csr", "ellpack"])
+def test_cg_solve_device_on_a_banded_spd_matrix(B, O, fresh_host_matrices, mode):
+    """cg_solve_device on a matrix that is no stencil at all (banded, SPD, grid_size = -1), through the CSR and ELLPACK
+    operators' fused launches, against the oracle's device-form CG on the same CSR arrays."""
+    e, r, c, _ = M.banded(20000, 5)
+    m = B.HostMatrix(e, r, c, -1)
+    op = B.Operator(mode)
+    assert op.init(m) == 0
+    b = np.random.default_rng(9).standard_normal(r)
+    x, hist, st = B.cg_solve(op, m, b, np.zeros(r), device=True)
+    rp, ci, va = O.build_csr(e, r)
+    xo, ho, ro = O.cg(rp, ci, va, -1, b, np.zeros(r), device_form=True)
+    assert st.iterations == ro.iterations and st.converged == 1 and hist_err(hist, ho) < TOL
+    assert np.max(np.abs(x - xo)) <= TOL * np.max(np.abs(xo))
+    op.free()

@@ -154,3 +154,19 @@ def test_threaded_oracle_build_agrees_with_the_serial_one(O):
     x, h, r = O.cg(rp, ci, va, n, b, x0)
     x2, h2, r2 = O.cg_all_cores(rp, ci, va, n, b, x0, threads=4)
     assert r.iterations == r2.iterations and np.max(np.abs(h - h2) / h) < 1e-12 and np.max(np.abs(x - x2)) < 1e-12
+
+
+@pytest.mark.parametrize("fixture,args", [("stencil_9point", (17,)), ("banded", (500, 4)), ("dense_blocks", (300, 16)), ("ill_conditioned", (400,))])
+def test_structured_fixtures_have_their_analytic_checksums(O, fixture, args):
+    """tests/matrices.py's structured fixtures (ideas of reference tests/helpers/matrix_fixtures.cpp:181-338): the oracle's CSR
+    loop on x = 1 reproduces each fixture's closed-form checksum, and the symmetric ones are symmetric."""
+    import matrices as M
+
+    e, r, c, checksum = getattr(M, fixture)(*args)
+    rp, ci, va = O.build_csr(e, r)
+    y = O.spmv_csr(rp, ci, va, np.ones(c))
+    assert abs(y.sum() - checksum) <= 1e-10 * max(1.0, np.abs(va).sum())
+    dense = np.zeros((r, c))
+    dense[e["row"], e["col"]] = e["value"]
+    assert np.array_equal(dense, dense.T)
+    assert np.allclose(dense @ np.ones(c), y, rtol=1e-13, atol=1e-13)

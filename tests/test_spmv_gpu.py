@@ -305,3 +305,35 @@ def test_rowlds_march_in_the_solver_changes_no_bit(B, O, fresh_host_matrices, mo
         assert got[0] == base[0] and np.array_equal(got[1], base[1]), args
         if base[2] is not None:
             assert np.array_equal(got[2], base[2]), args
+
+
+@pytest.mark.parametrize("fixture", ["stencil_9point", "banded", "dense_blocks", "ill_conditioned"])
+def test_structured_non_stencil_fixtures_through_every_operator(B, O, fresh_host_matrices, fixture):
+    """Structured matrices after the ideas of the reference's (stale) fixture file, tests/helpers/matrix_fixtures.cpp:181-338:
+    a 9-point stencil that CLAIMS a grid size (the stencil operators must notice it is not the 5-point pattern), a banded SPD
+    matrix, dense diagonal blocks (rows of 37 entries: the sub-wavefront CSR kernels), an ill-conditioned tridiagonal one
+    (12 decades on the diagonal). Every operator against the oracle's CSR loop: bit-exact where the summation order is the
+    sequential one, 1e-12 (scaled) otherwise; and the analytic checksum of A * 1 to rounding."""
+    e, r, c, checksum = {"stencil_9point": lambda: M.stencil_9point(41), "banded": lambda: M.banded(3000, 6),
+                         "dense_blocks": lambda: M.dense_blocks(1000, 37), "ill_conditioned": lambda: M.ill_conditioned(2500)}[fixture]()
+    grid = 41 if fixture == "stencil_9point" else -1
+    rng = np.random.default_rng(17)
+    x = rng.standard_normal(c)
+    rp, ci, va = O.build_csr(e, r)
+    want, want1 = O.spmv_csr(rp, ci, va, x), O.spmv_csr(rp, ci, va, np.ones(c))
+    assert abs(want1.sum() - checksum) <= 1e-9 * max(1.0, np.abs(va).sum())
+    scale = np.maximum(np.abs(want), O.spmv_csr(rp, ci, np.abs(va), np.abs(x)))
+    for mode in ("stencil5-csr", "cusparse-csr", "ellpack", "stencil5-ellpack"):
+        B.lib().spmv_amd_reset_host_matrices()
+        m = B.HostMatrix(e, r, c, grid)
+        op = B.Operator(mode)
+        assert op.init(m) == 0, mode
+        if mode == "stencil5-csr":
+            assert "csr-loop" in op.variant()
+        got, _ = op.run_timed(x)
+        sequential = mode != "cusparse-csr" or op.variant() in ("csr/stream", "csr/row-scalar")
+        if sequential:
+            assert np.array_equal(got, want), (mode, op.variant())
+        else:
+            assert np.max(np.abs(got - want) / np.maximum(scale, 1e-300)) <= 1e-12, (mode, op.variant())
+        op.free()
