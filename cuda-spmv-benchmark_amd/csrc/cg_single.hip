@@ -1,7 +1,8 @@
 // cg_single.hip -- single-GPU Conjugate Gradient over any SpmvOperator.
 //
-//   cg_solve        <- reference src/solvers/cg_solver.cu:154-378  (host scalars; SpMV through
-//                      run_timed with the direction vector travelling host<->device each iteration)
+//   cg_solve        <- reference src/solvers/cg_solver.cu:154-378  (host scalars; upstream the SpMV goes through
+//                      run_timed with the direction vector travelling host<->device each iteration; here only for
+//                      operators that have no run_device, otherwise the vector stays where it is)
 //   cg_solve_device <- reference src/solvers/cg_solver.cu:436-706  (device scalars; SpMV through
 //                      run_device). Round 3: no longer a restatement of the reference's loop -- 10 kernels, a blocking
 //                      4-byte read-back and a D2D copy per iteration, 152 B/row -- but the slab solver's loop
@@ -91,8 +92,10 @@ int cg_solve(SpmvOperator* spmv_op, MatrixData* mat, const double* b, double* x,
     // staging buffers of the host-interface SpMV: pinned, so that the two 8n-byte copies per iteration the interface
     // imposes (here and inside run_timed) run at the link's rate instead of through pageable bounce buffers
     double *h_in = nullptr, *h_out = nullptr;
-    HIP_CHECK(hipHostMalloc((void**)&h_in, (size_t)n * sizeof(double), hipHostMallocDefault));
-    HIP_CHECK(hipHostMalloc((void**)&h_out, (size_t)n * sizeof(double), hipHostMallocDefault));
+    if (spmv_op->run_device == nullptr) {
+        HIP_CHECK(hipHostMalloc((void**)&h_in, (size_t)n * sizeof(double), hipHostMallocDefault));
+        HIP_CHECK(hipHostMalloc((void**)&h_out, (size_t)n * sizeof(double), hipHostMallocDefault));
+    }
     std::vector<double>& hist = last_cg_history();
     hist.clear();
 
@@ -107,12 +110,23 @@ int cg_solve(SpmvOperator* spmv_op, MatrixData* mat, const double* b, double* x,
         t_red += part.elapsed_ms();
         return h;
     };
+    // The reference's host path hands the direction vector to run_timed as a HOST array: four PCIe transfers of the whole vector
+    // per SpMV (3.5 s per solve at 20 000^2, all of it the link: profiles/r03_cg_entry_points_20k.txt). The solver's vectors live
+    // on the device here as there, so when the operator offers run_device the product is taken where the vector already is; an
+    // operator WITHOUT a device entry point (run_device == NULL is legal, reference include/spmv.h:125-134) is driven through
+    // run_timed exactly as upstream. Scalars (alpha, beta, the norms) stay on the host either way: that is what this entry point is.
+    const bool through_host = spmv_op->run_device == nullptr;
     auto host_spmv = [&](const double* d_in, double* d_out) {
         double kernel_ms = 0.0;
         part.begin(kStream);
-        download(h_in, d_in, (size_t)n);
-        spmv_op->run_timed(h_in, h_out, &kernel_ms);
-        upload(d_out, h_out, (size_t)n);
+        if (through_host) {
+            download(h_in, d_in, (size_t)n);
+            spmv_op->run_timed(h_in, h_out, &kernel_ms);
+            upload(d_out, h_out, (size_t)n);
+        } else if (spmv_op->run_device(d_in, d_out) != 0) {
+            fprintf(stderr, "[CG] operator '%s': run_device failed\n", spmv_op->name);
+            exit(EXIT_FAILURE);
+        }
         part.end(kStream);
         t_spmv += part.elapsed_ms();
     };
@@ -170,8 +184,8 @@ int cg_solve(SpmvOperator* spmv_op, MatrixData* mat, const double* b, double* x,
 
     v.release();
     device_release(d_scalar);
-    (void)hipHostFree(h_in);
-    (void)hipHostFree(h_out);
+    if (h_in) (void)hipHostFree(h_in);
+    if (h_out) (void)hipHostFree(h_out);
     return 0;
 }
 

@@ -481,3 +481,38 @@ def test_cg_solve_device_on_a_banded_spd_matrix(B, O, fresh_host_matrices, mode)
     assert st.iterations == ro.iterations and st.converged == 1 and hist_err(hist, ho) < TOL
     assert np.max(np.abs(x - xo)) <= TOL * np.max(np.abs(xo))
     op.free()
+
+
+def test_cg_solve_host_interface_with_and_without_a_device_entry_point(B, O, fresh_host_matrices):
+    """cg_solve (reference cg_solver.cu:154-378: host scalars). An operator WITHOUT run_device (legal upstream: callers check
+    for NULL) is driven through run_timed with host arrays exactly as the reference does; one that has run_device keeps the
+    vector on the GPU. Same numbers either way, equal to the oracle's host form; cg_solve_device refuses the first kind."""
+    n = 130
+    m = B.HostMatrix(O.stencil5_coo(n), n * n, n * n, n)
+    real = B.Operator("stencil5-csr")
+    assert real.init(m) == 0
+    timed_calls = []
+
+    def run_timed(x, y, ms):
+        timed_calls.append(1)
+        return real.op.contents.run_timed(x, y, ms)
+
+    keep = (B.INIT_FN(lambda mat: 0), B.RUN_TIMED_FN(run_timed), B.FREE_FN(lambda: None))
+    table = B.SpmvOperator(b"host-only", keep[0], keep[1], B.RUN_DEVICE_FN(), keep[2])  # run_device = NULL
+
+    class HostOnly:
+        op = C.pointer(table)
+
+    rp, ci, va = O.stencil5_csr(n)
+    xo, ho, ro = O.cg(rp, ci, va, n, np.ones(n * n), np.zeros(n * n), device_form=False)
+    x1, h1, s1 = B.cg_solve(HostOnly, m, np.ones(n * n), np.zeros(n * n), device=False)
+    assert len(timed_calls) == s1.iterations + 1  # every SpMV went through run_timed
+    x2, h2, s2 = B.cg_solve(real, m, np.ones(n * n), np.zeros(n * n), device=False)
+    assert len(timed_calls) == s1.iterations + 1  # ... and none of the second solve's did
+    for x, h, s in ((x1, h1, s1), (x2, h2, s2)):
+        assert s.iterations == ro.iterations and s.converged == 1 and hist_err(h, ho) < TOL
+        assert np.max(np.abs(x - xo)) <= TOL * np.max(np.abs(xo))
+    assert np.array_equal(h1, h2) and np.array_equal(x1, x2)
+    with pytest.raises(RuntimeError):
+        B.cg_solve(HostOnly, m, np.ones(n * n), np.zeros(n * n), device=True)
+    real.free()
