@@ -607,6 +607,8 @@ def main():
     ap.add_argument("--leg-only", choices=["rccl", "mailbox"], default=None,
                     help="(internal) run one measurement leg with that all-reduce path and print its record")
     args = ap.parse_args()
+    if args.steps < 1 or args.warmup < 0 or args.gpus < 1 or args.grid < 2:
+        ap.error("--steps >= 1, --warmup >= 0, --gpus >= 1 and --grid >= 2 are required")
 
     if args.scaling_probe_only is None and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(self_launch(args))

@@ -25,7 +25,15 @@
 //  * the halo exchange of iteration k+1 runs on a side stream under the interior rows' SpMV; the
 //    first and last grid row of the slab are launched once the halo has landed. Each row is
 //    computed by the same code whichever launch it falls in, so overlap cannot change results;
+//  * (round 3) the direction update runs on the slab's first / last grid row FIRST and the exchange starts behind that
+//    launch: the RCCL send / recv kernel, which otherwise competes for CUs with a SpMV that fills the chip and ends after
+//    it, is over long before the interior rows are (early halo; SPMV_AMD_EARLY_HALO=0 = the old order, same bits);
 //  * every wait on another rank is bounded (watchdog.hpp): a wedged peer becomes a report and a non-zero exit.
+//
+// The same loop also serves the reference's SINGLE-GPU entry point, cg_solve_device (cg_solver.cu:436-706): a slab that
+// borrows the caller's SpmvOperator instead of owning a CSR (cg_solve_on_operator, near the end of this file), and it can
+// record a per-stage timeline of a solve with HIP events and no host syncs (spmv_amd_cg_slab_set_timeline): what the
+// reference's six MAX / MIN-reduced timers are (:748-800), without serialising the pipeline to take them.
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
