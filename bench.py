@@ -255,6 +255,11 @@ def scaling_probe(B, torch, grid, full_ms, full_iterations, steps=5):
         rec = {"as_rank": r, "neighbours": (1 if r > 0 else 0) + (1 if r < P - 1 else 0), "row_offset": slab.row_offset, "rows": slab.n_local,
                "halo_doubles": grid, "iterations": st.iterations, "ms_per_solve": ms, "us_per_iteration": ms / max(st.iterations, 1) * 1e3,
                "spmv_us_per_launch": spmv_ms / steps / max(st.iterations, 1) * 1e3}
+        try:  # where this slab's iteration goes: one more solve with stage-boundary events (no host syncs)
+            _, tl = slab.timeline_solve(max_iters=full_iterations, tol=0.0)
+            rec["stage_us"] = {k: round(v, 1) for k, v in tl.items() if k.endswith("_us")}
+        except Exception as e:
+            rec["stage_us"] = {"error": repr(e)}
         slab.destroy()
         return rec
 
