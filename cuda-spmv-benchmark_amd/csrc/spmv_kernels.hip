@@ -1813,18 +1813,16 @@ int launch_stencil5_spmv_first_and_last_gridrow(const SlabCsr& m, const Stencil5
 // 20/40-byte lane strides of col_idx/values are what the coalesced phase 1 of the stream kernel removes.
 // Short rows: stream; longer rows: about four entries per lane.
 CsrVariant csr_auto_variant(const SlabCsr& m) {
-    const double avg = m.n_local > 0 ? (double)m.nnz_local / m.n_local : 0.0;
-    // Round 3 (tools/generic_matrix_perf.py, profiles/r03_generic_matrix_perf.txt): the mean alone mis-steers skewed
-    // matrices -- 10^7 rows of 1-8 entries with one row in a thousand holding 2 000-20 000 (mean 15.5) went to subwave4,
-    // 7.5 ms, where stream took 4.2 ms and 32 lanes per row 3.1 ms. A matrix with rows longer than the stream kernel's
-    // strip takes the adaptive kernel: stream for the short rows, the whole workgroup for the long ones.
-    if (m.max_row_nnz > 1024) return CsrVariant::Adaptive;
-    return avg <= 10.0    ? CsrVariant::Stream
-           : avg <= 16.0  ? CsrVariant::SubWave4
-           : avg <= 32.0  ? CsrVariant::SubWave8
-           : avg <= 64.0  ? CsrVariant::SubWave16
-           : avg <= 128.0 ? CsrVariant::SubWave32
-                          : CsrVariant::Wavefront;
+    // Round 3 (tools/generic_matrix_perf.py, profiles/r03_generic_matrix_perf.txt), 10^8 entries each:
+    //  * uniform rows of 12 / 20 / 40 / 80 / 160 random columns: the stream kernel is within 1-3 % of the best variant at EVERY
+    //    length (1.86 / 1.75 / 1.50 / 1.19 / 0.74 ms against 1.81 / 1.71 / 1.49 / 1.19 / 0.74 ms) and 5-12 % ahead of what the
+    //    mean-row-length rule of rounds 1-2 picked (subwave4 / 8 / 16 / 32, wavefront) -- with the sequential, bit-reproducible
+    //    row sum the others give up; banded (9 per row): stream 0.223 ms, subwave4 0.339 ms;
+    //  * skewed (rows of 1-8 entries, one in a thousand with 2 000-20 000; mean 15.5): the mean sent it to subwave4, 7.5 ms;
+    //    stream 4.2 ms, 32 lanes per row 3.1 ms, adaptive 2.8 ms.
+    // So: rows longer than the stream kernel's strip -> adaptive (stream for the short rows, the whole workgroup for the long
+    // ones); everything else -> stream. The sub-wavefront kernels stay selectable (spmv_amd_operator_select_variant).
+    return m.max_row_nnz > 1024 ? CsrVariant::Adaptive : CsrVariant::Stream;
 }
 
 // Launch geometry of the stream / adaptive kernels: rows per block and logical blocks (= dot partials of a fused launch).

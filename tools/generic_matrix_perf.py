@@ -4,7 +4,7 @@ correctness tests on tests/matrices.py, after the ideas of reference tests/helpe
 (banded, unbalanced rows, seeded random).
    banded9   : 9 diagonals (offsets -4..4), random values: a banded matrix without any grid structure (grid_size = -1)
    skewed    : row lengths 1-8 except one row in 1000 with 2 000-20 000 entries, random columns: mean ~ 16, max 20 000
-   uniform40 : 40 random columns per row
+   uniform<K>: K random columns per row (10 * rows / K rows)
    python tools/generic_matrix_perf.py [rows=10000000] [cases...]
 Matrices are built as CSR-ordered COO entries with numpy and go through HostMatrix -> build_csr_struct -> upload like
 any file; sequential-order variants (stream, row-scalar) must agree bit for bit, the others to 1e-12."""
@@ -39,21 +39,26 @@ def skewed(rows, rng):
     return r, c, rows
 
 
-def uniform40(rows, rng):
-    r = np.repeat(np.arange(rows, dtype=np.int64), 40)
-    c = rng.integers(0, rows, size=len(r), dtype=np.int64)
-    return r, c, rows
+def uniform(k):
+    def make(rows, rng):
+        r = np.repeat(np.arange(rows, dtype=np.int64), k)
+        c = rng.integers(0, rows, size=len(r), dtype=np.int64)
+        return r, c, rows
+    return make
 
 
-CASES = {"banded9": banded9, "skewed": skewed, "uniform40": uniform40}
+CASES = {"banded9": banded9, "skewed": skewed}
 args = sys.argv[1:]
 rows = int(args[0]) if args and args[0].isdigit() else 10_000_000
+for a in args:  # uniform<K>: K random columns in every row, 10 * rows / K rows (the same 10 * rows entries whatever K)
+    if a.startswith("uniform") and a[7:].isdigit():
+        CASES[a] = uniform(int(a[7:]))
 cases = [a for a in args if a in CASES] or ["banded9", "skewed"]
 B.require_gpu()
 out = []
 for name in cases:
     rng = np.random.default_rng(42)  # mt19937 seed 42 upstream; any fixed seed serves
-    n_rows = rows if name != "uniform40" else rows // 4
+    n_rows = rows if not name.startswith("uniform") else 10 * rows // int(name[7:])
     t0 = time.perf_counter()
     r, c, n = CASES[name](n_rows, rng)
     nnz = len(r)
