@@ -161,6 +161,27 @@ def test_plain_c_program_binds_the_boundary(B, tmp_path):
     assert run.returncode == 0 and "c caller ok" in run.stdout, (run.returncode, run.stdout, run.stderr)
 
 
+def test_host_layer_under_sanitizers(tmp_path):
+    """The host layer of the boundary -- Matrix Market reader / writer, build_csr_struct (insertion and stable_sort paths), the
+    ELLPACK builders -- compiled with g++ -fsanitize=address,undefined (they are plain C++ and link without HIP) and driven
+    through well-formed and malformed files by tests/abi/host_sanitize.cpp: no sanitizer report, every malformed file refused.
+    (GPU AddressSanitizer is not available on the test pool; this is what sanitizers can cover.)"""
+    import subprocess
+    csrc = os.path.join(ROOT, "cuda-spmv-benchmark_amd", "csrc")
+    exe = tmp_path / "host_sanitize"
+    build = subprocess.run(["g++", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-g", "-O1",
+                            "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "abi", "host_sanitize.cpp"),
+                            os.path.join(csrc, "matrix_market.cpp"), os.path.join(csrc, "host_matrix.cpp"), "-o", str(exe)],
+                           capture_output=True, text=True)
+    assert build.returncode == 0, build.stderr[-3000:]
+    scratch = tmp_path / "files"
+    scratch.mkdir()
+    run = subprocess.run([str(exe), str(scratch)], capture_output=True, text=True, timeout=120,
+                         env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", LD_PRELOAD=""))
+    assert run.returncode == 0 and "host_sanitize: ok" in run.stdout, (run.returncode, run.stdout[-2000:], run.stderr[-3000:])
+    assert "ERROR: AddressSanitizer" not in run.stderr and "runtime error" not in run.stderr, run.stderr[-3000:]
+
+
 def test_only_the_declared_api_leaves_the_library(B):
     """csrc/exports.map: exactly the declared symbols are dynamic exports; no spmv_amd::launch_* or kernel stub leaks."""
     import subprocess
