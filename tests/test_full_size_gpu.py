@@ -138,6 +138,25 @@ def test_cg_20k_matches_committed_golden_history(B, golden):
     slab.destroy()
 
 
+def test_cg_solve_device_20k_matches_golden_history_and_checksums(B, golden):
+    """BASELINE config 3 through the reference's single-GPU entry point, cg_solve_device (cg_solver.cu:436-706), on the
+    stencil5-csr operator generated in HBM: 14 iterations, every ||r_k|| within 1e-10 of the CPU oracle's committed
+    history, and Sum(x) / Norm2(x) -- the checksums the reference main prints -- within 1e-10 of the oracle's."""
+    g = golden["cases"].get("20000:5.0")
+    if g is None:
+        pytest.skip("20k golden not generated")
+    n = 20000
+    op = B.Operator("stencil5-csr")
+    assert op.init_synthetic(n) == 0
+    shell = B.HostMatrix(np.empty(0, dtype=B.ENTRY_DTYPE), n * n, n * n, n)  # cg_solve_device reads mat->rows only
+    x, hist, st = B.cg_solve(op, shell, np.ones(n * n), np.zeros(n * n), device=True)
+    assert st.iterations == g["cg"]["iterations"] == 14 and st.converged == 1
+    assert hist_err(hist, g["cg"]["history"]) < 1e-10
+    assert abs(st.solution_sum - g["cg"]["solution_sum"]) <= 1e-10 * abs(g["cg"]["solution_sum"])
+    assert abs(st.solution_norm - g["cg"]["solution_norm"]) <= 1e-10 * g["cg"]["solution_norm"]
+    op.free()
+
+
 def test_sizes_beyond_int32_csr_are_refused(B):
     """nnz = 5n^2 - 4n must fit the reference's signed 32-bit CSR indices (hard parts):
     n = 20 724 is the last grid that does."""
