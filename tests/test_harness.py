@@ -77,3 +77,44 @@ def test_generate_matrix_binary_matches_reference_generator(O, tmp_path):
         theirs = tmp_path / "theirs.mtx"
         assert run([ref_gen, "12", str(theirs)]).returncode == 0
         assert mine.read_bytes() == theirs.read_bytes()
+
+
+def test_trace_gaps_finds_the_last_solve_by_every_anchor(tmp_path):
+    """tools/trace_gaps.py (per-kernel busy / idle table of the last solve in a rocprofv3 kernel trace) must find the solve
+    whichever way it starts: the fused initial residual (mode-2 row-lds launches, the default), cg_init_residual (slabs
+    that do not run row-lds), or only cg_scalars_init. CPU only: synthetic traces."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+
+    def trace(first_kernels):
+        rows, t = [], 1000
+        def add(name, dur):
+            nonlocal t
+            rows.append((t, t + dur, name))
+            t += dur + 5
+        for solve in range(2):
+            for name in first_kernels:
+                add(name, 400)
+            add("spmv_amd::(anonymous namespace)::cg_scalars_init_kernel(spmv_amd::CgScalars*, double*)", 4)
+            for it in range(3):
+                add("void spmv_amd::(anonymous namespace)::stencil5_rowlds_kernel<1, true>(spmv_amd::SlabCsr, ...)", 450)
+                add("spmv_amd::(anonymous namespace)::reduce_slices_kernel(double const*, int, int, double*, int const*)", 6)
+                add("spmv_amd::(anonymous namespace)::cg_update_r_kernel(unsigned long, ...)", 180)
+                add("spmv_amd::(anonymous namespace)::cg_update_p_ring_kernel(unsigned long, ...)", 175)
+        path = tmp_path / f"trace_{abs(hash(tuple(first_kernels)))}_kernel_trace.csv"
+        with open(path, "w") as f:
+            f.write('"Kernel_Name","Start_Timestamp","End_Timestamp"\n')
+            for s, e, name in rows:
+                f.write(f'"{name}",{s},{e}\n')
+        return path
+
+    fused = ["void spmv_amd::(anonymous namespace)::stencil5_rowlds_kernel<2, true>(spmv_amd::SlabCsr, ...)",
+             "void spmv_amd::(anonymous namespace)::stencil5_rowlds_kernel<2, false>(spmv_amd::SlabCsr, ...)"]
+    unfused = ["void spmv_amd::(anonymous namespace)::stencil5_rowdirect_kernel<1, false>(spmv_amd::SlabCsr, ...)",
+               "spmv_amd::(anonymous namespace)::cg_init_residual_kernel(unsigned long, ...)"]
+    bare = ["spmv_amd::(anonymous namespace)::reduce_partials_kernel(double const*, ...)"]
+    for first, kernels_in_solve in ((fused, 2 + 1 + 12), (unfused, 2 + 1 + 12), (bare, 1 + 1 + 12)):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "trace_gaps.py"), str(trace(first)), "3"], capture_output=True, text=True, timeout=60)
+        assert out.returncode == 0, out.stderr
+        assert f"last solve: {kernels_in_solve} kernels" in out.stdout, out.stdout
