@@ -431,7 +431,8 @@ __device__ __forceinline__ void flush_chunk(d2& xv, const RingSlots& ring, const
 
 // x = x_in + sum of alpha_j p_j over the ring window, one fma per term in iteration order: the chain
 // x <- fma(alpha_j, p_j, x) the per-iteration x updates evaluate (axpy_kernel, mgpu :598), read in one pass
-// with up to eight directions in flight per lane.
+// with up to eight directions in flight per lane (all fourteen requested before the first fma measured slower in round 3:
+// 8.56-8.59 ms against 8.03-8.36 ms at 4e8 rows, same bits).
 __global__ __launch_bounds__(kStream) void cg_flush_x_kernel(size_t n, const double* __restrict__ alphas, RingSlots ring,
                                                              int slots, int first_slot, int count,
                                                              const double* x_in, double* x) {
