@@ -145,9 +145,16 @@ def run_gpu_rccl(n, rank, world, mailbox):
     comm = B.Comm.rccl(rank, world, box[0])
     assert comm is not None and comm.transport() == "rccl" and comm.transport_ranks() == world
     assert comm.selftest() == 0  # all-reduce, neighbour send / recv, loopback, barrier -- between the devices
+    used_mailbox = False
     if mailbox:
-        assert comm.mailbox_enable() and comm.mailbox_ready()  # hipIpc mapping + 2048-round self-test across xGMI
-        assert comm.mailbox_selftest(3000) == 0
+        # all-or-nothing: hipIpc mapping + a 2048-round self-test across xGMI on every rank, or the transport's all-reduce stays
+        used_mailbox = bool(comm.mailbox_enable())
+        assert used_mailbox == bool(comm.mailbox_ready())
+        everyone = [None] * world
+        dist.all_gather_object(everyone, used_mailbox)
+        assert all(e == used_mailbox for e in everyone), everyone
+        if used_mailbox:
+            assert comm.mailbox_selftest(3000) == 0
     N = n * n
     slab = B.CgSlab.stencil5(n, comm)
     assert (slab.row_offset, slab.n_local) == O.partition_rows(N, world, rank)
@@ -173,7 +180,8 @@ def run_gpu_rccl(n, rank, world, mailbox):
     assert tl and tl["iterations"] == st_t.iterations and tl["halo_exchange_on_side_stream_us"] > 0
     slab.destroy()
     comm.destroy()
-    print(f"rank {rank}: slab solver over RCCL between devices ok ({'peer mailbox' if mailbox else 'ncclAllReduce'}), "
+    path = "peer mailbox" if used_mailbox else ("mailbox unavailable between these devices: ncclAllReduce" if mailbox else "ncclAllReduce")
+    print(f"rank {rank}: slab solver over RCCL between devices ok ({path}), "
           f"halo exchange {tl['halo_exchange_on_side_stream_us']:.1f} us, iteration {tl['iteration_us']:.1f} us")
 
 

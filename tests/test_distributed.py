@@ -214,7 +214,7 @@ TIMELINE_KEYS = ["iterations", "solve_ms", "initial_residual_us", "spmv_interior
                  "halo_exchange_on_side_stream_us", "final_x_flush_us"]
 
 
-def check_multi_rank_line(line, world):
+def check_multi_rank_line(line, world, mailbox_must_work=True):
     """What a multi-rank bench line must carry so that the number arrives with its own parity statement: the golden
     comparison, the ranks' agreement, the per-rank stage breakdown and both all-reduce figures."""
     assert line["value"] is not None and line["n_gpus"] == world and line["transport"] == "rccl"
@@ -229,8 +229,12 @@ def check_multi_rank_line(line, world):
     assert set(TIMELINE_KEYS) - {"iterations"} <= set(b["max_over_ranks"]) and b["max_over_ranks"]["iteration_us"] >= b["min_over_ranks"]["iteration_us"]
     ab = line["allreduce_ab"]
     assert ab["headline"] == "rccl" and ab["rccl"] == line["ms_per_step"]
-    assert ab["mailbox"] is not None and ab["mailbox"] > 0, ab  # the child leg ran and passed its own parity gate
     o = ab["other_leg"]
+    if ab["mailbox"] is None and not mailbox_must_work:
+        # between devices the mailbox may be refused (all-or-nothing set-up); the leg must then SAY so, and the headline stands
+        assert "mailbox" in o.get("error", ""), ab
+        return
+    assert ab["mailbox"] is not None and ab["mailbox"] > 0, ab  # the child leg ran and passed its own parity gate
     assert "peer mailbox" in o["allreduce"] and o["parity_vs_golden"]["ok"] and len(o["breakdown"]["per_rank"]) == world
 
 
@@ -281,18 +285,24 @@ def need_gpus(world):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("world,n,mode", [(2, 512, "gpu-rccl"), (2, 2000, "gpu-rccl"), (2, 2000, "gpu-rccl-mailbox"), (4, 2000, "gpu-rccl"),
-                                          (4, 2000, "gpu-rccl-mailbox"), (8, 2048, "gpu-rccl"), (8, 2048, "gpu-rccl-mailbox")])
+                                          (4, 2000, "gpu-rccl-mailbox")])
 def test_slab_solver_over_rccl_between_devices(world, n, mode):
     """BASELINE config 4's data path on real links: one rank per device, halo rows by ncclSend / ncclRecv over xGMI on the
     side stream, dot products by ncclAllReduce (or the peer mailbox: uncached memory mapped through hipIpc, system-scope
-    stores), against the oracle's partitioned CG at 1e-10, bit-reproducible, all ranks holding the same history."""
+    stores), against the oracle's partitioned CG at 1e-10, bit-reproducible, all ranks holding the same history.
+    The mailbox is all-or-nothing by design: where the devices cannot map one another's mailboxes it must refuse on EVERY rank
+    and the solve must run -- and pass -- on ncclAllReduce; the worker says which it was. (8 ranks are left to bench.py under
+    the driver: the test pool limits how many processes a test run may put on the GPUs.)"""
     need_gpus(world)
     outs = launch(world, mode, n, timeout=600)
     assert all("slab solver over RCCL between devices ok" in o for o in outs)
+    if mode.endswith("mailbox"):
+        said = {("peer mailbox" in o, "mailbox unavailable" in o) for o in outs}
+        assert len(said) == 1 and sum(next(iter(said))) == 1, outs  # every rank took the same path, and says which
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world", [2, 4, 8])
+@pytest.mark.parametrize("world", [2, 4])
 def test_bench_over_rccl_between_devices(world):
     """`python bench.py --gpus N` as the driver runs it, on N devices, at the 2000 x 2000 grid (golden history committed):
     rccl_ranks == N, parity_vs_golden green, breakdown for every rank, both all-reduce legs."""
@@ -304,7 +314,7 @@ def test_bench_over_rccl_between_devices(world):
     assert out.returncode == 0, out.stdout + out.stderr
     lines = _json_lines(out.stdout)
     assert len(lines) == 1 and lines[0]["rccl_ranks"] == world
-    check_multi_rank_line(lines[0], world)
+    check_multi_rank_line(lines[0], world, mailbox_must_work=False)
     assert len({d["pci_bus_id"] for d in lines[0]["devices"]}) == world  # distinct devices
 
 
