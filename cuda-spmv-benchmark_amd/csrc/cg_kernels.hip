@@ -535,17 +535,17 @@ void launch_cg_update_px(size_t n, const CgScalars* s, const double* r, double* 
                        iteration, reverse ? 1 : 0, fma_form ? 1 : 0, ~(size_t)0, (size_t)0);
 }
 
-// The same two kernels over TWO row ranges of equal, even length in one launch: [0, count) and [second, second + count),
-// second even -- the slab's first and last grid row, whose new direction values the neighbours are waiting for.
-void launch_cg_update_px_two_ranges(size_t count, size_t second, const CgScalars* s, const double* r, double* p, const double* x_in,
-                                    double* x, int iteration, hipStream_t stream, bool fma_form) {
-    hipLaunchKernelGGL(cg_update_px_kernel, dim3(stream_grid(2 * count)), dim3(kStream), 0, stream, 2 * count, s, r, p, x_in, x,
-                       iteration, 0, fma_form ? 1 : 0, count >> 1, (second - count) >> 1);
+// The same two kernels over TWO row ranges in one launch: [0, count_a) and [second, second + count_b), all three even -- the
+// slab's first and last grid row (rounded outwards to 4 KiB), whose new direction values the neighbours are waiting for.
+void launch_cg_update_px_two_ranges(size_t count_a, size_t second, size_t count_b, const CgScalars* s, const double* r, double* p,
+                                    const double* x_in, double* x, int iteration, hipStream_t stream, bool fma_form) {
+    hipLaunchKernelGGL(cg_update_px_kernel, dim3(stream_grid(count_a + count_b)), dim3(kStream), 0, stream, count_a + count_b, s, r, p, x_in, x,
+                       iteration, 0, fma_form ? 1 : 0, count_a >> 1, (second - count_a) >> 1);
 }
-void launch_cg_update_p_ring_two_ranges(size_t count, size_t second, const CgScalars* s, const double* r, const double* p_in,
-                                        double* p_out, int iteration, hipStream_t stream, bool fma_form) {
-    hipLaunchKernelGGL(cg_update_p_ring_kernel, dim3(stream_grid(2 * count)), dim3(kStream), 0, stream, 2 * count, s, r, p_in, p_out,
-                       iteration, 0, fma_form ? 1 : 0, count >> 1, (second - count) >> 1);
+void launch_cg_update_p_ring_two_ranges(size_t count_a, size_t second, size_t count_b, const CgScalars* s, const double* r,
+                                        const double* p_in, double* p_out, int iteration, hipStream_t stream, bool fma_form) {
+    hipLaunchKernelGGL(cg_update_p_ring_kernel, dim3(stream_grid(count_a + count_b)), dim3(kStream), 0, stream, count_a + count_b, s, r, p_in,
+                       p_out, iteration, 0, fma_form ? 1 : 0, count_a >> 1, (second - count_a) >> 1);
 }
 
 // Two launches. A one-launch form (every block publishes its slice sum with agent-scope atomics, the block that draws

@@ -772,9 +772,16 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
         // RCCL send / recv kernel, started together with a SpMV that fills every CU, took as long as that SpMV (480 us) and
         // the boundary rows waited ~25 us per iteration for it (profiles/r03_slab_timeline_*.txt). Same kernels, same
         // per-element arithmetic, disjoint row ranges: results cannot change.
-        const size_t head_rows = s->has_prev ? (size_t)s->halo : 0, tail_rows = s->has_next ? (size_t)s->halo : 0;
-        const bool early_halo = multi && !detail && !s->no_overlap && s->early_halo && (s->halo % 2) == 0 && (nl % 2) == 0 &&
-                                nl >= 4 * (size_t)s->halo;
+        // The two early ranges are rounded OUTWARDS to 4 KiB (512 doubles), so that the launch over the rest starts on a 4 KiB
+        // boundary like every whole-vector launch does: with the ranges cut exactly at the grid row, the rest of a 15 000-column
+        // slab started 64 bytes off a 128-byte line and its direction update ran 20-30 % slower (485 vs 386 us at 112.5 M rows;
+        // at 20 000 columns, 128-byte but not 4 KiB aligned, 8 %). A few rows beyond the grid row being updated early is harmless.
+        constexpr size_t kAlign = 512;
+        const size_t head_rows = s->has_prev ? ((size_t)s->halo + kAlign - 1) / kAlign * kAlign : 0;
+        const size_t tail_start = s->has_next ? (nl - (size_t)s->halo) / kAlign * kAlign : nl;
+        const size_t tail_rows = nl - tail_start;
+        const bool early_halo = multi && !detail && !s->no_overlap && s->early_halo && (nl % 2) == 0 && nl >= 4 * (size_t)s->halo + 4 * kAlign &&
+                                head_rows < tail_start;
         if (slots == 1) {
             const double* x_in = enqueued == 1 ? s->x0 : s->x;
             auto px = [&](size_t off, size_t count, bool reverse) {
@@ -784,16 +791,16 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
             timed(&stats->time_blas1_ms, &stats->time_axpby_update_p_ms, [&] {
                 if (early_halo) {
                     if (head_rows > 0 && tail_rows > 0)  // a rank with two neighbours: both grid rows in one launch
-                        launch_cg_update_px_two_ranges(head_rows, nl - tail_rows, s->d_s, s->r, s->p, x_in, s->x, enqueued, s->compute, s->device_form);
+                        launch_cg_update_px_two_ranges(head_rows, tail_start, tail_rows, s->d_s, s->r, s->p, x_in, s->x, enqueued, s->compute, s->device_form);
                     else
-                        px(0, head_rows, false), px(nl - tail_rows, tail_rows, false);
+                        px(0, head_rows, false), px(tail_start, tail_rows, false);
                     trace.pop();
                     {
                         TraceScope r(trace, "Halo_Exchange");
                         start_p_halo();
                     }
                     trace.push("BLAS_AXPBY");
-                    px(head_rows, nl - head_rows - tail_rows, backward);
+                    px(head_rows, tail_start - head_rows, backward);
                 } else {
                     px(0, nl, backward);
                 }
@@ -817,9 +824,9 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
             timed(&stats->time_blas1_ms, &stats->time_axpby_update_p_ms, [&] {
                 if (early_halo) {
                     if (head_rows > 0 && tail_rows > 0)  // a rank with two neighbours: both grid rows in one launch
-                        launch_cg_update_p_ring_two_ranges(head_rows, nl - tail_rows, s->d_s, s->r, p_in, p_next, enqueued, s->compute, s->device_form);
+                        launch_cg_update_p_ring_two_ranges(head_rows, tail_start, tail_rows, s->d_s, s->r, p_in, p_next, enqueued, s->compute, s->device_form);
                     else
-                        ring_update(0, head_rows, false), ring_update(nl - tail_rows, tail_rows, false);
+                        ring_update(0, head_rows, false), ring_update(tail_start, tail_rows, false);
                     s->p = p_next;  // the exchange sends from / receives into the new direction buffer
                     trace.pop();
                     {
@@ -827,7 +834,7 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
                         start_p_halo();
                     }
                     trace.push("BLAS_AXPBY");
-                    ring_update(head_rows, nl - head_rows - tail_rows, backward);
+                    ring_update(head_rows, tail_start - head_rows, backward);
                 } else {
                     ring_update(0, nl, backward);
                 }

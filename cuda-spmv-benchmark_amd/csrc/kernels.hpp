@@ -231,12 +231,12 @@ void launch_cg_update_p_ring(size_t n, const CgScalars* s, const double* r, cons
                              int iteration, hipStream_t stream, bool reverse = false, bool fma_form = false);
 // x = x_in + sum_j alpha[slot_j] * p[slot_j], slot_j = (first_slot + j) % slots for j = 0..count-1, added in that
 // order with one fma each: element for element the x the per-iteration updates x += alpha_j p_j produce.
-// Both direction updates over two row ranges of equal even length, [0, count) and [second, second + count) (second even), in
-// ONE launch: the first and last grid row of a slab, ahead of the rest (early halo exchange, cg_slab.hip).
-void launch_cg_update_px_two_ranges(size_t count, size_t second, const CgScalars* s, const double* r, double* p, const double* x_in,
-                                    double* x, int iteration, hipStream_t stream, bool fma_form = false);
-void launch_cg_update_p_ring_two_ranges(size_t count, size_t second, const CgScalars* s, const double* r, const double* p_in,
-                                        double* p_out, int iteration, hipStream_t stream, bool fma_form = false);
+// Both direction updates over two row ranges, [0, count_a) and [second, second + count_b) (all even), in ONE launch: the first
+// and last grid row of a slab, ahead of the rest (early halo exchange, cg_slab.hip).
+void launch_cg_update_px_two_ranges(size_t count_a, size_t second, size_t count_b, const CgScalars* s, const double* r, double* p,
+                                    const double* x_in, double* x, int iteration, hipStream_t stream, bool fma_form = false);
+void launch_cg_update_p_ring_two_ranges(size_t count_a, size_t second, size_t count_b, const CgScalars* s, const double* r,
+                                        const double* p_in, double* p_out, int iteration, hipStream_t stream, bool fma_form = false);
 constexpr int kMaxRingSlots = 16;
 struct RingSlots {
     const double* p[kMaxRingSlots];
