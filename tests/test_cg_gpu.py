@@ -220,6 +220,11 @@ def test_slab_timeline_accounts_for_the_solve(B, O, fresh_host_matrices):
     whole = t["initial_residual_us"] + t["iterations"] * t["iteration_us"] + t["final_x_flush_us"]
     assert 0.9 * whole <= t["solve_ms"] * 1e3 <= 1.1 * whole + 50.0
     assert slab.solve().iterations == st.iterations and B.lib().spmv_amd_cg_slab_timeline(slab.h, None, 0) == 0  # off again
+    # degenerate solves: no iteration at all, and a single one
+    st0, t0 = slab.timeline_solve(max_iters=0)
+    assert st0.iterations == 0 and t0["iterations"] == 0 and t0["iteration_us"] == 0.0 and t0["initial_residual_us"] > 0
+    st1, t1 = slab.timeline_solve(max_iters=1)
+    assert st1.iterations == 1 and t1["iterations"] == 1 and t1["iteration_us"] > 0
     slab.destroy()
 
 
