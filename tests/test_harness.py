@@ -118,3 +118,30 @@ def test_trace_gaps_finds_the_last_solve_by_every_anchor(tmp_path):
         out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "trace_gaps.py"), str(trace(first)), "3"], capture_output=True, text=True, timeout=60)
         assert out.returncode == 0, out.stderr
         assert f"last solve: {kernels_in_solve} kernels" in out.stdout, out.stdout
+
+
+def test_bench_parity_gate_logic_on_the_cpu(golden):
+    """bench.py's parity_vs_golden: the committed history passes; one residual off by 1e-9, a missing residual or another
+    iteration count does not; a grid without a committed history is reported as such (and does not block a run)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for grid in (512, 2000, 10000, 20000):
+        g = golden["cases"][f"{grid}:5.0"]["cg"]
+        ok = bench.parity_vs_golden(grid, g["history"], g["iterations"])
+        assert ok["available"] and ok["ok"] and ok["max_rel_err"] == 0.0 and ok["entries_compared"] == g["iterations"] + 1
+        off = list(g["history"])
+        off[len(off) // 2] *= 1.0 + 1e-9
+        assert not bench.parity_vs_golden(grid, off, g["iterations"])["ok"]
+        near = [v * (1.0 + 5e-11) for v in g["history"]]
+        assert bench.parity_vs_golden(grid, near, g["iterations"])["ok"]
+        assert not bench.parity_vs_golden(grid, g["history"][:-1], g["iterations"] - 1)["ok"]
+        assert not bench.parity_vs_golden(grid, g["history"], g["iterations"] + 1)["ok"]
+    none = bench.parity_vs_golden(777, [1.0, 0.5], 1)
+    assert none["available"] is False and "no committed golden" in none["note"]
+    # the per-rank breakdown summary: max / min over ranks of every stage
+    s = bench.breakdown_summary([{"rank": 0, "rows": 10, "iterations": 14.0, "iteration_us": 900.0, "update_r_us": 190.0},
+                                 {"rank": 1, "rows": 10, "iterations": 14.0, "iteration_us": 950.0, "update_r_us": 185.0}])
+    assert s["max_over_ranks"] == {"iteration_us": 950.0, "update_r_us": 190.0} and s["min_over_ranks"]["iteration_us"] == 900.0
+    assert [r["rank"] for r in s["per_rank"]] == [0, 1]
