@@ -33,6 +33,7 @@ struct CsrBackedOperator {
     int rows = 0, cols = 0;
     bool ready = false;
     Stencil5Variant stencil_variant = Stencil5Variant::Auto;
+    int march_rows = 0;  // stencil5-csr, variants "row-lds-march2" / "row-lds-march4": grid rows a row-lds wave walks (0 = SPMV_AMD_ROWLDS_ROWS / 1)
     CsrVariant csr_variant = CsrVariant::Auto;
     const char* variant_name = "uninitialised";
 
@@ -84,8 +85,11 @@ CsrBackedOperator g_csr{"cusparse-csr"};
 
 void stencil_pick_variant() {
     g_stencil.shape = current_launch_shape();
+    if (g_stencil.march_rows > 0) g_stencil.shape.knobs.rowlds_rows = g_stencil.march_rows;
     g_stencil.plan = plan_stencil5(g_stencil.A.view, 0, g_stencil.rows, g_stencil.stencil_variant, g_stencil.shape);
-    g_stencil.variant_name = g_stencil.plan.name;
+    g_stencil.variant_name = g_stencil.plan.lds_march_rows == 2   ? "stencil5/row-lds-march2"
+                             : g_stencil.plan.lds_march_rows == 4 ? "stencil5/row-lds-march4"
+                                                                  : g_stencil.plan.name;
 }
 
 int stencil_init(MatrixData* mat) {
@@ -476,8 +480,11 @@ extern "C" int spmv_amd_operator_select_variant(const char* mode, const char* va
     const bool automatic = variant == nullptr || !strcmp(variant, "auto");
     switch (which_operator(mode)) {
         case Which::Stencil:
+            g_stencil.march_rows = 0;
             if (automatic) g_stencil.stencil_variant = Stencil5Variant::Auto;
-            else if (!strcmp(variant, "row-lds")) g_stencil.stencil_variant = Stencil5Variant::RowLds;
+            else if (!strcmp(variant, "row-lds")) g_stencil.stencil_variant = Stencil5Variant::RowLds, g_stencil.march_rows = 1;
+            else if (!strcmp(variant, "row-lds-march2")) g_stencil.stencil_variant = Stencil5Variant::RowLds, g_stencil.march_rows = 2;
+            else if (!strcmp(variant, "row-lds-march4")) g_stencil.stencil_variant = Stencil5Variant::RowLds, g_stencil.march_rows = 4;
             else if (!strcmp(variant, "row-direct")) g_stencil.stencil_variant = Stencil5Variant::RowDirect;
             else if (!strcmp(variant, "column-march")) g_stencil.stencil_variant = Stencil5Variant::ColumnMarch;
             else if (!strcmp(variant, "wave-tile")) g_stencil.stencil_variant = Stencil5Variant::WaveTile;

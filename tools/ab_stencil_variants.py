@@ -4,6 +4,7 @@ same x = 1, the reference's benchmark rule (5 warm-ups, 10 timed launches, >2 si
 results checked against the default variant.
    python tools/ab_stencil_variants.py [grid=20000]
 Variants: row-lds (default; coefficients through a wave-private LDS strip, W/E from LDS, XCD runs of one grid row),
+row-lds-march2 / -march4 (round 3: the same tile, a wave walking 2 / 4 consecutive grid rows with x rotating in registers),
 row-direct (one thread per row on a 2-D index, strided coefficient loads), column-march (north_star's sketch taken
 literally: x north / centre / south rows kept across a march down the grid rows, coefficients through LDS),
 wave-tile (128 consecutive rows per wave), row-generic (the reference's own thread-per-row shape with div/mod)."""
@@ -28,7 +29,7 @@ assert op.init_synthetic(n) == 0
 x = np.random.default_rng(1).standard_normal(rows)
 dx1, dxr, dy = B.DeviceVector(rows, fill=1.0), B.DeviceVector.from_host(x), B.DeviceVector(rows, fill=0.0)
 out, ref = [], None
-for variant in ("row-lds", "row-direct", "column-march", "wave-tile", "row-generic"):
+for variant in ("row-lds", "row-lds-march2", "row-lds-march4", "row-direct", "column-march", "wave-tile", "row-generic"):
     op.select_variant(variant)
     op.time_device(dx1, dy, 5)
     ms = op.time_device(dx1, dy, 10)
