@@ -268,7 +268,7 @@ def test_rowlds_march_is_bit_exact(B, O, fresh_host_matrices, monkeypatch, rows,
     e, x = random_stencil(O, n, 100 * rows + n)
     m = B.HostMatrix(e, n * n, n * n, n)
     op = B.Operator("stencil5-csr")
-    assert op.init(m) == 0 and op.variant() == "stencil5/row-lds"
+    assert op.init(m) == 0 and op.variant() == f"stencil5/row-lds-march{rows}"
     rp, ci, va = O.build_csr(e, n * n)
     want = O.spmv_stencil5(rp, ci, va, x, n)
     got, _ = op.run_timed(x)
