@@ -109,7 +109,8 @@ def test_csr_operator(B, O, fresh_host_matrices, variant):
     e, r, c = M.random_sparse(1000, 777, 33, seed=9)
     mats.append((e, r, c, -1, np.random.default_rng(4).standard_normal(c)))
     # rows far longer than the stream kernel's 1024-entry LDS strip (its chunked walk), next to short and empty ones
-    e, r, c = M.random_sparse(300, 6000, lambda row, rng: 3500 if row in (0, 137) else (0 if row % 11 == 0 else int(rng.integers(1, 9))), seed=12)
+    # (rows 0 and 1 are both long and share a block: one long row ends and the next begins inside the same chunk; row 137 sits alone)
+    e, r, c = M.random_sparse(300, 6000, lambda row, rng: (3500 if row == 0 else 2900) if row in (0, 1, 137) else (0 if row % 11 == 0 else int(rng.integers(1, 9))), seed=12)
     mats.append((e, r, c, -1, np.random.default_rng(6).standard_normal(c)))
     for e, r, c, grid, x in mats:
         B.lib().spmv_amd_reset_host_matrices()
