@@ -41,10 +41,22 @@ configuration of reference docs/PROBLEM_SIZE_SCALING_RESULTS.md:40-47, on N row 
             iteration and around every halo exchange (no host syncs, overlap intact): interior SpMV, wait for the halo +
             boundary rows, p.Ap sum + all-reduce, r update, r.r sum + all-reduce + scalar step, direction update, gap
             before the next iteration; max / min over the ranks as the reference reports its timers (mgpu :748-800).
-  allreduce_ab  (N > 1) `value` is north_star's path: RCCL send/recv halos + ncclAllReduce on the two dot products.
-            The same K steps are then repeated with the peer-mailbox all-reduce (csrc/mailbox.hip) in CHILD processes,
-            one per rank, after the headline leg's slabs are freed: {"rccl": ms, "mailbox": ms | null, "other_leg": {...}}.
-            SPMV_AMD_BENCH_ALLREDUCE=mailbox swaps the two legs; --no-allreduce-ab skips the second.
+  allreduce_ab  (opt-in: --allreduce-ab, multi-rank runs) `value` is north_star's path: RCCL send/recv halos + ncclAllReduce on
+            the two dot products. With the flag the same K steps are then repeated with the peer-mailbox all-reduce
+            (csrc/mailbox.hip) in CHILD processes, one per rank: {"rccl": ms, "mailbox": ms | null, "other_leg": {...}}. The
+            headline line is written BEFORE that leg starts and written again, augmented, if the leg returns; a default run
+            never starts it, so a default `--gpus N` run has exactly N processes on the GPUs (N = 1: one more for the probe).
+            SPMV_AMD_BENCH_ALLREDUCE=mailbox swaps the two legs.
+
+Wall time, worst case of every DEFAULT path (the driver's limit for this file is 600 s):
+  N = 1   torch import + library (<= 120 s on a fresh box) + SpMV leg (~5 s) + (W + K + 1) solves of ~0.11 s + stream ceiling
+          (~0.1 s) + scaling probe in a child, ended after --probe-timeout = 150 s (~10 s when healthy) + CPU baseline
+          (~25 s of host work, no GPU) : < 330 s, ~25 s when healthy (BENCH_r03: 25.2 s).
+  N > 1   the same import + rendezvous (gloo, 120 s limit for the store) + (W + K + 1) solves + nothing else: rank 0 prints
+          the line as soon as the ranks have agreed on the measured leg. Every wait on a peer inside a solve ends after
+          SPMV_AMD_WATCHDOG_S = 60 s with a report; gloo collectives give up after 180 s; a self-launched run is ended by
+          its parent after --launch-timeout = 420 s, with a line that says so. < 420 s in every case, ~20 s when healthy.
+  --allreduce-ab adds one child leg, ended after --ab-timeout = 180 s; it cannot delay or remove the headline line.
 
 Multi-GPU: one process per GPU. Either the driver starts the ranks (`python -m torch.distributed.run
 --nproc-per-node N bench.py --gpus N ...`, RANK / WORLD_SIZE in the environment) or `python bench.py --gpus N`
@@ -90,6 +102,15 @@ def load_binding():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     return mod
+
+
+def log_process(role, rank=None):
+    """SPMV_AMD_BENCH_PROCESS_LOG=<file> (test hook): every process of a bench.py run appends one line saying what it is, so
+    a test can count the processes a command really started (tests/test_distributed.py)."""
+    path = os.environ.get("SPMV_AMD_BENCH_PROCESS_LOG")
+    if path:
+        with open(path, "a") as f:
+            f.write(json.dumps({"pid": os.getpid(), "role": role, "rank": rank, "argv": sys.argv[1:]}) + "\n")
 
 
 def reference_stats(times_ms):
@@ -310,6 +331,7 @@ def self_launch(args):
     import tempfile
 
     n = args.gpus
+    log_process("launcher")
     port = free_port()
     argv = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
     procs = []
@@ -325,15 +347,18 @@ def self_launch(args):
         procs.append(subprocess.Popen(argv, env=env, stdout=out0_file if rank == 0 else sys.stderr.fileno()))
     deadline = time.monotonic() + args.launch_timeout
     failed_at = None
+    ended_by_deadline = set()
     while any(p.poll() is None for p in procs):
         time.sleep(0.2)
         now = time.monotonic()
         if failed_at is None and any(p.poll() not in (None, 0) for p in procs):
             failed_at = now  # the other ranks notice through gloo / the solver's watchdog; give them a moment to report
         if (failed_at is not None and now - failed_at > args.launch_grace) or now > deadline:
-            for p in procs:
+            for i, p in enumerate(procs):
                 if p.poll() is None:
                     p.kill()  # exactly the children started above
+                    if failed_at is None:
+                        ended_by_deadline.add(i)
             break
     codes = [p.wait() for p in procs]
     out0_file.seek(0)
@@ -342,7 +367,17 @@ def self_launch(args):
     lines = [l for l in out0.splitlines() if l.startswith("{")]
     worst = max(codes, key=abs) if codes else 1
     if lines:
+        # the last line rank 0 wrote: the headline, or the headline augmented by an opt-in extra leg that completed
         sys.stdout.write(lines[-1] + "\n")
+        try:
+            measured = json.loads(lines[-1]).get("value") is not None
+        except ValueError:
+            measured = False
+        if measured and ended_by_deadline and all(c == 0 for i, c in enumerate(codes) if i not in ended_by_deadline):
+            # the measurement was complete and printed; only an opt-in extra was still running when the deadline came
+            print(f"bench.py: launcher deadline ({args.launch_timeout:.0f} s) reached after the headline line was written; "
+                  f"ranks {sorted(ended_by_deadline)} ended", file=sys.stderr)
+            worst = 0
     else:
         reason = f"ranks exited with {codes} and rank 0 printed no result line" + (" (launcher deadline reached)" if time.monotonic() > deadline else "")
         sys.stdout.write(json.dumps({"metric": "cg_iterations_per_second", "value": None, "unit": "CG iterations/s", "n_gpus": n,
@@ -391,6 +426,7 @@ def setup_process(args):
         print(f"bench.py: rank {c.rank} exiting with status 7 on request (SPMV_AMD_BENCH_TEST_CRASH_RANK)", file=sys.stderr)
         os._exit(7)
     c.local_rank = int(os.environ.get("LOCAL_RANK", str(c.rank)))
+    log_process("leg-child" if args.leg_only else "rank", c.rank)
     if c.world != args.gpus:
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={c.world}: running {c.world} rank(s)", file=sys.stderr)
         args.gpus = c.world
@@ -412,8 +448,9 @@ def setup_process(args):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if c.world == 1 and "MASTER_PORT" not in os.environ:  # SPMV_AMD_BENCH_FORCE_DIST without a launcher
             os.environ["MASTER_PORT"] = str(free_port())
+        # collectives of a healthy run take milliseconds; a rank that is gone must not hold the others past the driver's limit
         dist.init_process_group("gloo", rank=c.rank, world_size=c.world,
-                                timeout=datetime.timedelta(seconds=120 if args.leg_only else 600))
+                                timeout=datetime.timedelta(seconds=120 if args.leg_only else 180))
         dist.barrier()
     c.L = B.lib()
     return c
@@ -504,6 +541,10 @@ def measure_leg(c, allreduce_kind):
     try:
         for _ in range(args.warmup):
             st = slab.solve()
+        if args.leg_only and os.environ.get("SPMV_AMD_BENCH_TEST_KILL_LEG_CHILD") == "1":  # test hook: the extra leg dies mid-run
+            import signal
+
+            os.kill(os.getpid(), signal.SIGKILL)
         barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -557,10 +598,34 @@ def breakdown_summary(per_rank):
             "per_rank": per_rank}
 
 
+def run_child_for_record(argv, env, timeout_s, what):
+    """Runs one evidence-only child of this file and returns the JSON object of its last `{` line. Whatever happens to the
+    child -- non-zero exit, killed by a signal, no output, not done within timeout_s (it is then killed) -- comes back as a
+    record with an "error" key, never as an exception: the caller's own line does not depend on it."""
+    rec = None
+    try:
+        child = subprocess.run(argv, env=env, capture_output=True, text=True, timeout=timeout_s)
+        lines = [l for l in child.stdout.splitlines() if l.startswith("{")]
+        if lines:
+            try:
+                rec = json.loads(lines[-1])
+            except ValueError:
+                rec = None
+        if rec is None or child.returncode != 0:
+            how = f"killed by signal {-child.returncode}" if child.returncode < 0 else f"exited with {child.returncode}"
+            rec = dict(rec or {}, error=(rec or {}).get("error") or f"{what} {how}", stderr_tail=child.stderr[-600:])
+    except subprocess.TimeoutExpired:
+        rec = {"error": f"{what} did not finish within {timeout_s:.0f} s and was ended"}
+    except Exception as e:  # evidence only
+        rec = {"error": repr(e)}
+    return rec
+
+
 def other_allreduce_leg(c, kind, timeout_s):
-    """The same K steps with the OTHER all-reduce path, in child processes (one per rank, fresh rendezvous on a new port):
-    whatever happens there -- a failed set-up, a watchdog exit, a GPU fault in an unproven path -- the headline measured
-    above is still printed. Returns rank 0's record of the child leg (or the reason there is none)."""
+    """--allreduce-ab: the same K steps with the OTHER all-reduce path, in child processes (one per rank, fresh rendezvous on a
+    new port), started only after the headline line is on stdout: whatever happens there -- a failed set-up, a watchdog exit,
+    a GPU fault in an unproven path, a kill from outside -- the headline stands. Returns rank 0's record of the child leg
+    (or the reason there is none)."""
     port = [free_port() if c.rank == 0 else None]
     if c.multi:
         c.dist.broadcast_object_list(port, src=0)
@@ -575,20 +640,12 @@ def other_allreduce_leg(c, kind, timeout_s):
         env.pop(k)
     argv = [sys.executable, os.path.abspath(__file__), "--gpus", str(c.world), "--steps", str(c.args.steps), "--warmup", str(c.args.warmup),
             "--grid", str(c.args.grid), "--leg-only", kind]
-    rec = None
-    try:
-        child = subprocess.run(argv, env=env, capture_output=True, text=True, timeout=timeout_s)
-        lines = [l for l in child.stdout.splitlines() if l.startswith("{")]
-        if lines:
-            rec = json.loads(lines[-1])
-        if rec is None or child.returncode != 0:
-            rec = dict(rec or {}, error=(rec or {}).get("error") or f"child leg exited with {child.returncode}", stderr_tail=child.stderr[-600:])
-    except subprocess.TimeoutExpired:
-        rec = {"error": f"child leg did not finish within {timeout_s:.0f} s"}
-    except Exception as e:  # evidence only
-        rec = {"error": repr(e)}
+    rec = run_child_for_record(argv, env, timeout_s, "child leg")
     if c.multi:
-        c.dist.barrier()
+        try:
+            c.dist.barrier()
+        except Exception as e:  # a rank lost in the extra leg must not take the (already printed) headline's exit status with it
+            rec = dict(rec, barrier_after_leg=repr(e))
     return rec
 
 
@@ -603,8 +660,13 @@ def main():
     ap.add_argument("--no-spmv", action="store_true", help="skip the N=1 SpMV headline leg")
     ap.add_argument("--no-scaling-probe", action="store_true", help="skip the N=1 one-GPU strong-scaling probe")
     ap.add_argument("--no-ceiling", action="store_true", help="skip the in-run stream-ceiling probe")
-    ap.add_argument("--no-allreduce-ab", action="store_true", help="multi-rank runs: skip the second leg with the other all-reduce path")
-    ap.add_argument("--launch-timeout", type=float, default=1500.0, help="self-launch only: seconds before the parent ends the ranks")
+    ap.add_argument("--allreduce-ab", action="store_true",
+                    help="multi-rank runs, opt-in: after the headline line is printed, repeat the K steps with the other all-reduce path in child processes")
+    ap.add_argument("--no-allreduce-ab", action="store_true", help="(accepted for older command lines; the second leg is off unless --allreduce-ab)")
+    ap.add_argument("--ab-timeout", type=float, default=180.0, help="--allreduce-ab: seconds before the child leg is ended")
+    ap.add_argument("--probe-timeout", type=float, default=150.0, help="N = 1: seconds before the scaling-probe child is ended")
+    ap.add_argument("--launch-timeout", type=float, default=420.0,
+                    help="self-launch only: seconds before the parent ends the ranks (below the driver's 600 s limit for this file)")
     ap.add_argument("--launch-grace", type=float, default=90.0,
                     help="self-launch only: seconds the other ranks get to report after one rank has exited non-zero")
     ap.add_argument("--scaling-probe-only", nargs=2, metavar=("FULL_MS", "FULL_ITERATIONS"), default=None,
@@ -635,6 +697,7 @@ def main():
         B.require_gpu()
         torch.cuda.set_device(0)
         B.lib().spmv_amd_set_device(0)
+        log_process("probe-child")
         emit(scaling_probe(B, torch, args.grid, float(args.scaling_probe_only[0]), int(args.scaling_probe_only[1])))
         return
 
@@ -754,17 +817,6 @@ def main():
 
     devices = gather(c, {"rank": rank, "device": c.device_index, "pci_bus_id": c.pci})
 
-    # second leg, multi-rank runs only: the same K steps with the other all-reduce path, in child processes
-    allreduce_ab = None
-    if multi and not args.no_allreduce_ab and transport == "rccl":
-        other = "mailbox" if headline_kind == "rccl" else "rccl"
-        child = other_allreduce_leg(c, other, timeout_s=max(300.0, 20.0 * (args.steps + args.warmup)))
-        allreduce_ab = {headline_kind: leg["ms_per_step"], other: child.get("ms_per_step"), "headline": headline_kind,
-                        "unit": "ms per step (one CG solve), max over ranks, same K steps after the same warm-ups",
-                        "other_leg": child,
-                        "note": "the other leg runs in child processes after the headline leg has been measured and its slabs freed: "
-                                "its failure cannot touch `value`"}
-
     out = None
     if rank == 0:
         value = args.steps * iterations / dt
@@ -781,25 +833,43 @@ def main():
                    launched_by="bench.py (self-launched ranks)" if os.environ.get("SPMV_AMD_BENCH_SELF_LAUNCHED") == "1" else
                    ("external launcher (RANK/WORLD_SIZE in the environment)" if "RANK" in os.environ else "single process"),
                    roofline=roofline)
-        if allreduce_ab is not None:
-            out["allreduce_ab"] = allreduce_ab
+        if leg.get("placement") is not None:
+            out["placement_trials"] = leg["placement"]
         if degraded:
             out["degraded"] = degraded
         if spmv is not None:
             out["spmv"] = spmv
 
-    if rank == 0 and world == 1 and not multi and not args.no_scaling_probe and n >= 8192:
-        # evidence only, in a child process: whatever happens to it, the benchmark line above is printed
+    if multi:
+        # A multi-rank run has nothing left to measure: the line goes out NOW, while every rank process is still alive and
+        # before anything optional can start. A default run ends here with exactly `world` processes on the GPUs.
+        if rank == 0:
+            emit(out)
+        if args.allreduce_ab and transport == "rccl":
+            # opt-in second leg: the same K steps with the other all-reduce path, in child processes; if it returns, the
+            # line is written once more with the comparison added (a reader takes the last line; the first one stands alone)
+            other = "mailbox" if headline_kind == "rccl" else "rccl"
+            child = other_allreduce_leg(c, other, timeout_s=args.ab_timeout)
+            if rank == 0:
+                out["allreduce_ab"] = {headline_kind: leg["ms_per_step"], other: child.get("ms_per_step"), "headline": headline_kind,
+                                       "unit": "ms per step (one CG solve), max over ranks, same K steps after the same warm-ups",
+                                       "other_leg": child,
+                                       "note": "the other leg runs in child processes after the headline line has been written: "
+                                               "its failure cannot touch `value`"}
+                emit(out)
+        leave(0)
+
+    # single process (N = 1): the evidence-only extras, each bounded, then the ONE line
+    if rank == 0 and not args.no_scaling_probe and n >= 8192:
+        # in a child process: whatever happens to it, the benchmark line is printed
+        out["scaling_probe"] = run_child_for_record(
+            [sys.executable, os.path.abspath(__file__), "--grid", str(n), "--scaling-probe-only", repr(out["ms_per_step"]), str(iterations)],
+            dict(os.environ), args.probe_timeout, "scaling probe")
+    if rank == 0 and not args.no_cpu_baseline:
         try:
-            child = subprocess.run([sys.executable, os.path.abspath(__file__), "--grid", str(n), "--scaling-probe-only",
-                                    repr(out["ms_per_step"]), str(iterations)], capture_output=True, text=True, timeout=600)
-            lines = [l for l in child.stdout.splitlines() if l.startswith("{")]
-            out["scaling_probe"] = json.loads(lines[-1]) if child.returncode == 0 and lines else {
-                "error": f"probe exited with {child.returncode}", "stderr_tail": child.stderr[-400:]}
-        except Exception as e:
-            out["scaling_probe"] = {"error": repr(e)}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args.cpu_sample_grid, rows)
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample_grid, rows)
+        except Exception as e:  # the checker failing to build or load must not take the GPU measurement with it
+            out["cpu_baseline"] = {"value": None, "error": repr(e)}
     if rank == 0:
         emit(out)
     leave(0)

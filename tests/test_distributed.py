@@ -38,17 +38,6 @@ def free_port():
 
 
 def launch(world, mode, n, timeout=300):
-    """launch_once, repeated once if the rendezvous port turned out to be taken (EADDRINUSE: a property of the box's port
-    table at that moment, not of the code under test)."""
-    try:
-        return launch_once(world, mode, n, timeout)
-    except AssertionError as e:
-        if "EADDRINUSE" not in str(e):
-            raise
-        return launch_once(world, mode, n, timeout)
-
-
-def launch_once(world, mode, n, timeout=300):
     """Starts `world` ranks of tests/dist_worker.py. A rank that fails must not leave the others waiting in a gloo
     collective until some outer limit: as soon as one exits non-zero (or the deadline passes) the rest are ended and
     the failing rank's output is reported."""
@@ -214,9 +203,10 @@ TIMELINE_KEYS = ["iterations", "solve_ms", "initial_residual_us", "spmv_interior
                  "halo_exchange_on_side_stream_us", "final_x_flush_us"]
 
 
-def check_multi_rank_line(line, world, mailbox_must_work=True):
+def check_multi_rank_line(line, world, mailbox_must_work=True, with_ab=False):
     """What a multi-rank bench line must carry so that the number arrives with its own parity statement: the golden
-    comparison, the ranks' agreement, the per-rank stage breakdown and both all-reduce figures."""
+    comparison, the ranks' agreement, the per-rank stage breakdown and -- only when --allreduce-ab asked for the second
+    leg -- both all-reduce figures."""
     assert line["value"] is not None and line["n_gpus"] == world and line["transport"] == "rccl"
     assert line["allreduce"] == "ncclAllReduce"  # north_star's path is the headline
     p = line["parity_vs_golden"]
@@ -227,6 +217,9 @@ def check_multi_rank_line(line, world, mailbox_must_work=True):
     for r in b["per_rank"]:
         assert all(k in r for k in TIMELINE_KEYS) and r["spmv_interior_us"] > 0 and r["iteration_us"] > 0
     assert set(TIMELINE_KEYS) - {"iterations"} <= set(b["max_over_ranks"]) and b["max_over_ranks"]["iteration_us"] >= b["min_over_ranks"]["iteration_us"]
+    if not with_ab:
+        assert "allreduce_ab" not in line  # a default run measures north_star's path and nothing else
+        return
     ab = line["allreduce_ab"]
     assert ab["headline"] == "rccl" and ab["rccl"] == line["ms_per_step"]
     o = ab["other_leg"]
@@ -238,13 +231,21 @@ def check_multi_rank_line(line, world, mailbox_must_work=True):
     assert "peer mailbox" in o["allreduce"] and o["parity_vs_golden"]["ok"] and len(o["breakdown"]["per_rank"]) == world
 
 
+def read_process_log(path):
+    return [json.loads(l) for l in open(path).read().splitlines() if l.strip()] if os.path.exists(path) else []
+
+
+FORCED_MULTI_ENV = dict(SPMV_AMD_BENCH_FORCE_DIST="1", SPMV_AMD_FORCE_COLLECTIVES="1", SPMV_AMD_SELF_NEIGHBOUR="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+
+
 @pytest.mark.gpu
-def test_bench_multi_rank_line_carries_parity_breakdown_and_both_allreduce_legs():
-    """One GPU, the complete multi-rank pipeline (SPMV_AMD_BENCH_FORCE_DIST + SPMV_AMD_SELF_NEIGHBOUR: RCCL send / recv
-    of the halo rows on the side stream, split SpMV launches, ncclAllReduce of both dot products) on the 2000 x 2000 grid,
-    for which a golden history is committed: the line carries parity_vs_golden, the stage breakdown and allreduce_ab with
-    the mailbox leg measured in a child process."""
-    env = dict(os.environ, SPMV_AMD_BENCH_FORCE_DIST="1", SPMV_AMD_FORCE_COLLECTIVES="1", SPMV_AMD_SELF_NEIGHBOUR="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+def test_bench_multi_rank_default_run_is_lean(tmp_path):
+    """One GPU, the complete multi-rank pipeline (SPMV_AMD_BENCH_FORCE_DIST + SPMV_AMD_SELF_NEIGHBOUR: RCCL send / recv of the
+    halo rows on the side stream, split SpMV launches, ncclAllReduce of both dot products) on the 2000 x 2000 grid, for which a
+    golden history is committed, WITHOUT any option: exactly one process touched the GPU (the rank; no child leg, no probe),
+    ONE line, with parity_vs_golden and the stage breakdown and no allreduce_ab."""
+    log = tmp_path / "procs.jsonl"
+    env = dict(os.environ, SPMV_AMD_BENCH_PROCESS_LOG=str(log), **FORCED_MULTI_ENV)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--grid", "2000",
                           "--no-cpu-baseline", "--no-spmv"], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
@@ -252,7 +253,40 @@ def test_bench_multi_rank_line_carries_parity_breakdown_and_both_allreduce_legs(
     assert len(lines) == 1
     check_multi_rank_line(lines[0], 1)
     assert lines[0]["breakdown"]["per_rank"][0]["halo_exchange_on_side_stream_us"] > 0
-    assert lines[0]["rccl_ranks"] == 1
+    assert lines[0]["rccl_ranks"] == 1 and "scaling_probe" not in lines[0]
+    assert [p["role"] for p in read_process_log(log)] == ["rank"]
+
+
+@pytest.mark.gpu
+def test_bench_multi_rank_line_carries_both_allreduce_legs_when_asked():
+    """--allreduce-ab: the headline line first, alone; then the mailbox leg in a child process and the line again with
+    allreduce_ab added."""
+    env = dict(os.environ, **FORCED_MULTI_ENV)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--grid", "2000",
+                          "--no-cpu-baseline", "--no-spmv", "--allreduce-ab"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = _json_lines(out.stdout)
+    assert len(lines) == 2
+    check_multi_rank_line(lines[0], 1)
+    check_multi_rank_line(lines[1], 1, with_ab=True)
+    assert lines[1]["value"] == lines[0]["value"] and lines[1]["config"] == lines[0]["config"]
+
+
+@pytest.mark.gpu
+def test_bench_headline_survives_a_second_leg_that_is_killed(tmp_path):
+    """--allreduce-ab with the child leg ending itself by SIGKILL after its warm-ups (SPMV_AMD_BENCH_TEST_KILL_LEG_CHILD), the way
+    a process guard or an out-of-memory kill would: the headline line was already written, the exit status is 0, and the
+    second line says what happened to the leg."""
+    log = tmp_path / "procs.jsonl"
+    env = dict(os.environ, SPMV_AMD_BENCH_TEST_KILL_LEG_CHILD="1", SPMV_AMD_BENCH_PROCESS_LOG=str(log), **FORCED_MULTI_ENV)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--grid", "2000",
+                          "--no-cpu-baseline", "--no-spmv", "--allreduce-ab"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = _json_lines(out.stdout)
+    assert len(lines) == 2 and lines[0]["value"] is not None and lines[0]["parity_vs_golden"]["ok"] and "allreduce_ab" not in lines[0]
+    ab = lines[1]["allreduce_ab"]
+    assert lines[1]["value"] == lines[0]["value"] and ab["mailbox"] is None and "signal 9" in ab["other_leg"]["error"], ab
+    assert sorted(p["role"] for p in read_process_log(log)) == ["leg-child", "rank"]
 
 
 @pytest.mark.gpu
@@ -303,19 +337,21 @@ def test_slab_solver_over_rccl_between_devices(world, n, mode):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("world", [2, 4])
-def test_bench_over_rccl_between_devices(world):
+def test_bench_over_rccl_between_devices(world, tmp_path):
     """`python bench.py --gpus N` as the driver runs it, on N devices, at the 2000 x 2000 grid (golden history committed):
-    rccl_ranks == N, parity_vs_golden green, breakdown for every rank, both all-reduce legs."""
+    rccl_ranks == N, parity_vs_golden green, breakdown for every rank, exactly N rank processes."""
     need_gpus(world)
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    log = tmp_path / "procs.jsonl"
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", SPMV_AMD_BENCH_PROCESS_LOG=str(log))
     env.pop("RANK", None), env.pop("WORLD_SIZE", None)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "3", "--warmup", "1", "--grid", "2000"],
                          env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout + out.stderr
     lines = _json_lines(out.stdout)
     assert len(lines) == 1 and lines[0]["rccl_ranks"] == world
-    check_multi_rank_line(lines[0], world, mailbox_must_work=False)
+    check_multi_rank_line(lines[0], world)
     assert len({d["pci_bus_id"] for d in lines[0]["devices"]}) == world  # distinct devices
+    assert sorted(p["role"] for p in read_process_log(log)) == ["launcher"] + ["rank"] * world  # N processes on the GPUs, no more
 
 
 def test_bench_self_launches_its_ranks_and_fails_loudly_without_gpus():
@@ -331,6 +367,57 @@ def test_bench_self_launches_its_ranks_and_fails_loudly_without_gpus():
     assert len(lines) == 1 and lines[0]["value"] is None and lines[0]["n_gpus"] == 2
     assert "rank 0:" in lines[0]["unmeasured"] and "rank 1:" in lines[0]["unmeasured"]
     assert "UNMEASURED" in out.stderr
+
+
+def test_bench_default_multi_gpu_command_starts_exactly_n_rank_processes(tmp_path):
+    """`python bench.py --gpus 2` with every default: the processes of the run are the launcher (no torch, no GPU) and two
+    ranks -- no second leg, no probe, nothing else that could touch a GPU (no GPU here: the ranks then report UNMEASURED)."""
+    log = tmp_path / "procs.jsonl"
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="", SPMV_AMD_BENCH_PROCESS_LOG=str(log))
+    env.pop("RANK", None), env.pop("WORLD_SIZE", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 3, out.stdout + out.stderr
+    procs = read_process_log(log)
+    assert sorted(p["role"] for p in procs) == ["launcher", "rank", "rank"] and sorted(p["rank"] for p in procs if p["role"] == "rank") == [0, 1]
+
+
+def load_bench_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_bench_extra_leg_runner_survives_a_killed_a_silent_and_a_slow_child(tmp_path):
+    """run_child_for_record() is how bench.py starts everything that is evidence only (the --allreduce-ab leg, the N = 1
+    scaling probe). A child that is SIGKILLed mid-run, one that prints nothing, one that overruns its limit: each comes back
+    as a record with "error", within the limit, never as an exception -- the caller's headline does not depend on it."""
+    bench = load_bench_module()
+    killed = tmp_path / "killed.py"
+    killed.write_text("import os, signal, sys\nprint('{\"partial\": 1}', flush=True)\nos.kill(os.getpid(), signal.SIGKILL)\n")
+    rec = bench.run_child_for_record([sys.executable, str(killed)], dict(os.environ), 60, "child leg")
+    assert rec["partial"] == 1 and "signal 9" in rec["error"]
+    silent = tmp_path / "silent.py"
+    silent.write_text("import sys\nsys.exit(0)\n")
+    assert "error" in bench.run_child_for_record([sys.executable, str(silent)], dict(os.environ), 60, "child leg")
+    slow = tmp_path / "slow.py"
+    slow.write_text("import time\ntime.sleep(600)\n")
+    t0 = time.monotonic()
+    rec = bench.run_child_for_record([sys.executable, str(slow)], dict(os.environ), 2, "child leg")
+    assert "did not finish within 2 s" in rec["error"] and time.monotonic() - t0 < 30
+    good = tmp_path / "good.py"
+    good.write_text("print('noise')\nprint('{\"ms_per_step\": 1.5}')\n")
+    assert bench.run_child_for_record([sys.executable, str(good)], dict(os.environ), 60, "child leg") == {"ms_per_step": 1.5}
+
+
+def test_bench_default_timeouts_fit_the_drivers_limit():
+    """The driver ends bench.py after 600 s: every limit bench.py sets for itself must expire first, so that its own line
+    (with the reason) is what the driver reads."""
+    import re
+    defaults = {m.group(1): float(m.group(2)) for m in re.finditer(r'"--([a-z-]+-timeout)", type=float, default=([0-9.]+)', open(os.path.join(ROOT, "bench.py")).read())}
+    assert set(defaults) == {"ab-timeout", "probe-timeout", "launch-timeout"}
+    assert defaults["launch-timeout"] < 600 and defaults["ab-timeout"] < defaults["launch-timeout"] and defaults["probe-timeout"] + 180 < 600
 
 
 def test_bench_self_launch_reports_a_rank_that_died():
