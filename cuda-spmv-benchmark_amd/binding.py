@@ -93,7 +93,7 @@ DECLARED_SYMBOLS = [
     "spmv_amd_comm_mailbox_disable", "spmv_amd_comm_mailbox_ready",
     "spmv_amd_cg_slab_create", "spmv_amd_cg_slab_create_stencil5", "spmv_amd_cg_slab_create_stencil5_as", "spmv_amd_cg_slab_set_vectors", "spmv_amd_cg_slab_solve",
     "spmv_amd_cg_slab_gather", "spmv_amd_cg_slab_history", "spmv_amd_cg_slab_spmv", "spmv_amd_cg_slab_info",
-    "spmv_amd_cg_slab_time_spmv", "spmv_amd_cg_slab_set_timeline", "spmv_amd_cg_slab_timeline_names", "spmv_amd_cg_slab_timeline", "spmv_amd_cg_slab_variant", "spmv_amd_cg_slab_destroy", "spmv_amd_version", "spmv_amd_write_stencil5_values",
+    "spmv_amd_cg_slab_time_spmv", "spmv_amd_cg_slab_set_timeline", "spmv_amd_cg_slab_set_option", "spmv_amd_cg_release_workspace", "spmv_amd_cg_slab_timeline_names", "spmv_amd_cg_slab_timeline", "spmv_amd_cg_slab_variant", "spmv_amd_cg_slab_destroy", "spmv_amd_version", "spmv_amd_write_stencil5_values",
     "spmv_amd_blas1_axpy", "spmv_amd_blas1_axpby", "spmv_amd_blas1_axpy_dev", "spmv_amd_blas1_update_p_dev", "spmv_amd_blas1_dot",
     "spmv_amd_cg_fused_step",
 ]
@@ -197,6 +197,8 @@ def lib():
     L.spmv_amd_cg_slab_destroy.argtypes = [C.c_void_p]
     L.spmv_amd_cg_slab_set_timeline.argtypes = [C.c_void_p, C.c_int]
     L.spmv_amd_cg_slab_set_timeline.restype = None
+    L.spmv_amd_cg_slab_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_longlong]
+    L.spmv_amd_cg_slab_set_option.restype = C.c_int
     L.spmv_amd_cg_slab_timeline_names.restype = C.c_char_p
     L.spmv_amd_cg_slab_timeline.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     L.spmv_amd_cg_slab_variant.restype = C.c_char_p
@@ -606,6 +608,11 @@ class CgSlab:
         v = np.zeros(len(names), dtype=np.float64)
         count = lib().spmv_amd_cg_slab_timeline(self.h, v.ctypes.data, len(v))
         return st, ({k: float(x) for k, x in zip(names, v)} if count == len(names) else {})
+
+    def set_option(self, name, value):
+        """Loop option of this slab ("late_bulk", "lead_rows", "early_halo", "pingpong", "r_pingpong"): A/B runs on the same allocations."""
+        if lib().spmv_amd_cg_slab_set_option(self.h, name.encode(), int(value)) != 0:
+            raise ValueError(f"unknown slab option {name!r}")
 
     def time_spmv(self, reps):
         ms = (C.c_float * reps)()

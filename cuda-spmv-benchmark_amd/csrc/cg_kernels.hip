@@ -278,10 +278,12 @@ __global__ __launch_bounds__(kStream) void cg_init_residual_kernel(size_t n, con
     block_partial(acc, partials);
 }
 
-// r -= alpha*Ap with the r.r partials (axpy_kernel(-alpha, Ap, r) + the dot, mgpu :612,627).
+// r -= alpha*Ap with the r.r partials (axpy_kernel(-alpha, Ap, r) + the dot, mgpu :612,627). r_out may be r_in (the
+// reference's in-place update) or a second buffer (SPMV_AMD_R_PINGPONG, an A/B aid): every element is loaded before it
+// is stored, so neither pointer is declared restrict.
 __global__ __launch_bounds__(kStream) void cg_update_r_kernel(size_t n, const CgScalars* __restrict__ s,
                                                              const double* __restrict__ Ap,
-                                                             double* __restrict__ r,
+                                                             const double* r_in, double* r,
                                                              double* __restrict__ partials, int reverse) {
     // The vector loads are issued BEFORE the scalars are looked at: a wave does not wait for the scalar loads, the
     // convergence test and an fp64 division ahead of its first memory request (a launch enqueued past convergence
@@ -293,7 +295,7 @@ __global__ __launch_bounds__(kStream) void cg_update_r_kernel(size_t n, const Cg
     d2 av = {0.0, 0.0}, rv = {0.0, 0.0};
     if (i < pairs) {
         av = load_once(Ap, i);
-        rv = load_once(r, i);
+        rv = load_once(r_in, i);
     }
     const int converged = s->converged;
     const double rr_old = s->rr_old, pAp = s->pAp;
@@ -308,7 +310,7 @@ __global__ __launch_bounds__(kStream) void cg_update_r_kernel(size_t n, const Cg
         acc = fma(rv.y, rv.y, acc);
     }
     if ((n & 1) && block == 0 && threadIdx.x == 0) {
-        const double rl = fma(-alpha, Ap[n - 1], r[n - 1]);
+        const double rl = fma(-alpha, Ap[n - 1], r_in[n - 1]);
         r[n - 1] = rl;
         acc = fma(rl, rl, acc);
     }
@@ -524,8 +526,8 @@ void launch_cg_init_residual(size_t n, const double* b, const double* Ap, double
 }
 
 void launch_cg_update_r(size_t n, const CgScalars* s, const double* Ap, double* r, double* partials,
-                        hipStream_t stream, bool reverse) {
-    hipLaunchKernelGGL(cg_update_r_kernel, dim3(stream_grid(n)), dim3(kStream), 0, stream, n, s, Ap, r, partials,
+                        hipStream_t stream, bool reverse, const double* r_in) {
+    hipLaunchKernelGGL(cg_update_r_kernel, dim3(stream_grid(n)), dim3(kStream), 0, stream, n, s, Ap, r_in ? r_in : r, r, partials,
                        reverse ? 1 : 0);
 }
 

@@ -116,6 +116,7 @@ int cg_solve(SpmvOperator* spmv_op, MatrixData* mat, const double* b, double* x,
     // operator WITHOUT a device entry point (run_device == NULL is legal, reference include/spmv.h:125-134) is driven through
     // run_timed exactly as upstream. Scalars (alpha, beta, the norms) stay on the host either way: that is what this entry point is.
     const bool through_host = spmv_op->run_device == nullptr;
+    bool op_failed = false;  // run_device returned non-zero: stop, release everything, return 1 (never exit() from a library)
     auto host_spmv = [&](const double* d_in, double* d_out) {
         double kernel_ms = 0.0;
         part.begin(kStream);
@@ -125,7 +126,7 @@ int cg_solve(SpmvOperator* spmv_op, MatrixData* mat, const double* b, double* x,
             upload(d_out, h_out, (size_t)n);
         } else if (spmv_op->run_device(d_in, d_out) != 0) {
             fprintf(stderr, "[CG] operator '%s': run_device failed\n", spmv_op->name);
-            exit(EXIT_FAILURE);
+            op_failed = true;
         }
         part.end(kStream);
         t_spmv += part.elapsed_ms();
@@ -148,8 +149,9 @@ int cg_solve(SpmvOperator* spmv_op, MatrixData* mat, const double* b, double* x,
 
     int iter;
     double residual_norm = b_norm;
-    for (iter = 0; iter < config.max_iters; iter++) {
+    for (iter = 0; iter < config.max_iters && !op_failed; iter++) {
         host_spmv(v.p, v.Ap);
+        if (op_failed) break;
         const double pAp = host_dot(v.Ap, v.p);
         const double alpha = rr_old / pAp;
         timed_blas([&] { launch_axpy((size_t)n, alpha, v.p, v.x, kStream); });
@@ -180,13 +182,13 @@ int cg_solve(SpmvOperator* spmv_op, MatrixData* mat, const double* b, double* x,
     stats->time_reductions_ms = t_red;
     stats->converged = (residual_norm / b_norm < config.tolerance) ? 1 : 0;
     fill_solution_checksums(x, n, &stats->solution_sum, &stats->solution_norm);
-    if (config.verbose >= 1) print_breakdown("CG", stats);
+    if (config.verbose >= 1 && !op_failed) print_breakdown("CG", stats);
 
     v.release();
     device_release(d_scalar);
     if (h_in) (void)hipHostFree(h_in);
     if (h_out) (void)hipHostFree(h_out);
-    return 0;
+    return op_failed ? 1 : 0;
 }
 
 int cg_solve_device(SpmvOperator* spmv_op, MatrixData* mat, const double* b, double* x,

@@ -38,6 +38,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
 #include <vector>
 
 #include "comm.hpp"
@@ -63,6 +64,7 @@ struct SpmvAmdCgSlab {
     // stencil5-csr, through its fused launch (FusedSpmv: p.Ap partials / initial residual written by the SpMV itself).
     // Such a slab is the whole matrix on one rank, has no halos, and runs on the DEFAULT stream, where run_device enqueues.
     SpmvOperator* op = nullptr;
+    bool op_failed = false;  // the borrowed operator's run_device returned non-zero: the solve stops enqueuing and returns 1
     FusedSpmv fused;
     const char* label = nullptr;  // verbose prefix of the reference entry point that owns the solve ("CG-DEVICE")
     bool device_form = false;     // direction update rounded as update_p_kernel does (cg_solver.cu:90-95), see cg_kernels.hip
@@ -134,6 +136,20 @@ struct SpmvAmdCgSlab {
     bool roctx_always = false;  // SPMV_AMD_ROCTX=1: roctx ranges even without detailed timers
     bool no_overlap = false;  // SPMV_AMD_NO_OVERLAP=1: halo exchange on the compute stream, for A/B runs of the overlap
     bool early_halo = true;   // SPMV_AMD_EARLY_HALO=0: halo exchange only after the whole direction update (round 2's order)
+    // Late bulk (round 4): the direction update of iteration k is enqueued before the host knows whether k converged, and on
+    // the converging iteration that launch only reads a flag -- 3.1 M one-wave workgroups at 4e8 rows, 0.65 ms of pure
+    // dispatch per solve. On large slabs the host enqueues a LEAD piece of lead_rows rows (long enough to cover one host
+    // wake-up and a launch), reads the status record, and enqueues the rest only if the loop goes on: the reference tests
+    // convergence before its p update too (cg_solver_mgpu_partitioned.cu:652-676). Same kernel over disjoint row ranges:
+    // same bits. Measured at 4e8 rows on one slab, settings alternated between solves: 108.04 -> 107.34 ms per solve, -0.65 %
+    // (profiles/r04_ab_late_bulk.txt). Small slabs (a whole update is ~0.2 ms at 5e7 rows) keep the single launch;
+    // SPMV_AMD_LATE_BULK=0/1 forces. Ring mode only.
+    bool late_bulk = false;
+    size_t lead_rows = (size_t)1 << 24;
+    // A/B aid (SPMV_AMD_R_PINGPONG=1): the r update writes into a second buffer instead of in place (+8 B/row of HBM).
+    // Measured SLOWER at 4e8 rows: r update 1.446 -> 1.473 ms, solve +0.5 % (profiles/r04_ab_r_pingpong.txt); off.
+    bool r_pingpong = false;
+    double* r2 = nullptr;
     int poll_sequence = 0;
     double last_spmv_ms = 0.0;
     int last_spmv_launches = 0;
@@ -146,7 +162,7 @@ constexpr int kTimelineMarks = 7;
 const char* const kTimelineNames =
     "iterations,solve_ms,initial_residual_us,spmv_interior_us,halo_wait_and_boundary_rows_us,reduce_pAp_and_allreduce_us,"
     "update_r_us,reduce_rr_allreduce_and_scalar_step_us,direction_update_us,gap_before_next_iteration_us,iteration_us,"
-    "halo_exchange_on_side_stream_us,final_x_flush_us";
+    "halo_exchange_on_side_stream_us,final_x_flush_us,direction_updates";
 }  // namespace
 
 namespace {
@@ -227,7 +243,12 @@ void make_common(SpmvAmdCgSlab* s) {
         const size_t keep_free = (size_t)4 << 30;  // leave room for the caller's own buffers
         const size_t per_slot = slot_doubles * sizeof(double);
         const int asked = want;
-        while (want > 1 && (size_t)(want - 1) * per_slot + keep_free > free_b) --want;
+        // A slab that owns its matrix may take what is free. The workspace of cg_solve_device outlives the call (until an
+        // operator's free() or spmv_amd_cg_release_workspace()) next to a caller who goes on allocating -- a second operator,
+        // say -- so its ring is held to a quarter of what is free now: 16 slots of 3.2 GB at 4e8 rows on an otherwise idle
+        // MI355X, fewer on a fuller device, the in-place form when even four do not fit.
+        const size_t budget = s->op != nullptr ? free_b / 4 : (free_b > keep_free ? free_b - keep_free : 0);
+        while (want > 1 && (size_t)(want - 1) * per_slot > budget) --want;
         if (want < asked && want < 4) want = 1;  // a ring cut short by memory flushes too often to pay
         for (int k = 1; k < want; ++k) {
             double* a = device_alloc<double>(slot_doubles);
@@ -248,6 +269,11 @@ void make_common(SpmvAmdCgSlab* s) {
     if (const char* v = getenv("SPMV_AMD_NO_OVERLAP")) s->no_overlap = v[0] == '1';
     if (const char* v = getenv("SPMV_AMD_EARLY_HALO")) s->early_halo = v[0] != '0';
     if (const char* v = getenv("SPMV_AMD_ROCTX")) s->roctx_always = v[0] == '1';
+    s->late_bulk = nl >= 100000000;
+    if (const char* v = getenv("SPMV_AMD_LATE_BULK")) s->late_bulk = v[0] == '1';
+    if (const char* v = getenv("SPMV_AMD_LEAD_ROWS")) s->lead_rows = (size_t)atoll(v) / 512 * 512;
+    if (s->lead_rows < 512) s->lead_rows = 512;
+    if (const char* v = getenv("SPMV_AMD_R_PINGPONG")) s->r_pingpong = v[0] == '1';
     s->partials_blas = device_alloc<double>(dot_scratch_doubles(nl));
     s->reduce_stage = device_alloc<double>((size_t)reduce_stage_doubles());
     // (their last slot was the ticket counter of round 2's one-launch reduction; kept zeroed, unused)
@@ -354,8 +380,10 @@ int slab_spmv(SpmvAmdCgSlab* s, bool with_dot, bool overlap, const int* skip,
         if (part != nullptr) {
             used = s->fused.launch(in, s->Ap, part, skip, s->shape.reverse, init, s->compute);
         } else if (s->op->run_device(in, s->Ap) != 0) {
+            // The reference ignores this return value (cg_solver.cu:498,541); a library must not end its caller's process
+            // over it either: remember it, let the solve wind down and hand the failure back as a status.
             fprintf(stderr, "[cg] operator '%s': run_device failed\n", s->op->name);
-            exit(EXIT_FAILURE);
+            s->op_failed = true;
         }
         if (s->tl_after_interior) HIP_CHECK(hipEventRecord(s->tl_after_interior, s->compute));
     } else if (!overlap || hi <= lo || (lo == 0 && hi == s->n_local)) {
@@ -541,6 +569,7 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
     const PeerMailbox* mailbox = (reduce && comm->mailbox_ready()) ? comm->d_mailbox : nullptr;
     const bool separate = reduce && mailbox == nullptr;
     s->reduce_mailbox = nullptr;  // the initial SpMV has no dot product
+    s->op_failed = false;
     memset(stats, 0, sizeof(*stats));
 
     // residual history: one slot per iteration, capped at 2^20 entries (later iterations go unrecorded)
@@ -679,10 +708,15 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
     start_p_halo();
 
     // ---- iterations ----
+    if (s->r_pingpong && s->r2 == nullptr) s->r2 = device_alloc<double>(nl);
+    double* r_cur = s->r;  // the residual of the iteration being enqueued; with r_pingpong the update alternates r / r2
+    double* r_alt = s->r_pingpong ? s->r2 : nullptr;
+    // (ring mode only: with the in-place form the x update of the converging iteration rides in that very launch)
+    const bool late = s->late_bulk && !detail && slots > 1;
     int enqueued = 0, sampled = 0;
     std::vector<int> sampled_iteration;  // 0-based loop index of each timed SpMV
     bool done = false;
-    while (!done && enqueued < config->max_iters) {
+    while (!done && !s->op_failed && enqueued < config->max_iters) {
         // SpMV and x/p update of iteration k walk one way, the r update between them the other way; the
         // direction flips every iteration, so every kernel starts where the previous one ended
         const bool backward = s->pingpong && (enqueued & 1) == 0;  // iteration 0 follows the forward initial-residual pass
@@ -720,6 +754,7 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
         }
         trace.pop();
         s->spmv_progress = nullptr;
+        if (s->op_failed) break;  // nothing of this iteration is awaited yet: the status record's sequence is advanced below
         s->enqueued_stage = "all-reduce of p.Ap";
         if (separate || (reduce && !s->fused_dot)) {
             TraceScope r(trace, "AllReduce");
@@ -729,7 +764,9 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
         s->enqueued_stage = "r update";
         trace.push("BLAS_AXPY");
         timed(&stats->time_blas1_ms, &stats->time_axpy_update_r_ms, [&] {
-            launch_cg_update_r(nl, s->d_s, s->Ap, s->r, s->partials_blas, s->compute, s->pingpong && !backward);
+            double* r_out = r_alt ? r_alt : r_cur;
+            launch_cg_update_r(nl, s->d_s, s->Ap, r_out, s->partials_blas, s->compute, s->pingpong && !backward, r_cur);
+            if (r_alt) r_alt = r_cur, r_cur = r_out;
         });
         trace.pop();
         mark(enqueued, 4);
@@ -782,16 +819,39 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
         const size_t tail_rows = nl - tail_start;
         const bool early_halo = multi && !detail && !s->no_overlap && s->early_halo && (nl % 2) == 0 && nl >= 4 * (size_t)s->halo + 4 * kAlign &&
                                 head_rows < tail_start;
+        // The bulk of the update over rows [lo, hi), lo on a 4 KiB boundary. Late bulk: the piece the sweep walks first, then
+        // the status record, then -- unless the iteration converged -- the rest; the lead piece keeps the GPU busy while
+        // the host reads the record and launches.
+        bool status_known = false;
+        auto bulk = [&](auto&& update, size_t lo, size_t hi) {
+            if (!late || hi - lo < 4 * s->lead_rows) {
+                update(lo, hi - lo, backward);
+                return;
+            }
+            const size_t cut = backward ? (hi - s->lead_rows) / kAlign * kAlign : lo + s->lead_rows;
+            if (backward)
+                update(cut, hi - cut, true);
+            else
+                update(lo, cut - lo, false);
+            s->enqueued_stage = "direction update (lead piece)";
+            wait_for_status(s);
+            status_known = true;
+            if (s->h_poll->converged) return;  // the loop ends here: nothing reads the rest of this direction
+            if (backward)
+                update(lo, cut - lo, true);
+            else
+                update(cut, hi - cut, false);
+        };
         if (slots == 1) {
             const double* x_in = enqueued == 1 ? s->x0 : s->x;
             auto px = [&](size_t off, size_t count, bool reverse) {
                 if (count > 0)
-                    launch_cg_update_px(count, s->d_s, s->r + off, s->p + off, x_in + off, s->x + off, enqueued, s->compute, reverse, s->device_form);
+                    launch_cg_update_px(count, s->d_s, r_cur + off, s->p + off, x_in + off, s->x + off, enqueued, s->compute, reverse, s->device_form);
             };
             timed(&stats->time_blas1_ms, &stats->time_axpby_update_p_ms, [&] {
                 if (early_halo) {
                     if (head_rows > 0 && tail_rows > 0)  // a rank with two neighbours: both grid rows in one launch
-                        launch_cg_update_px_two_ranges(head_rows, tail_start, tail_rows, s->d_s, s->r, s->p, x_in, s->x, enqueued, s->compute, s->device_form);
+                        launch_cg_update_px_two_ranges(head_rows, tail_start, tail_rows, s->d_s, r_cur, s->p, x_in, s->x, enqueued, s->compute, s->device_form);
                     else
                         px(0, head_rows, false), px(tail_start, tail_rows, false);
                     trace.pop();
@@ -800,9 +860,9 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
                         start_p_halo();
                     }
                     trace.push("BLAS_AXPBY");
-                    px(head_rows, tail_start - head_rows, backward);
+                    bulk(px, head_rows, tail_start);
                 } else {
-                    px(0, nl, backward);
+                    bulk(px, 0, nl);
                 }
             });
         } else {
@@ -819,12 +879,12 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
             const double* p_in = s->p;
             auto ring_update = [&](size_t off, size_t count, bool reverse) {
                 if (count > 0)
-                    launch_cg_update_p_ring(count, s->d_s, s->r + off, p_in + off, p_next + off, enqueued, s->compute, reverse, s->device_form);
+                    launch_cg_update_p_ring(count, s->d_s, r_cur + off, p_in + off, p_next + off, enqueued, s->compute, reverse, s->device_form);
             };
             timed(&stats->time_blas1_ms, &stats->time_axpby_update_p_ms, [&] {
                 if (early_halo) {
                     if (head_rows > 0 && tail_rows > 0)  // a rank with two neighbours: both grid rows in one launch
-                        launch_cg_update_p_ring_two_ranges(head_rows, tail_start, tail_rows, s->d_s, s->r, p_in, p_next, enqueued, s->compute, s->device_form);
+                        launch_cg_update_p_ring_two_ranges(head_rows, tail_start, tail_rows, s->d_s, r_cur, p_in, p_next, enqueued, s->compute, s->device_form);
                     else
                         ring_update(0, head_rows, false), ring_update(tail_start, tail_rows, false);
                     s->p = p_next;  // the exchange sends from / receives into the new direction buffer
@@ -834,9 +894,9 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
                         start_p_halo();
                     }
                     trace.push("BLAS_AXPBY");
-                    ring_update(head_rows, tail_start - head_rows, backward);
+                    bulk(ring_update, head_rows, tail_start);
                 } else {
-                    ring_update(0, nl, backward);
+                    bulk(ring_update, 0, nl);
                 }
             });
             s->p = p_next;
@@ -848,7 +908,7 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
             TraceScope r(trace, "Halo_Exchange");
             start_p_halo();
         }
-        wait_for_status(s);
+        if (!status_known) wait_for_status(s);
         mailbox_check(comm);
         if (s->h_poll->converged) done = true;
         if (config->verbose >= 2 && comm->rank == 0) {
@@ -894,11 +954,17 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
         };
         const std::vector<hipEvent_t>& E = s->tl_compute;
         const int its = fin.iterations < enqueued ? fin.iterations : enqueued;
+        // The direction update of the converging iteration does no work (its launch reads the flag and returns; with late
+        // bulk only a lead piece is launched at all): it is left out of that stage's average, as the reference divides each
+        // timer by the iterations that ran it (cg_solver_mgpu_partitioned.cu:770-800) and tests convergence before its p
+        // update (:652-676). iteration_us stays the average over all counted iterations, the shorter last one included.
+        const int direction_updates = fin.converged && its > 0 ? its - 1 : its;
         double stage[kTimelineMarks] = {0, 0, 0, 0, 0, 0, 0};  // [k] = mark k -> mark k+1; [6] = mark 6 -> next iteration's mark 0
         double iteration_us = 0.0;
         for (int it = 0; it < its; ++it) {
             const size_t base = 2 + (size_t)it * kTimelineMarks;
-            for (int k = 0; k < kTimelineMarks - 1; ++k) stage[k] += us(E[base + k], E[base + k + 1]);
+            for (int k = 0; k < kTimelineMarks - 1; ++k)
+                if (k != 5 || it < direction_updates) stage[k] += us(E[base + k], E[base + k + 1]);
             // the last counted iteration ends at the flush mark
             const hipEvent_t next = it + 1 < enqueued ? E[base + kTimelineMarks] : E[tl_flush];
             stage[6] += us(E[base + 6], next);
@@ -909,8 +975,8 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
         for (int j = 0; j < exchanges; ++j) side_us += us(s->tl_side[2 * (size_t)j], s->tl_side[2 * (size_t)j + 1]);
         const double per = its > 0 ? 1.0 / its : 0.0;
         s->timeline_us = {(double)its, (double)total_ms, us(E[0], E[1]), stage[0] * per, stage[1] * per, stage[2] * per, stage[3] * per,
-                          stage[4] * per, stage[5] * per, stage[6] * per, iteration_us * per,
-                          exchanges > 0 ? side_us / exchanges : 0.0, us(E[tl_flush], E[tl_flush + 1])};
+                          stage[4] * per, direction_updates > 0 ? stage[5] / direction_updates : 0.0, stage[6] * per, iteration_us * per,
+                          exchanges > 0 ? side_us / exchanges : 0.0, us(E[tl_flush], E[tl_flush + 1]), (double)direction_updates};
     }
     if (timeline) {
         stats->time_spmv_ms = (s->timeline_us[3] + s->timeline_us[4]) * s->timeline_us[0] / 1e3;
@@ -943,7 +1009,7 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
     s->history.assign((size_t)count, 0.0);
     download(s->history.data(), s->d_hist, (size_t)count);
     last_cg_history() = s->history;
-    return 0;
+    return s->op_failed ? 1 : 0;
 }
 
 extern "C" int spmv_amd_cg_slab_gather(SpmvAmdCgSlab* s, double* x_full) {
@@ -987,6 +1053,19 @@ extern "C" void spmv_amd_cg_slab_info(const SpmvAmdCgSlab* s, int* row_offset, i
 extern "C" const char* spmv_amd_cg_slab_variant(const SpmvAmdCgSlab* s) { return s->variant_name; }
 
 extern "C" void spmv_amd_cg_slab_set_timeline(SpmvAmdCgSlab* s, int on) { s->timeline_on = on != 0; }
+
+// Loop options of an existing slab, for A/B measurements on the SAME allocations (two slabs of one process differ by up to
+// +-1.3 % through their placement alone, profiles/r03_placement.txt). Every option leaves the results bit-identical.
+// Returns 0, or -1 for an unknown name.
+extern "C" int spmv_amd_cg_slab_set_option(SpmvAmdCgSlab* s, const char* name, long long value) {
+    if (strcmp(name, "late_bulk") == 0) s->late_bulk = value != 0;
+    else if (strcmp(name, "lead_rows") == 0) s->lead_rows = value < 512 ? 512 : (size_t)value / 512 * 512;
+    else if (strcmp(name, "early_halo") == 0) s->early_halo = value != 0;
+    else if (strcmp(name, "pingpong") == 0) s->pingpong = value != 0;
+    else if (strcmp(name, "r_pingpong") == 0) s->r_pingpong = value != 0;
+    else return -1;
+    return 0;
+}
 extern "C" const char* spmv_amd_cg_slab_timeline_names(void) { return kTimelineNames; }
 extern "C" int spmv_amd_cg_slab_timeline(const SpmvAmdCgSlab* s, double* out, int cap) {
     const int count = (int)s->timeline_us.size();
@@ -1017,6 +1096,7 @@ extern "C" void spmv_amd_cg_slab_destroy(SpmvAmdCgSlab* s) {
     device_release(s->x0_alloc);
     s->x0 = nullptr;
     device_release(s->r);
+    device_release(s->r2);
     device_release(s->Ap);
     device_release(s->b);
     for (double*& a : s->ring_alloc) device_release(a);
@@ -1046,14 +1126,21 @@ extern "C" void spmv_amd_cg_slab_destroy(SpmvAmdCgSlab* s) {
 namespace {
 SpmvAmdCgSlab* g_workspace = nullptr;  // vectors, direction ring, scalars of cg_solve_device, kept between calls
 int g_workspace_device = -1;
+// one solve at a time on the shared workspace (the reference's operators are not re-entrant either, SURVEY 8b "Threading";
+// two host threads calling cg_solve_device are serialised here instead of racing on the buffers)
+std::mutex g_workspace_lock;
+void release_cg_workspace_locked() {
+    if (g_workspace == nullptr) return;
+    spmv_amd_cg_slab_destroy(g_workspace);
+    g_workspace = nullptr;
+}
 }  // namespace
 
 namespace spmv_amd {
 
 void release_cg_workspace() {
-    if (g_workspace == nullptr) return;
-    spmv_amd_cg_slab_destroy(g_workspace);
-    g_workspace = nullptr;
+    std::lock_guard<std::mutex> guard(g_workspace_lock);
+    release_cg_workspace_locked();
 }
 
 // The loop of spmv_amd_cg_slab_solve driven through the caller's operator: the same fused kernels, direction ring,
@@ -1065,9 +1152,10 @@ void release_cg_workspace() {
 // operator's free() (the harness solves the same system 13 times: 3 warm-ups + 10 runs, src/main/cg_solver.cu:154-178).
 int cg_solve_on_operator(SpmvOperator* op, int n, const double* b, double* x, const CGConfig& config, CGStats* stats,
                          std::vector<double>* history) {
+    std::lock_guard<std::mutex> guard(g_workspace_lock);
     int device = 0;
     HIP_CHECK(hipGetDevice(&device));
-    if (g_workspace != nullptr && (g_workspace->n != n || g_workspace_device != device)) release_cg_workspace();
+    if (g_workspace != nullptr && (g_workspace->n != n || g_workspace_device != device)) release_cg_workspace_locked();
     if (g_workspace == nullptr) {
         SpmvAmdCgSlab* s = new SpmvAmdCgSlab();
         s->comm = self_comm();
@@ -1184,6 +1272,11 @@ int cg_solve_mgpu_partitioned(SpmvOperator* spmv_op, MatrixData* mat, const doub
     spmv_amd_cg_slab_destroy(s);
     return 0;
 }
+
+// Frees what cg_solve_device keeps between calls (five vectors + the direction ring). A caller that drives its OWN operator
+// table through cg_solve_device never passes through this library's operator free(), which is where the workspace is
+// otherwise released.
+extern "C" void spmv_amd_cg_release_workspace(void) { spmv_amd::release_cg_workspace(); }
 
 extern "C" int spmv_amd_cg_solve_mgpu_partitioned(MatrixData* mat, const double* b, double* x,
                                                   const CGConfigMultiGPU* config,

@@ -215,8 +215,9 @@ void launch_cg_init_residual(size_t n, const double* b, const double* Ap, double
                              double* partials, hipStream_t stream);
 // alpha = rr_old / pAp (per thread, from the scalars) ; r -= alpha Ap ; partials of r.r
 // reverse: workgroups walk the vectors from the end (same results, same partial slots).
+// r_in (optional): read the old residual from there and write the new one to r (out of place); null = in place.
 void launch_cg_update_r(size_t n, const CgScalars* s, const double* Ap, double* r, double* partials,
-                        hipStream_t stream, bool reverse = false);
+                        hipStream_t stream, bool reverse = false, const double* r_in = nullptr);
 // x += alpha p (the update of iteration `iteration`), then p = 1.0*r + beta*p unless that iteration
 // converged; one pass over p (axpy + axpby of cg_solver_mgpu_partitioned.cu:598,682 fused).
 // x = x_in + alpha p: x_in is x, or the stored initial guess in the first iteration of a solve.

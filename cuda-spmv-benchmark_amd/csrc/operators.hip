@@ -505,7 +505,20 @@ extern "C" int spmv_amd_operator_select_variant(const char* mode, const char* va
             else if (!strcmp(variant, "subwave32")) v = CsrVariant::SubWave32;
             else return EXIT_FAILURE;
             g_csr.csr_variant = v;
-            if (g_csr.ready) g_csr.variant_name = csr_variant_name(v, g_csr.A.view);
+            if (g_csr.ready) {
+                // the tunables (SPMV_AMD_XCD_GROUP, SPMV_AMD_CSR_STREAM_ROWS, ...) are re-read: an A/B of launch geometries
+                // can then run on ONE initialised operator, i.e. on the same allocations (tools/ab_csr_runs.py)
+                g_csr.shape = current_launch_shape();
+                g_csr.variant_name = csr_variant_name(v, g_csr.A.view);
+            }
+            return 0;
+        }
+        case Which::Ell:
+        case Which::EllStencil: {
+            // one kernel each: "auto" only, which re-reads the tunables (same reason as above)
+            if (!automatic) return EXIT_FAILURE;
+            EllOperator& e = which_operator(mode) == Which::Ell ? g_ell : g_ell_stencil;
+            if (e.ready) e.pick();
             return 0;
         }
         default: return EXIT_FAILURE;

@@ -1202,9 +1202,14 @@ __global__ __launch_bounds__(kThreads) void csr_stream_kernel(SlabCsr m, const d
                 v[u] = live ? m.values[e] : 0.0;
             }
 #pragma unroll
-            for (int u = 0; u < kCsrStreamPerThread; ++u) xv[u] = x_at(x, (long long)c[u] - m.row_offset, lo, hi);
+            for (int u = 0; u < kCsrStreamPerThread; ++u) {
+                // a dead slot (past the chunk's end) gathers nothing and contributes +0.0: with x[0] in its place a
+                // non-finite x[0] would turn 0 * x[0] into NaN in the no-staging fold below, for a row that has no column 0
+                const bool live = base + (int)threadIdx.x + u * kThreads < end;
+                xv[u] = live ? x_at(x, (long long)c[u] - m.row_offset, lo, hi) : 0.0;
+            }
             if (kVectorLong && owner >= 0) {
-                // the whole chunk belongs to one row: no staging, no barrier (dead slots carry v = 0)
+                // the whole chunk belongs to one row: no staging, no barrier (dead slots carry v = 0 and x = 0)
 #pragma unroll
                 for (int u = 0; u < kCsrStreamPerThread; ++u) vacc = fma(v[u], xv[u], vacc);
                 long_owner = owner;

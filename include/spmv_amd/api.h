@@ -234,6 +234,10 @@ int spmv_amd_cg_fused_step(int which, size_t n, const double* scalars, const dou
 /* Copies ||r_k||, k = 0..iterations, into out (at most cap values); returns how
  * many the solve recorded. */
 int spmv_amd_cg_last_history(double* out, int cap);
+/* cg_solve_device keeps its five vectors and direction ring between calls (the harness solves one system 13 times,
+ * reference src/main/cg_solver.cu:154-178). They are released by the free() of any of this library's operators, or here --
+ * the call for a caller that drives its own SpmvOperator table through cg_solve_device. Safe to call at any time. */
+void spmv_amd_cg_release_workspace(void);
 
 /* ---- multi-GPU communicator ---- */
 typedef struct SpmvAmdComm SpmvAmdComm;
@@ -332,8 +336,13 @@ int spmv_amd_cg_slab_time_spmv(SpmvAmdCgSlab* s, int reps, float* ms_each);
  * interior rows stays as it is in a timed solve. spmv_amd_cg_slab_timeline() returns the values of the last such
  * solve -- averages per counted iteration, microseconds -- in the order of the comma-separated names
  * spmv_amd_cg_slab_timeline_names() returns; 0 values if the last solve ran without the timeline. Each stage runs from
- * the end of the previous stage's last kernel to the end of its own, so queue gaps are inside the stage that waits. */
+ * the end of the previous stage's last kernel to the end of its own, so queue gaps are inside the stage that waits.
+ * The direction-update stage is averaged over the launches that did work ("direction_updates": the converging
+ * iteration's update is never needed -- the reference tests convergence before its p update, :652-676). */
 void spmv_amd_cg_slab_set_timeline(SpmvAmdCgSlab* s, int on);
+/* Loop options of an existing slab (measurement aid: A/B runs on the same allocations; results are bit-identical under
+ * every option): "late_bulk" 0/1, "lead_rows" N, "early_halo" 0/1, "pingpong" 0/1, "r_pingpong" 0/1. 0, or -1 = unknown name. */
+int spmv_amd_cg_slab_set_option(SpmvAmdCgSlab* s, const char* name, long long value);
 const char* spmv_amd_cg_slab_timeline_names(void);
 int spmv_amd_cg_slab_timeline(const SpmvAmdCgSlab* s, double* out, int cap);
 void spmv_amd_cg_slab_destroy(SpmvAmdCgSlab* s);

@@ -202,6 +202,45 @@ def test_cg_solve_device_through_a_callers_own_operator_table(B, O, fresh_host_m
     real.free()
 
 
+@pytest.mark.parametrize("device", [True, False])
+def test_a_failing_run_device_is_a_status_not_the_end_of_the_callers_process(B, O, fresh_host_matrices, device):
+    """A caller's operator table whose run_device starts failing in its third call: cg_solve_device / cg_solve hand back a
+    non-zero status (the reference ignores the value, cg_solver.cu:498,541; ending the caller's process over it is not a
+    library's call to make), this process lives on, and the next solve on a healthy table is right."""
+    n = 120
+    m = B.HostMatrix(O.stencil5_coo(n), n * n, n * n, n)
+    real = B.Operator("cusparse-csr")
+    assert real.init(m) == 0
+    calls = []
+
+    def run_device(d_x, d_y):
+        calls.append(1)
+        return 1 if len(calls) >= 3 and fail[0] else real.op.contents.run_device(d_x, d_y)
+
+    keep = (B.INIT_FN(lambda mat: 0), B.RUN_TIMED_FN(lambda x, y, ms: 1), B.RUN_DEVICE_FN(run_device), B.FREE_FN(lambda: None))
+    table = B.SpmvOperator(b"callers-own", *keep)
+
+    class Foreign:
+        op = C.pointer(table)
+
+    fail = [True]
+    with pytest.raises(RuntimeError, match="cg_solve -> 1"):
+        B.cg_solve(Foreign, m, np.ones(n * n), np.zeros(n * n), device=device)
+    assert len(calls) == 3  # nothing was enqueued after the failing call
+    fail[0] = False
+    rp, ci, va = O.stencil5_csr(n)
+    x, hist, st = B.cg_solve(Foreign, m, np.ones(n * n), np.zeros(n * n), device=device)
+    xo, ho, ro = O.cg(rp, ci, va, n, np.ones(n * n), np.zeros(n * n), device_form=device)
+    assert st.iterations == ro.iterations and st.converged == 1 and hist_err(hist, ho) < TOL
+    assert np.max(np.abs(x - xo)) <= TOL * np.max(np.abs(xo))
+    # a caller with its own table never reaches this library's operator free(): the workspace has its own release call
+    B.lib().spmv_amd_cg_release_workspace()
+    B.lib().spmv_amd_cg_release_workspace()  # idempotent
+    x2, hist2, _ = B.cg_solve(Foreign, m, np.ones(n * n), np.zeros(n * n), device=device)
+    assert np.array_equal(hist2, hist) and np.array_equal(x2, x)
+    real.free()
+
+
 def test_slab_timeline_accounts_for_the_solve(B, O, fresh_host_matrices):
     """spmv_amd_cg_slab_set_timeline: stage-boundary events without host syncs. The stages of an iteration add up to the
     iteration, the iterations (+ initial residual + flush) to the solve, and the numbers are those of a plain solve."""
@@ -216,7 +255,13 @@ def test_slab_timeline_accounts_for_the_solve(B, O, fresh_host_matrices):
     stages = ["spmv_interior_us", "halo_wait_and_boundary_rows_us", "reduce_pAp_and_allreduce_us", "update_r_us",
               "reduce_rr_allreduce_and_scalar_step_us", "direction_update_us", "gap_before_next_iteration_us"]
     assert all(t[k] >= 0.0 for k in stages) and t["spmv_interior_us"] > 0 and t["update_r_us"] > 0
-    assert abs(sum(t[k] for k in stages) - t["iteration_us"]) <= 1e-3 * t["iteration_us"] + 1.0
+    # The converging iteration's direction update does no work (the reference tests convergence before its p update,
+    # cg_solver_mgpu_partitioned.cu:652-676): the stage is averaged over the launches that did, one fewer than the iterations.
+    assert st_t.converged == 1 and t["direction_updates"] == st.iterations - 1 and t["direction_update_us"] > 0
+    # a solve that is stopped by max_iters runs the update in every iteration, and its stages add up to the iteration
+    st_f, tf = slab.timeline_solve(max_iters=st.iterations - 2)
+    assert st_f.converged == 0 and tf["direction_updates"] == tf["iterations"] == st.iterations - 2
+    assert abs(sum(tf[k] for k in stages) - tf["iteration_us"]) <= 1e-3 * tf["iteration_us"] + 1.0
     whole = t["initial_residual_us"] + t["iterations"] * t["iteration_us"] + t["final_x_flush_us"]
     assert 0.9 * whole <= t["solve_ms"] * 1e3 <= 1.1 * whole + 50.0
     assert slab.solve().iterations == st.iterations and B.lib().spmv_amd_cg_slab_timeline(slab.h, None, 0) == 0  # off again
@@ -224,8 +269,48 @@ def test_slab_timeline_accounts_for_the_solve(B, O, fresh_host_matrices):
     st0, t0 = slab.timeline_solve(max_iters=0)
     assert st0.iterations == 0 and t0["iterations"] == 0 and t0["iteration_us"] == 0.0 and t0["initial_residual_us"] > 0
     st1, t1 = slab.timeline_solve(max_iters=1)
-    assert st1.iterations == 1 and t1["iterations"] == 1 and t1["iteration_us"] > 0
+    assert st1.iterations == 1 and t1["iterations"] == 1 and t1["iteration_us"] > 0 and t1["direction_updates"] == 1
     slab.destroy()
+
+
+@pytest.mark.parametrize("n,P,r", [(1024, 1, 0), (1000, 1, 0), (1024, 4, 1), (1024, 2, 0), (1001, 1, 0)])
+def test_late_bulk_and_out_of_place_r_leave_every_bit_alone(B, monkeypatch, n, P, r):
+    """Round 4's loop options on one slab: the direction update split into a lead piece + (after the status record) the rest,
+    forced on with a lead of 50 000 rows so that small grids take the path in both sweep directions; the r update written out
+    of place. History and solution must be bit-identical to the plain loop, with the direction ring and with the in-place
+    x / p update, on a plain slab (even and odd row counts) and on stand-in slabs of a larger job (early halo + late bulk)."""
+    comm = None
+    if P > 1:
+        monkeypatch.setenv("SPMV_AMD_SELF_NEIGHBOUR", "1")
+        monkeypatch.setenv("SPMV_AMD_FORCE_COLLECTIVES", "1")
+    for ring in ("16", "1"):
+        monkeypatch.setenv("SPMV_AMD_P_RING", ring)
+        if P > 1:
+            comm = B.Comm.rccl(0, 1, B.Comm.unique_id())
+            slab = B.CgSlab.stencil5_as(n, r, P, comm)
+            kw = dict(max_iters=9, tol=0.0)
+        else:
+            slab = B.CgSlab.stencil5(n)
+            kw = {}
+        slab.set_option("late_bulk", 0)
+        st0 = slab.solve(**kw)
+        h0, x0 = slab.history().copy(), slab.gather() if P == 1 else None
+        for opts in ({"late_bulk": 1, "lead_rows": 50000}, {"late_bulk": 1, "lead_rows": 512}, {"late_bulk": 0, "r_pingpong": 1},
+                     {"late_bulk": 1, "lead_rows": 50000, "r_pingpong": 1}):
+            for k in ("late_bulk", "r_pingpong"):
+                slab.set_option(k, opts.get(k, 0))
+            slab.set_option("lead_rows", opts.get("lead_rows", 1 << 24))
+            st = slab.solve(**kw)
+            assert (st.iterations, st.converged) == (st0.iterations, st0.converged) and np.array_equal(slab.history(), h0), (ring, opts)
+            if P == 1:
+                assert np.array_equal(slab.gather(), x0), (ring, opts)
+            _, tl = slab.timeline_solve(**kw)
+            assert np.array_equal(slab.history(), h0) and tl["direction_updates"] == st0.iterations - st0.converged
+        with pytest.raises(ValueError):
+            slab.set_option("no_such_option", 1)
+        slab.destroy()
+        if comm is not None:
+            comm.destroy()
 
 
 def test_reference_entry_point_cg_solve_mgpu_partitioned(B, O, fresh_host_matrices):

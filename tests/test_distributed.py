@@ -200,7 +200,7 @@ def _json_lines(text):
 
 TIMELINE_KEYS = ["iterations", "solve_ms", "initial_residual_us", "spmv_interior_us", "halo_wait_and_boundary_rows_us", "reduce_pAp_and_allreduce_us",
                  "update_r_us", "reduce_rr_allreduce_and_scalar_step_us", "direction_update_us", "gap_before_next_iteration_us", "iteration_us",
-                 "halo_exchange_on_side_stream_us", "final_x_flush_us"]
+                 "halo_exchange_on_side_stream_us", "final_x_flush_us", "direction_updates"]
 
 
 def check_multi_rank_line(line, world, mailbox_must_work=True, with_ab=False):

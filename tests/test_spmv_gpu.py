@@ -308,6 +308,40 @@ def test_rowlds_march_in_the_solver_changes_no_bit(B, O, fresh_host_matrices, mo
             assert np.array_equal(got[2], base[2]), args
 
 
+@pytest.mark.parametrize("variant", [None, "stream", "adaptive", "row-scalar", "subwave32", "wavefront"])
+def test_csr_rows_without_column_zero_never_touch_x0(B, O, fresh_host_matrices, variant):
+    """Padding slots of the CSR kernels' chunked loads must not gather x[0]: with x[0] = inf a folded 0 * x[0] would be NaN.
+    Long rows (> the 1024-entry strip, ending inside a partial chunk: the adaptive kernel's no-staging fold), short and empty
+    rows, none of them with an entry in column 0: y must be finite and equal the oracle's, which reads x only where A has an entry."""
+    e, r, c = M.random_sparse(300, 6000, lambda row, rng: (3500 if row == 0 else 2900) if row in (0, 1, 137) else (0 if row % 11 == 0 else int(rng.integers(1, 9))), seed=21)
+    e = e[e["col"] != 0]
+    x = np.random.default_rng(8).standard_normal(c)
+    x[0] = np.inf
+    op = B.Operator("cusparse-csr")
+    op.select_variant(variant)
+    m = B.HostMatrix(e, r, c, -1)
+    assert op.init(m) == 0
+    if variant is None:
+        assert op.variant() == "csr/adaptive"  # the automatic choice for rows beyond the strip
+    rp, ci, va = O.build_csr(e, r)
+    want = O.spmv_csr(rp, ci, va, x)
+    got, _ = op.run_timed(x)
+    assert np.all(np.isfinite(want)) and np.all(np.isfinite(got))
+    scale = np.maximum(np.abs(want), O.spmv_csr(rp, ci, np.abs(va), np.abs(np.where(np.isfinite(x), x, 0.0))))
+    assert np.max(np.abs(got - want) / np.maximum(scale, 1e-300)) <= 1e-12
+    op.free()
+    op.select_variant(None)
+    # ELLPACK pads with index -1: same property
+    B.lib().spmv_amd_reset_host_matrices()
+    short = e[(e["row"] != 0) & (e["row"] != 1) & (e["row"] != 137)]
+    ell = B.Operator("ellpack")
+    assert ell.init(B.HostMatrix(short, r, c, -1)) == 0
+    rp, ci, va = O.build_csr(short, r)
+    got, _ = ell.run_timed(x)
+    assert np.array_equal(got, O.spmv_csr(rp, ci, va, x))
+    ell.free()
+
+
 @pytest.mark.parametrize("fixture", ["stencil_9point", "banded", "dense_blocks", "ill_conditioned"])
 def test_structured_non_stencil_fixtures_through_every_operator(B, O, fresh_host_matrices, fixture):
     """Structured matrices after the ideas of the reference's (stale) fixture file, tests/helpers/matrix_fixtures.cpp:181-338:

@@ -1,7 +1,10 @@
-"""CSR-stream: does an XCD walking a column band pay (as it does for the stencil kernels)? One process, one matrix, the operator
-re-initialised with SPMV_AMD_XCD_GROUP = g for runs of 8 * g blocks that cover k grid rows + ~1100 rows (k = 1, 2, 3) and for
-dispatch order (g = 1), each setting measured three times in alternation so that drift cannot pass for a gain.
-   python tools/ab_csr_runs.py [grid=20000]"""
+"""CSR-stream / ELLPACK launch geometry on ONE initialised operator (the same allocations for every setting: two
+initialisations of one process differ by placement alone, profiles/r04_placement_probe.txt): rows per block x consecutive
+blocks per XCD, each setting measured `reps` times in alternation so that drift cannot pass for a gain.
+   python tools/ab_csr_runs.py [grid=10000] [mode=cusparse-csr] [reps=4]
+Round 4's question: does a block size that DIVIDES the grid row (200 rows: 10 000 = 50 blocks, 15 000 = 75,
+20 000 = 100; 1000 of the strip's 1024 entries), with an XCD run of one grid row + ~1100 columns as the row-lds kernel uses,
+keep x[row +- n] in the XCD's own L2?"""
 import importlib.util
 import os
 import sys
@@ -13,22 +16,53 @@ spec = importlib.util.spec_from_file_location("spmv_amd_binding", os.path.join(R
 B = importlib.util.module_from_spec(spec)
 spec.loader.exec_module(B)
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
+mode = sys.argv[2] if len(sys.argv) > 2 else "cusparse-csr"
+reps = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 rows = n * n
-rows_per_block = 176
-groups = [1] + [max(2, round((k * n + 1100) / (8 * rows_per_block))) for k in (1, 2, 3)] + [8, 32]
+if mode == "cusparse-csr":
+    settings = [(176, 1)]  # the default: strip filled to ~90 %, dispatch order
+    for rpb in (176, 200):
+        per_row = n / rpb
+        for k in (1, 2):
+            settings.append((rpb, max(2, round((k * n + 1100) / (8 * rpb)))))
+        settings.append((rpb, 8))
+    settings.append((200, 1))
+    settings.append((200, int(np.ceil(n / 200 / 8))))  # a run of 8 * g blocks = exactly one grid row band per XCD pass
+else:
+    settings = [(256, 0)] + [(256, g) for g in (1, 4, 8, 16, max(2, round((n + 1100) / (8 * 256))))]
+settings = list(dict.fromkeys(settings))
 dx, dy = B.DeviceVector(rows, fill=1.0), B.DeviceVector(rows, fill=0.0)
-op = B.Operator("cusparse-csr")
-results = {g: [] for g in groups}
-for rep in range(3):
-    for g in groups:
-        os.environ["SPMV_AMD_XCD_GROUP"] = str(g)
-        assert op.init_synthetic(n) == 0
-        op.time_device(dx, dy, 3)
-        results[g].append(float(np.median(op.time_device(dx, dy, 10))))
-        op.free()
-print(f"grid {n}: csr/stream, {rows_per_block} rows per block; median ms of 10 launches, three alternating repetitions per setting")
-for g in groups:
-    span = 8 * g * rows_per_block
-    print(f"   xcd_group {g:4d}  (run = {span:8d} rows = {span / n:6.3f} grid rows)   " + "  ".join(f"{v:.3f}" for v in results[g]) + f"   best {min(results[g]):.3f}")
+op = B.Operator(mode)
+assert op.init_synthetic(n) == 0
+want = None
+results = {s: [] for s in settings}
+same = True
+for rep in range(reps):
+    for s in (settings if rep % 2 == 0 else settings[::-1]):
+        rpb, g = s
+        if mode == "cusparse-csr":
+            os.environ["SPMV_AMD_CSR_STREAM_ROWS"] = str(rpb)
+        if g > 0:
+            os.environ["SPMV_AMD_XCD_GROUP"] = str(g)
+        else:
+            os.environ.pop("SPMV_AMD_XCD_GROUP", None)
+        op.select_variant(None)
+        op.time_device(dx, dy, 2)
+        results[s].append(float(np.median(op.time_device(dx, dy, 10))))
+        if rep == 0:
+            y = dy.to_host()
+            if want is None:
+                want = y
+            same = same and bool(np.array_equal(y, want))
+print(f"grid {n}, {mode} ({op.variant()}): median ms of 10 launches, {reps} alternating repetitions per setting, one operator instance")
+base = float(np.median(results[settings[0]]))
+for s in settings:
+    rpb, g = s
+    span = 8 * max(g, 1) * rpb
+    med = float(np.median(results[s]))
+    print(f"   rows/block {rpb:4d}  xcd_group {g:4d}  (run = {span:8d} rows = {span / n:6.3f} grid rows)   " + "  ".join(f"{v:.3f}" for v in results[s])
+          + f"   median {med:.3f}  ({100.0 * (med / base - 1.0):+.2f} % vs the default)")
+print(f"   results bit-identical across settings: {same}")
+op.free()
 dx.free(), dy.free()
