@@ -833,8 +833,6 @@ def main():
                    launched_by="bench.py (self-launched ranks)" if os.environ.get("SPMV_AMD_BENCH_SELF_LAUNCHED") == "1" else
                    ("external launcher (RANK/WORLD_SIZE in the environment)" if "RANK" in os.environ else "single process"),
                    roofline=roofline)
-        if leg.get("placement") is not None:
-            out["placement_trials"] = leg["placement"]
         if degraded:
             out["degraded"] = degraded
         if spmv is not None:

@@ -38,6 +38,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
+#include <chrono>
 #include <mutex>
 #include <vector>
 
@@ -73,6 +75,15 @@ struct SpmvAmdCgSlab {
     DeviceCsr A;
     double *x = nullptr, *x0 = nullptr, *r = nullptr, *Ap = nullptr, *b = nullptr;
     double* x0_alloc = nullptr;  // x0 carries halo rows too ([pad | prev halo | local | next halo]): the initial SpMV reads it in place
+    // Vector arena (round 4): r, Ap and every direction buffer are carved out of ONE allocation, in that order, r and Ap
+    // first. On MI355X a kernel that walks two or three vectors at the same index runs 6.5 % slower when the vectors lie in
+    // different 32 GiB regions of the physical address space (regions of the same class repeat every 96 GiB: 288 GiB = 3 classes
+    // x 3; all pairs of 40 vectors in one 143 GB allocation: profiles/r04_arena_probe40.txt) -- the price of alternating
+    // between two stack-level ranks on the same channels, presumably. Separate hipMallocs land in a class at random (the fast /
+    // slow lottery behind the "+-1.3 % between processes" of rounds 2-3: profiles/r04_placement_*.txt, r04_offset_probe.txt);
+    // neighbours inside one allocation share a region except where it crosses a boundary. The SpMV's coefficient stream does
+    // not take part (40 B/row against 8 B/row: not in lock step; r04_arena_spmv_mix.txt), so the CSR arrays stay where they are.
+    double* vec_arena = nullptr;
     double* p_alloc = nullptr;  // [pad | prev halo | local | next halo]
     double* p = nullptr;        // local part of the CURRENT direction vector, 16-byte aligned
     // Direction ring (deferred x update). With ring_slots > 1 the direction update is written out of place into
@@ -81,6 +92,7 @@ struct SpmvAmdCgSlab {
     // moves 56 + 24 + 24 B/row plus 8 B/row for the deferred re-read of p_k (+ 16/ring_slots for x) instead of
     // 56 + 24 + 40. The fma chain per element of x is the same, in the same order. Costs ring_slots - 1 extra
     // vectors of HBM (48 GB at 400 M rows and 16 slots, of 288 GB); ring_slots = 1 is the in-place form.
+    size_t slot_doubles = 0, slot_lead = 0;  // size of one halo-carrying buffer and where its local part starts
     std::vector<double*> ring_alloc;  // allocations, ring_alloc[0] == p_alloc
     std::vector<double*> ring;        // local parts
     int ring_slots = 1;
@@ -213,8 +225,6 @@ void make_common(SpmvAmdCgSlab* s) {
     HIP_CHECK(hipEventCreateWithFlags(&s->ev_p_ready, hipEventDisableTiming));
     HIP_CHECK(hipEventCreateWithFlags(&s->ev_halo_done, hipEventDisableTiming));
     s->x = device_alloc<double>(nl);
-    s->r = device_alloc<double>(nl);
-    s->Ap = device_alloc<double>(nl);
     s->b = device_alloc<double>(nl);
     // The local part of every halo-carrying buffer starts on a 4 KiB boundary whatever the halo length, like the
     // plain allocations of r, Ap, x. Measured with the rank as its own neighbour: a halo of 14 142 doubles put
@@ -224,38 +234,48 @@ void make_common(SpmvAmdCgSlab* s) {
     constexpr size_t kLeadUnit = 512;  // doubles
     const size_t lead = s->halo == 0 ? 0 : ((size_t)s->halo + kLeadUnit - 1) / kLeadUnit * kLeadUnit;
     const size_t slot_doubles = lead + nl + (size_t)s->halo + 2;
+    s->slot_doubles = slot_doubles;
+    s->slot_lead = lead;
     s->x0_alloc = device_alloc<double>(slot_doubles);
     s->x0 = s->x0_alloc + lead;
     HIP_CHECK(hipMemset(s->x0_alloc, 0, slot_doubles * sizeof(double)));
-    s->p_alloc = device_alloc<double>(slot_doubles);
-    s->p = s->p_alloc + lead;
-    HIP_CHECK(hipMemset(s->p_alloc, 0, slot_doubles * sizeof(double)));
-    s->ring_alloc.assign(1, s->p_alloc);
-    s->ring.assign(1, s->p);
     {
         // as many direction buffers as fit comfortably (default 16, SPMV_AMD_P_RING=1 keeps the in-place update)
         int want = kMaxRingSlots;
         const char* forced = getenv("SPMV_AMD_P_RING");
         if (forced) want = atoi(forced);
         want = want < 1 ? 1 : (want > kMaxRingSlots ? kMaxRingSlots : want);
+        // One vector every `pitch` doubles: the vector rounded up to 2 MiB, plus 4 KiB -- consecutive vectors then differ in
+        // their phase inside the memory system's interleave as well (~1 % on both BLAS1 kernels against a pitch of whole
+        // 2 MiB units, profiles/r04_arena_probe.txt). r and Ap are slots 0 and 1, the direction buffers follow.
+        constexpr size_t k2MiB = (size_t)2 << 20, k4KiB = 4096;
+        const size_t pitch = ((slot_doubles * sizeof(double) + k2MiB - 1) / k2MiB * k2MiB + k4KiB) / sizeof(double);
         size_t free_b = 0, total_b = 0;
         HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
         const size_t keep_free = (size_t)4 << 30;  // leave room for the caller's own buffers
-        const size_t per_slot = slot_doubles * sizeof(double);
+        const size_t per_slot = pitch * sizeof(double);
         const int asked = want;
         // A slab that owns its matrix may take what is free. The workspace of cg_solve_device outlives the call (until an
         // operator's free() or spmv_amd_cg_release_workspace()) next to a caller who goes on allocating -- a second operator,
         // say -- so its ring is held to a quarter of what is free now: 16 slots of 3.2 GB at 4e8 rows on an otherwise idle
         // MI355X, fewer on a fuller device, the in-place form when even four do not fit.
-        const size_t budget = s->op != nullptr ? free_b / 4 : (free_b > keep_free ? free_b - keep_free : 0);
+        const size_t fixed = 3 * per_slot;  // r, Ap, the first direction buffer
+        const size_t budget = s->op != nullptr ? free_b / 4 : (free_b > keep_free + fixed ? free_b - keep_free - fixed : 0);
         while (want > 1 && (size_t)(want - 1) * per_slot > budget) --want;
         if (want < asked && want < 4) want = 1;  // a ring cut short by memory flushes too often to pay
-        for (int k = 1; k < want; ++k) {
-            double* a = device_alloc<double>(slot_doubles);
-            HIP_CHECK(hipMemset(a, 0, slot_doubles * sizeof(double)));
+        s->vec_arena = device_alloc<double>((size_t)(2 + want) * pitch);
+        HIP_CHECK(hipMemset(s->vec_arena, 0, (size_t)(2 + want) * pitch * sizeof(double)));
+        s->r = s->vec_arena;
+        s->Ap = s->vec_arena + pitch;
+        s->ring_alloc.clear();
+        s->ring.clear();
+        for (int k = 0; k < want; ++k) {
+            double* a = s->vec_arena + (size_t)(2 + k) * pitch;
             s->ring_alloc.push_back(a);
             s->ring.push_back(a + lead);
         }
+        s->p_alloc = s->ring_alloc[0];
+        s->p = s->ring[0];
         s->ring_slots = want;
         s->d_alpha_ring = device_alloc<double>(kMaxRingSlots);
         HIP_CHECK(hipMemset(s->d_alpha_ring, 0, kMaxRingSlots * sizeof(double)));
@@ -1095,12 +1115,12 @@ extern "C" void spmv_amd_cg_slab_destroy(SpmvAmdCgSlab* s) {
     device_release(s->x);
     device_release(s->x0_alloc);
     s->x0 = nullptr;
-    device_release(s->r);
+    device_release(s->vec_arena);  // r, Ap and the direction buffers
+    s->r = s->Ap = s->p_alloc = s->p = nullptr;
+    s->ring_alloc.clear();
+    s->ring.clear();
     device_release(s->r2);
-    device_release(s->Ap);
     device_release(s->b);
-    for (double*& a : s->ring_alloc) device_release(a);
-    s->p_alloc = nullptr;
     device_release(s->d_alpha_ring);
     device_release(s->partials_spmv);
     device_release(s->partials_blas);

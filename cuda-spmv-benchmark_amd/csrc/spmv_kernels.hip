@@ -1825,8 +1825,15 @@ CsrVariant csr_auto_variant(const SlabCsr& m) {
     //    row sum the others give up; banded (9 per row): stream 0.223 ms, subwave4 0.339 ms;
     //  * skewed (rows of 1-8 entries, one in a thousand with 2 000-20 000; mean 15.5): the mean sent it to subwave4, 7.5 ms;
     //    stream 4.2 ms, 32 lanes per row 3.1 ms, adaptive 2.8 ms.
-    // So: rows longer than the stream kernel's strip -> adaptive (stream for the short rows, the whole workgroup for the long
+    // Round 4 (profiles/r04_generic_long_rows.txt), the regime the round-3 table stopped short of -- uniform rows of 320 / 640 /
+    // 1000 random columns, 10^8 entries: stream 0.85 / 1.51 / 2.30 ms (at >= 64 entries per row the block holds 16 rows, the
+    // span leaves the strip and 16 of 256 threads fold sequentially), one row per wavefront 0.67 / 0.65 / 0.64 ms, 32 lanes
+    // per row 0.68 / 0.65 / 0.63 ms. At 160 per row the two still tie (0.74 ms, round 3).
+    // So: a MEAN row length above 192 -> one row per wavefront (its tree sum replaces the sequential one: 2e-15 relative);
+    // else rows longer than the stream kernel's strip -> adaptive (stream for the short rows, the whole workgroup for the long
     // ones); everything else -> stream. The sub-wavefront kernels stay selectable (spmv_amd_operator_select_variant).
+    const double mean = m.n_local > 0 ? (double)m.nnz_local / (double)m.n_local : 0.0;
+    if (mean > 192.0) return CsrVariant::Wavefront;
     return m.max_row_nnz > 1024 ? CsrVariant::Adaptive : CsrVariant::Stream;
 }
 

@@ -1,7 +1,7 @@
 """CSR-stream / ELLPACK launch geometry on ONE initialised operator (the same allocations for every setting: two
 initialisations of one process differ by placement alone, profiles/r04_placement_probe.txt): rows per block x consecutive
 blocks per XCD, each setting measured `reps` times in alternation so that drift cannot pass for a gain.
-   python tools/ab_csr_runs.py [grid=10000] [mode=cusparse-csr] [reps=4]
+   python tools/ab_csr_runs.py [grid=10000] [mode=cusparse-csr] [reps=4] [rows per block, comma separated: dispatch order only]
 Round 4's question: does a block size that DIVIDES the grid row (200 rows: 10 000 = 50 blocks, 15 000 = 75,
 20 000 = 100; 1000 of the strip's 1024 entries), with an XCD run of one grid row + ~1100 columns as the row-lds kernel uses,
 keep x[row +- n] in the XCD's own L2?"""
@@ -19,6 +19,7 @@ spec.loader.exec_module(B)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
 mode = sys.argv[2] if len(sys.argv) > 2 else "cusparse-csr"
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+rows_only = [int(v) for v in sys.argv[4].split(",")] if len(sys.argv) > 4 else None  # e.g. 176,192,200,204: dispatch order only
 rows = n * n
 if mode == "cusparse-csr":
     settings = [(176, 1)]  # the default: strip filled to ~90 %, dispatch order
@@ -31,6 +32,8 @@ if mode == "cusparse-csr":
     settings.append((200, int(np.ceil(n / 200 / 8))))  # a run of 8 * g blocks = exactly one grid row band per XCD pass
 else:
     settings = [(256, 0)] + [(256, g) for g in (1, 4, 8, 16, max(2, round((n + 1100) / (8 * 256))))]
+if rows_only:
+    settings = [(r, 1) for r in rows_only]
 settings = list(dict.fromkeys(settings))
 dx, dy = B.DeviceVector(rows, fill=1.0), B.DeviceVector(rows, fill=0.0)
 op = B.Operator(mode)
