@@ -34,6 +34,11 @@ configuration of reference docs/PROBLEM_SIZE_SCALING_RESULTS.md:40-47, on N row 
             (~10 s), and `spmv` = its STENCIL5 and CSR SpMV (1 warm-up + 3 runs, median) in the reference's
             effective-GB/s formula and in algorithmic GB/s; `all_cores` = the same loops under OpenMP.
 
+  placement (rank 0's slab) and spmv.output_placement: on this part a SpMV is ~4.5 % faster when the vector it writes lies in another
+            class of 32 GiB address regions than the data it reads, and only hipMalloc decides the class (profiles/r04_spmv_regions.txt):
+            at set-up, outside every timed region, the operator times its kernel on three allocations for y, one 32 GiB region apart, and keeps the fastest;
+            the slab does the same for its [Ap | r] pair against one iteration's streaming kernels. Addresses only, same bits.
+
   parity_vs_golden  every run, every N: the residual history of the timed solves against the committed CPU-oracle
             history of the same grid (tests/golden/known_answers.json: 3, 81, 512, 2000, 10000, 20000); above 1e-10
             relative, or on another iteration count, the run is UNMEASURED (exit 3), whatever it timed.
@@ -131,16 +136,21 @@ def spmv_headline(B, n, warmup=5, runs=10):
     op = B.Operator("stencil5-csr")
     if op.init_synthetic(n) != 0:
         raise RuntimeError("stencil5-csr synthetic init failed")
-    dx, dy = B.DeviceVector(rows, fill=1.0), B.DeviceVector(rows, fill=0.0)
-    op.time_device(dx, dy, warmup)
-    ms = op.time_device(dx, dy, runs)
+    # the operator's own staging vectors, as in the reference harness (main.cu:158-187 times run_timed, whose kernel reads and
+    # writes the vectors the operator owns): x = 1; y was placed by the operator at init (output placement, csrc/device_runtime.hpp)
+    op.time_device(None, None, warmup)
+    ms = op.time_device(None, None, runs)
     median_ms, dropped = reference_stats(ms)
+    placement = op.placement()
     y_sum = None
     if rows <= 50_000_000:
+        dx, dy = B.DeviceVector(rows, fill=1.0), B.DeviceVector(rows, fill=0.0)
+        op.run_device(dx, dy)
         y = dy.to_host()
         y_sum = float(y.sum())
+        dx.free(), dy.free()
     variant = op.variant()
-    dx.free(), dy.free(), op.free()
+    op.free()
     secs = median_ms / 1e3
     bytes_today, bytes_published, bytes_algorithmic = spmv_byte_formulas(rows, nnz)
     return {
@@ -149,6 +159,8 @@ def spmv_headline(B, n, warmup=5, runs=10):
         "effective_gbs": bytes_today / secs / 1e9, "effective_gbs_published_formula": bytes_published / secs / 1e9,
         "algorithmic_gbs": bytes_algorithmic / secs / 1e9, "frac_of_hbm_peak": bytes_algorithmic / secs / 1e9 / HBM_PEAK_GBS,
         "vs_a100_published": bytes_published / secs / 1e9 / A100_SPMV_EFFECTIVE_GBS_PUBLISHED_FORMULA, "sum_y": y_sum,
+        "vectors": "the operator's own x (= 1) and y, the ones run_timed's kernel works on",
+        "output_placement": None if placement is None else {"candidates_timed": placement[0], "first_candidate_over_kept": placement[1]},
     }
 
 
@@ -533,6 +545,7 @@ def measure_leg(c, allreduce_kind):
         if rank == 0:
             print(f"bench.py: dot-product all-reduce: {allreduce}", file=sys.stderr)
     slab = B.CgSlab.stencil5(n, comm)
+    placement = slab.placement()  # set-up work, outside the timed region (csrc/cg_slab.hip, place_ap_and_r)
 
     def barrier():
         if multi:
@@ -579,7 +592,8 @@ def measure_leg(c, allreduce_kind):
                "final_residual": st.residual_norm, "history": [float(v) for v in hist], "rank_ms": rank_ms, "parity_vs_golden": parity,
                "ranks_agree_on_history": True if multi else None, "breakdown": breakdown, "variant": slab.variant(),
                "local_rows": slab.n_local, "local_nnz": slab.local_nnz, "spmv_ms": spmv_ms, "spmv_launches": spmv_launches,
-               "rccl_ranks": comm.transport_ranks() if (comm is not None and transport == "rccl") else 0}
+               "rccl_ranks": comm.transport_ranks() if (comm is not None and transport == "rccl") else 0,
+               "placement": placement}
     finally:
         slab.destroy()
         if comm is not None:
@@ -833,6 +847,8 @@ def main():
                    launched_by="bench.py (self-launched ranks)" if os.environ.get("SPMV_AMD_BENCH_SELF_LAUNCHED") == "1" else
                    ("external launcher (RANK/WORLD_SIZE in the environment)" if "RANK" in os.environ else "single process"),
                    roofline=roofline)
+        if leg.get("placement") is not None:
+            out["placement"] = leg["placement"]
         if degraded:
             out["degraded"] = degraded
         if spmv is not None:

@@ -93,7 +93,7 @@ DECLARED_SYMBOLS = [
     "spmv_amd_comm_mailbox_disable", "spmv_amd_comm_mailbox_ready",
     "spmv_amd_cg_slab_create", "spmv_amd_cg_slab_create_stencil5", "spmv_amd_cg_slab_create_stencil5_as", "spmv_amd_cg_slab_set_vectors", "spmv_amd_cg_slab_solve",
     "spmv_amd_cg_slab_gather", "spmv_amd_cg_slab_history", "spmv_amd_cg_slab_spmv", "spmv_amd_cg_slab_info",
-    "spmv_amd_cg_slab_time_spmv", "spmv_amd_cg_slab_set_timeline", "spmv_amd_cg_slab_set_option",  "spmv_amd_cg_release_workspace", "spmv_amd_cg_slab_timeline_names", "spmv_amd_cg_slab_timeline", "spmv_amd_cg_slab_variant", "spmv_amd_cg_slab_destroy", "spmv_amd_version", "spmv_amd_write_stencil5_values",
+    "spmv_amd_cg_slab_time_spmv", "spmv_amd_cg_slab_set_timeline", "spmv_amd_cg_slab_set_option", "spmv_amd_cg_slab_lab_spmv", "spmv_amd_operator_placement", "spmv_amd_cg_slab_placement", "spmv_amd_cg_slab_lab_pair", "spmv_amd_cg_slab_lab_direction", "spmv_amd_cg_slab_spmv_launch_ms",  "spmv_amd_cg_release_workspace", "spmv_amd_cg_slab_timeline_names", "spmv_amd_cg_slab_timeline", "spmv_amd_cg_slab_variant", "spmv_amd_cg_slab_destroy", "spmv_amd_version", "spmv_amd_write_stencil5_values",
     "spmv_amd_blas1_axpy", "spmv_amd_blas1_axpby", "spmv_amd_blas1_axpy_dev", "spmv_amd_blas1_update_p_dev", "spmv_amd_blas1_dot",
     "spmv_amd_cg_fused_step",
 ]
@@ -375,11 +375,20 @@ class Operator:
         return self.op.contents.run_device(d_x.ptr, d_y.ptr)
 
     def time_device(self, d_x, d_y, reps):
+        """Kernel-only ms of `reps` run_device launches; d_x / d_y None = the operator's own staging vectors (x = 1), the
+        ones run_timed's kernel works on."""
         ms = (C.c_float * reps)()
-        rc = lib().spmv_amd_time_run_device(self.name.encode(), d_x.ptr, d_y.ptr, reps, ms)
+        rc = lib().spmv_amd_time_run_device(self.name.encode(), None if d_x is None else d_x.ptr, None if d_y is None else d_y.ptr, reps, ms)
         if rc != 0:
             raise RuntimeError(f"time_run_device -> {rc}")
         return np.array(ms[:], dtype=np.float64)
+
+    def placement(self):
+        """(candidates timed for the operator's y vector at init, kernel time on the first / on the one kept)"""
+        cand, gain = C.c_int(), C.c_double()
+        lib().spmv_amd_operator_placement.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p]
+        ok = lib().spmv_amd_operator_placement(self.name.encode(), C.byref(cand), C.byref(gain))
+        return (cand.value, gain.value) if ok else None
 
     def variant(self):
         return lib().spmv_amd_operator_variant(self.name.encode()).decode()
@@ -608,6 +617,21 @@ class CgSlab:
         v = np.zeros(len(names), dtype=np.float64)
         count = lib().spmv_amd_cg_slab_timeline(self.h, v.ctypes.data, len(v))
         return st, ({k: float(x) for k, x in zip(names, v)} if count == len(names) else {})
+
+    def placement(self):
+        """What the placement of [Ap | r] at creation did, or None if it did not run."""
+        v = (C.c_double * 3)()
+        lib().spmv_amd_cg_slab_placement.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        if lib().spmv_amd_cg_slab_placement(self.h, v, 3) != 3:
+            return None
+        return {"candidates": int(v[0]), "iteration_kernels_ms_in_arena": float(v[1]), "iteration_kernels_ms_kept": float(v[2])}
+
+    def spmv_launch_ms(self):
+        """The timed in-loop SpMV launches of the last solve, one by one (ms)."""
+        out = (C.c_float * 1024)()
+        lib().spmv_amd_cg_slab_spmv_launch_ms.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        count = lib().spmv_amd_cg_slab_spmv_launch_ms(self.h, out, 1024)
+        return np.array(out[:min(count, 1024)], dtype=np.float64)
 
     def set_option(self, name, value):
         """Loop option of this slab ("late_bulk", "lead_rows", "early_halo", "pingpong", "r_pingpong"): A/B runs on the same allocations."""

