@@ -37,7 +37,7 @@ configuration of reference docs/PROBLEM_SIZE_SCALING_RESULTS.md:40-47, on N row 
   placement (rank 0's slab) and spmv.output_placement: on this part a SpMV is ~4.5 % faster when the vector it writes lies in another
             class of 32 GiB address regions than the data it reads, and only hipMalloc decides the class (profiles/r04_spmv_regions.txt):
             at set-up, outside every timed region, the operator times its kernel on three allocations for y, one 32 GiB region apart, and keeps the fastest;
-            the slab does the same for its [Ap | r] pair against one iteration's streaming kernels. Addresses only, same bits.
+            the slab does the same for its coefficient stream, which must not share Ap's class (csrc/cg_slab.hip). Addresses only, same bits.
 
   parity_vs_golden  every run, every N: the residual history of the timed solves against the committed CPU-oracle
             history of the same grid (tests/golden/known_answers.json: 3, 81, 512, 2000, 10000, 20000); above 1e-10
@@ -545,7 +545,7 @@ def measure_leg(c, allreduce_kind):
         if rank == 0:
             print(f"bench.py: dot-product all-reduce: {allreduce}", file=sys.stderr)
     slab = B.CgSlab.stencil5(n, comm)
-    placement = slab.placement()  # set-up work, outside the timed region (csrc/cg_slab.hip, place_ap_and_r)
+    placement = slab.placement()  # set-up work, outside the timed region (csrc/cg_slab.hip, place_coefficients)
 
     def barrier():
         if multi:

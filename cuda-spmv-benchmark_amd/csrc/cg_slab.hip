@@ -85,14 +85,7 @@ struct SpmvAmdCgSlab {
     // not take part (40 B/row against 8 B/row: not in lock step; r04_arena_spmv_mix.txt), so the CSR arrays stay where they are.
     double* vec_arena = nullptr;
     bool x_b_x0_in_arena = false;
-    // Ap and r (round 4, output placement: device_runtime.hpp): the SpMV writes Ap, and a SpMV whose output lies in another
-    // class of address regions than x and the coefficients is ~4.5 % faster; r must stay with Ap (r update), and the
-    // direction update then reads r and p from different classes (+4.5 % on that kernel). Which side wins is measured: at
-    // creation the pair [Ap | r] is offered a few allocations next to its two slots in the arena, every candidate is timed on
-    // the streaming kernels of one iteration (SpMV from two direction buffers, r update, direction update) and the
-    // cheapest is kept.
-    double* ap_r_block = nullptr;       // non-null: Ap and r live here, not in the arena
-    std::vector<double> ap_r_placement;  // {candidates timed, iteration-kernels ms on the arena's slots, on the block kept}
+    std::vector<double> placement;  // place_coefficients: {candidates timed, SpMV ms before, SpMV ms kept}
     double* p_alloc = nullptr;  // [pad | prev halo | local | next halo]
     double* p = nullptr;        // local part of the CURRENT direction vector, 16-byte aligned
     // Direction ring (deferred x update). With ring_slots > 1 the direction update is written out of place into
@@ -205,7 +198,7 @@ void adopt_operator(SpmvAmdCgSlab* s, SpmvOperator* op) {
     }
 }
 
-void place_ap_and_r(SpmvAmdCgSlab* s);  // below
+void place_coefficients(SpmvAmdCgSlab* s);  // below
 
 void make_common(SpmvAmdCgSlab* s) {
     const size_t nl = (size_t)s->n_local;
@@ -366,80 +359,74 @@ void make_common(SpmvAmdCgSlab* s) {
         const auto rowlds = [&](const Stencil5Plan& p) { return p.last_row <= p.first_row || tiled(p); };
         s->fuse_init_residual = tiled(s->plan_whole) && rowlds(s->plan_interior) && rowlds(s->plan_head) && rowlds(s->plan_tail);
     }
-    place_ap_and_r(s);
+    place_coefficients(s);
     launch_fill(s->b, nl, 1.0, s->compute);   // default right-hand side b = 1
     launch_fill(s->x0, nl, 0.0, s->compute);  // default initial guess x0 = 0
     HIP_CHECK(hipDeviceSynchronize());
 }
 
-// See SpmvAmdCgSlab::ap_r_block. Own-matrix slabs of >= 16 Mi rows; runs after the launch plans exist.
-void place_ap_and_r(SpmvAmdCgSlab* s) {
+// The coefficient stream's place (round 4). The in-loop SpMV reads the coefficients V and a direction buffer x and writes Ap; by
+// class of address regions (device_runtime.hpp; whole solves with every vector bound to a slot of a chosen class:
+// profiles/r04_loop_regions.txt): Ap in a class of its own 3.55 ms, Ap with x 3.70 ms, Ap with V but not with x 3.88 ms -- and
+// a solve between 103.3 and 109.4 ms. In the vector arena Ap shares its region with the first direction buffers and not with the
+// later ones, so the one thing left to chance is whether V lies in Ap's class: if it does, every iteration on a later buffer runs
+// in the slow mode (in-loop average 3.75-3.80 ms instead of 3.60-3.65: the process that is 2 % slow). So the coefficients are
+// offered three allocations one region apart, each timed on the SpMV from an early and from a late direction buffer, and the
+// fastest is kept. Set-up work (the reference builds and uploads its CSR before its timed region,
+// cg_solver_mgpu_partitioned.cu:303-413); the values are copied, never changed. Slabs of >= 16 Mi rows that own their matrix.
+void place_coefficients(SpmvAmdCgSlab* s) {
     const size_t nl = (size_t)s->n_local;
-    if (s->op != nullptr || nl < ((size_t)16 << 20) || s->ring.size() < 2 || placement_candidates() <= 1) return;
+    if (s->op != nullptr || nl < ((size_t)16 << 20) || s->ring.size() < 4 || placement_candidates() <= 1 || s->A.values == nullptr ||
+        s->A.view.planes != nullptr)
+        return;
     hipStream_t q = s->compute;
-    CgScalars sc;  // scalars that make the timed kernels harmless: alpha = 0 (r unchanged), beta = 0, "iteration 1 of a running solve"
-    memset(&sc, 0, sizeof sc);
-    sc.pAp = 1.0;
-    sc.iterations = 1;
-    HIP_CHECK(hipMemcpy(s->d_s, &sc, sizeof sc, hipMemcpyHostToDevice));
-    for (double* a : s->ring) launch_fill(a, nl, 1.0, q);
+    const size_t count = (size_t)s->A.view.nnz_local;
+    const double* early = s->ring[1];
+    const double* late = s->ring[s->ring.size() - 3];
+    launch_fill(s->ring[1], nl, 1.0, q);
+    launch_fill(s->ring[s->ring.size() - 3], nl, 1.0, q);
+    HIP_CHECK(hipMemsetAsync(&s->d_s->converged, 0, sizeof(int), q));
     EventTimer timer;
-    auto median3 = [&](auto&& launch) {
-        float ms[3];
-        launch();
-        for (float& m : ms) {
-            timer.begin(q);
-            launch();
-            timer.end(q);
-            m = timer.elapsed_ms();
+    double* const original = s->A.values;
+    auto cost = [&](double* values) {
+        s->A.view.values = values;
+        double total = 0.0;
+        for (const double* x : {early, late}) {
+            float ms[3];
+            for (int i = 0; i < 4; ++i) {
+                timer.begin(q);
+                (void)launch_stencil5_spmv(s->A.view, s->plan_whole, x, s->Ap, 1.0, s->fused_dot ? s->partials_spmv : nullptr, nullptr, false, q);
+                timer.end(q);
+                const float t = timer.elapsed_ms();
+                if (i > 0) ms[i - 1] = t;
+            }
+            std::sort(ms, ms + 3);
+            total += ms[1];
         }
-        std::sort(ms, ms + 3);
-        return (double)ms[1];
+        s->A.view.values = original;
+        return 0.5 * total;
     };
-    const size_t pitch = (size_t)(s->Ap - s->r);  // the arena's slot pitch
-    const size_t mid = s->ring.size() / 2;
-    // one iteration's streaming kernels with Ap = block, r = block + pitch; two direction buffers stand for the ring
-    auto cost = [&](double* block) {
-        double* Ap = block;
-        double* r = block + pitch;
-        launch_fill(r, nl, 1.0, q);
-        double t = 0.0;
-        for (size_t k : {(size_t)0, mid}) {
-            const size_t next = (k + 1) % s->ring.size();
-            t += median3([&] {
-                (void)launch_stencil5_spmv(s->A.view, s->plan_whole, s->ring[k], Ap, 1.0, s->fused_dot ? s->partials_spmv : nullptr, nullptr, false, q);
-            });
-            t += median3([&] { launch_cg_update_r(nl, s->d_s, Ap, r, s->partials_blas, q, false); });
-            t += median3([&] { launch_cg_update_p_ring(nl, s->d_s, r, s->ring[k], s->ring[next], 1, q, false, s->device_form); });
-        }
-        return 0.5 * t;
-    };
-    double* const arena_block = s->r;  // slots 0 (r) and 1 (Ap) of the arena: as a block, "Ap" = slot 0 and "r" = slot 1
-    const double in_arena = cost(arena_block);
+    const double before = cost(original);
     int tried = 0;
-    double gain = 1.0;
-    double best_cost = in_arena;
-    double* block = device_alloc_best_of<double>(2 * pitch, 0, [&](double* cand) {
-        const double c = cost(cand);
-        if (c < best_cost) best_cost = c;
-        return c;
-    }, &tried, &gain);
-    const double block_cost = cost(block);
-    if (block_cost < 0.997 * in_arena) {
-        s->ap_r_block = block;
-        s->Ap = block;
-        s->r = block + pitch;
-        HIP_CHECK(hipMemsetAsync(block, 0, 2 * pitch * sizeof(double), q));
+    double* best = device_alloc_best_of<double>(count, 0, [&](double* cand) {
+        HIP_CHECK(hipMemcpyAsync(cand, original, count * sizeof(double), hipMemcpyDeviceToDevice, q));
+        return cost(cand);
+    }, &tried);
+    const double after = cost(best);
+    if (after < 0.99 * before) {
+        HIP_CHECK(hipStreamSynchronize(q));
+        device_release(s->A.values);
+        s->A.values = best;
     } else {
-        device_release(block);
+        device_release(best);
     }
+    s->A.view.values = s->A.values;
     for (double* a : s->ring_alloc) HIP_CHECK(hipMemsetAsync(a, 0, s->slot_doubles * sizeof(double), q));
-    HIP_CHECK(hipMemset(s->d_s, 0, sizeof(CgScalars)));
     HIP_CHECK(hipStreamSynchronize(q));
-    s->ap_r_placement = {(double)(tried + 1), in_arena, s->ap_r_block ? block_cost : in_arena};
+    s->placement = {(double)(tried + 1), before, s->A.values == best ? after : before};
     if (getenv("SPMV_AMD_PLACEMENT_VERBOSE"))
-        fprintf(stderr, "[cg-slab] Ap | r placement: %d candidates, iteration kernels %.4f ms in the arena, %.4f ms on the best block: %s\n", tried,
-                in_arena, block_cost, s->ap_r_block ? "moved" : "kept in the arena");
+        fprintf(stderr, "[cg-slab] coefficient placement: %d candidates, SpMV %.4f ms where they were, %.4f ms on the best candidate: %s\n", tried, before,
+                after, s->A.values == best ? "moved" : "kept");
 }
 
 bool partition_ok(const SpmvAmdComm* comm, int n, int grid, int n_local) {
@@ -1214,6 +1201,24 @@ extern "C" int spmv_amd_cg_slab_lab_pair(SpmvAmdCgSlab* s, const double* a, doub
     return 0;
 }
 
+//  lab_rebind: points the slab's loop vectors at caller-owned storage (NULL = leave as it is): Ap, r, the coefficient stream
+//  (the slab's coefficients are copied there) and the local parts of the first `ring_count` direction buffers. The caller keeps
+//  the storage alive until the slab is destroyed; the slab's own allocations stay allocated and unused. Single-rank slabs.
+extern "C" int spmv_amd_cg_slab_lab_rebind(SpmvAmdCgSlab* s, double* Ap, double* r, double* values, double* const* ring, int ring_count) {
+    if (s->op != nullptr || s->has_prev || s->has_next || ring_count > (int)s->ring.size()) return -1;
+    HIP_CHECK(hipDeviceSynchronize());
+    if (Ap) s->Ap = Ap;
+    if (r) s->r = r;
+    if (values) {
+        HIP_CHECK(hipMemcpy(values, s->A.view.values, (size_t)s->A.view.nnz_local * sizeof(double), hipMemcpyDeviceToDevice));
+        s->A.view.values = values;
+    }
+    for (int k = 0; k < ring_count; ++k)
+        if (ring[k]) s->ring[(size_t)k] = ring[k];
+    s->p = s->ring[0];
+    return 0;
+}
+
 //  lab_direction: the direction-update kernel p_out = r + 0 * p_in on caller-chosen vectors, n doubles each.
 extern "C" int spmv_amd_cg_slab_lab_direction(SpmvAmdCgSlab* s, const double* r, const double* p_in, double* p_out, size_t n, int reps,
                                               float* ms_each) {
@@ -1235,11 +1240,11 @@ extern "C" int spmv_amd_cg_slab_lab_direction(SpmvAmdCgSlab* s, const double* r,
     return 0;
 }
 
-// What the placement of [Ap | r] at creation did: {candidates timed, ms of one iteration's streaming kernels with Ap and r in the
-// arena, ms with the block that was kept}; 0 values = it did not run (small slab, borrowed operator, SPMV_AMD_PLACEMENT_CANDIDATES=1).
+// What the placement of the coefficient stream at creation did: {candidates timed, SpMV ms (mean of an early and a late
+// direction buffer as x) where the coefficients were, ms where they are now}; 0 values = it did not run.
 extern "C" int spmv_amd_cg_slab_placement(const SpmvAmdCgSlab* s, double* out, int cap) {
-    const int count = (int)s->ap_r_placement.size();
-    for (int i = 0; i < count && i < cap; ++i) out[i] = s->ap_r_placement[i];
+    const int count = (int)s->placement.size();
+    for (int i = 0; i < count && i < cap; ++i) out[i] = s->placement[i];
     return count;
 }
 
@@ -1297,7 +1302,6 @@ extern "C" void spmv_amd_cg_slab_destroy(SpmvAmdCgSlab* s) {
         device_release(s->b);
     }
     s->x0 = nullptr;
-    device_release(s->ap_r_block);
     device_release(s->vec_arena);  // r, Ap and the direction buffers
     s->r = s->Ap = s->p_alloc = s->p = nullptr;
     s->ring_alloc.clear();

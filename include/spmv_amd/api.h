@@ -351,9 +351,10 @@ void spmv_amd_cg_slab_set_timeline(SpmvAmdCgSlab* s, int on);
 /* Measurement aids (tools/spmv_regions.py): the slab's SpMV kernel / r-update kernel on caller-chosen device addresses. */
 int spmv_amd_cg_slab_lab_spmv(SpmvAmdCgSlab* s, double* values, double* x, double* y, int reverse, int reps, float* ms_each);
 int spmv_amd_cg_slab_lab_pair(SpmvAmdCgSlab* s, const double* a, double* b, size_t n, int reps, float* ms_each);
+int spmv_amd_cg_slab_lab_rebind(SpmvAmdCgSlab* s, double* Ap, double* r, double* values, double* const* ring, int ring_count);
 int spmv_amd_cg_slab_lab_direction(SpmvAmdCgSlab* s, const double* r, const double* p_in, double* p_out, size_t n, int reps, float* ms_each);
-/* Placement of the slab's [Ap | r] pair at creation (csrc/cg_slab.hip, place_ap_and_r): {candidates timed, ms of one iteration's
- * streaming kernels with the pair in the vector arena, ms with the allocation kept}. Returns 3, or 0 if it did not run. */
+/* Placement of the slab's coefficient stream at creation (csrc/cg_slab.hip, place_coefficients): {candidates timed, SpMV ms where
+ * the coefficients were first allocated, SpMV ms where they are now}. Returns 3, or 0 if it did not run. */
 int spmv_amd_cg_slab_placement(const SpmvAmdCgSlab* s, double* out, int cap);
 /* The timed in-loop SpMV launches of the last solve, one by one (ms, iteration order). Returns their number. */
 int spmv_amd_cg_slab_spmv_launch_ms(const SpmvAmdCgSlab* s, float* out, int cap);

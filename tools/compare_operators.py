@@ -2,6 +2,7 @@
 reference's benchmark rule (x = 1, 5 warm-ups, 10 timed launches, >2 sigma dropped, median;
 src/main/main.cu:136-187) and both byte counts: the reference's "effective" formula
 (spmv_metrics.cu:85-101) and the algorithmic bytes of each format.
+Vectors: each operator's own staging pair, as in the reference harness (run_timed).
    python tools/compare_operators.py 10000 stencil5-csr cusparse-csr
    python tools/compare_operators.py 15000 ellpack stencil5-ellpack stencil5-csr cusparse-csr"""
 import importlib.util
@@ -38,9 +39,10 @@ out = []
 for mode in modes:
     op = B.Operator(mode)
     assert op.init_synthetic(n) == 0
-    dx, dy = B.DeviceVector(rows, fill=1.0), B.DeviceVector(rows, fill=0.0)
-    op.time_device(dx, dy, 5)
-    ms = op.time_device(dx, dy, 10)
+    # the operator's own x (= 1) and y: the vectors run_timed's kernel works on, y placed by the operator at init
+    op.time_device(None, None, 5)
+    ms = op.time_device(None, None, 10)
+    placed = op.placement()
     keep = ms[np.abs(ms - ms.mean()) <= 2.0 * ms.std()]
     med = float(np.median(keep))
     rec = {"operator": mode, "variant": op.variant(), "grid": n, "median_ms": med, "gflops": 2.0 * nnz / med / 1e6,
@@ -53,5 +55,7 @@ for mode in modes:
     print(f"{mode:18s} {rec['variant']:22s} {med:8.3f} ms  eff {rec['effective_gbs_reference_formula']:8.1f} GB/s  "
           f"alg {rec['algorithmic_gbs']:8.1f} GB/s ({rec['frac_of_8TBs']:.3f} of 8 TB/s"
           + (f", {rec['frac_of_ceiling']:.3f} of the measured {MIX[mode]}-mix ceiling)" if "frac_of_ceiling" in rec else ")"))
-    dx.free(), dy.free(), op.free()
+    if placed:
+        print(f"{'':18s} output placement: {placed[0]} candidates timed at init, first / kept = {placed[1]:.3f}")
+    op.free()
 print(json.dumps(out))
