@@ -415,8 +415,7 @@ void place_coefficients(SpmvAmdCgSlab* s) {
     const double after = cost(best);
     if (after < 0.99 * before) {
         HIP_CHECK(hipStreamSynchronize(q));
-        device_release(s->A.values);
-        s->A.values = best;
+        s->A.replace_values(best);
     } else {
         device_release(best);
     }

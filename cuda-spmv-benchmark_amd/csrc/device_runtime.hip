@@ -67,13 +67,37 @@ LaunchShape current_launch_shape() {
     return cached;
 }
 
+void DeviceCsr::allocate(size_t n_local, size_t local_nnz) {
+    const char* v = getenv("SPMV_AMD_CSR_ARENA");
+    if (v != nullptr && v[0] == '0') {
+        row_ptr = device_alloc<int>(n_local + 1);
+        col_idx = device_alloc<int>(local_nnz);
+        values = device_alloc<double>(local_nnz);
+        return;
+    }
+    constexpr size_t k4KiB = 4096;
+    auto up = [](size_t bytes) { return (bytes + k4KiB - 1) / k4KiB * k4KiB; };
+    const size_t v_bytes = up((local_nnz ? local_nnz : 1) * sizeof(double)), c_bytes = up((local_nnz ? local_nnz : 1) * sizeof(int)),
+                 r_bytes = up((n_local + 1) * sizeof(int));
+    block = device_alloc<char>(v_bytes + c_bytes + r_bytes);
+    values = reinterpret_cast<double*>(block);
+    col_idx = reinterpret_cast<int*>(static_cast<char*>(block) + v_bytes);
+    row_ptr = reinterpret_cast<int*>(static_cast<char*>(block) + v_bytes + c_bytes);
+}
+
+void DeviceCsr::replace_values(double* fresh) {
+    if (values_moved != nullptr) device_release(values_moved);
+    if (block == nullptr) device_release(values);
+    values_moved = fresh;
+    values = fresh;
+    view.values = fresh;
+}
+
 void DeviceCsr::upload_slab(const CSRMatrix& host, int row_offset, int n_local, int grid_size) {
     release();
     const long long base = host.row_ptr[row_offset];
     const long long local_nnz = (long long)host.row_ptr[row_offset + n_local] - base;
-    row_ptr = device_alloc<int>((size_t)n_local + 1);
-    col_idx = device_alloc<int>((size_t)local_nnz);
-    values = device_alloc<double>((size_t)local_nnz);
+    allocate((size_t)n_local, (size_t)local_nnz);
     if (base == 0) {
         upload(row_ptr, host.row_ptr, (size_t)n_local + 1);
     } else {
@@ -106,9 +130,7 @@ void DeviceCsr::generate_stencil5(int n, int row_offset, int n_local, double cen
     const long long base = stencil_row_start_flat(row_offset, n);
     const long long end = stencil_row_start_flat((long long)row_offset + n_local, n);
     const long long local_nnz = end - base;
-    row_ptr = device_alloc<int>((size_t)n_local + 1);
-    col_idx = device_alloc<int>((size_t)local_nnz);
-    values = device_alloc<double>((size_t)local_nnz);
+    allocate((size_t)n_local, (size_t)local_nnz);
     launch_generate_stencil5_csr(n, row_offset, n_local, base, center, off, row_ptr, col_idx, values,
                                  stream);
     view = SlabCsr{};
@@ -155,9 +177,22 @@ void DeviceCsr::build_planes(hipStream_t stream) {
 
 void DeviceCsr::release() {
     device_release(planes);
-    device_release(row_ptr);
-    device_release(col_idx);
-    device_release(values);
+    if (block != nullptr) {
+        char* b = static_cast<char*>(block);
+        device_release(b);
+        block = nullptr;
+        row_ptr = nullptr;
+        col_idx = nullptr;
+        if (values_moved == nullptr) values = nullptr;
+    } else {
+        device_release(row_ptr);
+        device_release(col_idx);
+        if (values_moved == nullptr) device_release(values);
+    }
+    if (values_moved != nullptr) {
+        device_release(values_moved);
+        values = nullptr;
+    }
     view = SlabCsr{};
 }
 

@@ -137,9 +137,19 @@ void release_cg_workspace();
 
 // Device-resident CSR of one operator or one slab (owning).
 struct DeviceCsr {
+    // The three arrays are carved out of ONE allocation, values first: the CSR kernels read values[e] and col_idx[e] in lock
+    // step, and lock-step streams in different 32 GiB classes of the address space run ~6 % slower (see device_alloc_best_of
+    // below); neighbours in one allocation share a region except where it crosses a boundary. SPMV_AMD_CSR_ARENA=0: three
+    // allocations, as before round 4.
+    void* block = nullptr;          // owner of row_ptr / col_idx / values when non-null
+    double* values_moved = nullptr;  // owner of `values` after replace_values()
     int* row_ptr = nullptr;
     int* col_idx = nullptr;
     double* values = nullptr;
+    // allocates the three arrays for n_local rows and local_nnz entries (one block, or three allocations)
+    void allocate(size_t n_local, size_t local_nnz);
+    // `values` := fresh (same contents, the caller copied them); the array inside the block stays allocated and unused
+    void replace_values(double* fresh);
     double* planes = nullptr;  // optional plane copy of a verified stencil's coefficients (SlabCsr::planes)
     SlabCsr view;  // non-owning descriptor handed to the kernels
 

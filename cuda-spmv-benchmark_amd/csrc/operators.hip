@@ -12,6 +12,7 @@
 // the x/y staging vectors; run_timed copies x in, times the kernel alone with events, copies y
 // out; run_device enqueues on the default stream and returns; free drops device memory only.
 // One live instance per operator per process (file-static state, as upstream).
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -234,8 +235,23 @@ void csr_free() {
 struct EllOperator {
     const char* tag;
     bool stencil_fast_path;
-    int* idx = nullptr;    // slot-major
-    double* val = nullptr; // slot-major
+    // slot-major planes, both carved out of ONE allocation (val first): the kernel reads val[k][r] and idx[k][r] in lock step
+    // (DeviceCsr has the reason; SPMV_AMD_CSR_ARENA=0: two allocations)
+    char* planes_block = nullptr;
+    int* idx = nullptr;
+    double* val = nullptr;
+    void alloc_planes(size_t slots) {
+        const char* v = getenv("SPMV_AMD_CSR_ARENA");
+        if (v != nullptr && v[0] == '0') {
+            idx = device_alloc<int>(slots);
+            val = device_alloc<double>(slots);
+            return;
+        }
+        const size_t v_bytes = (slots * sizeof(double) + 4095) / 4096 * 4096;
+        planes_block = device_alloc<char>(v_bytes + slots * sizeof(int));
+        val = reinterpret_cast<double*>(planes_block);
+        idx = reinterpret_cast<int*>(planes_block + v_bytes);
+    }
     double* dX = nullptr;
     double* dY = nullptr;
     int rows = 0, cols = 0, width = 0, grid_size = -1;
@@ -245,8 +261,14 @@ struct EllOperator {
     int y_candidates = 1;  // output placement (device_runtime.hpp)
     double y_gain = 1.0;
     void drop() {
-        device_release(idx);
-        device_release(val);
+        if (planes_block != nullptr) {
+            device_release(planes_block);
+            idx = nullptr;
+            val = nullptr;
+        } else {
+            device_release(idx);
+            device_release(val);
+        }
         device_release(dX);
         device_release(dY);
         ready = false;
@@ -306,8 +328,7 @@ int ell_init_common(EllOperator& op, MatrixData* mat) {
     double* val_rm = device_alloc<double>(slots);
     upload(idx_rm, E.indices, slots);
     upload(val_rm, E.values, slots);
-    op.idx = device_alloc<int>(slots);
-    op.val = device_alloc<double>(slots);
+    op.alloc_planes(slots);
     launch_ell_transpose(op.rows, op.width, idx_rm, val_rm, op.idx, op.val, kDefaultStream);
     HIP_CHECK(hipStreamSynchronize(kDefaultStream));
     device_release(idx_rm);
@@ -337,8 +358,7 @@ int ell_init_synthetic(EllOperator& op, int n) {
     op.width = n >= 3 ? 5 : (n == 2 ? 3 : 1);
     op.grid_size = n;
     const size_t slots = (size_t)op.rows * op.width;
-    op.idx = device_alloc<int>(slots);
-    op.val = device_alloc<double>(slots);
+    op.alloc_planes(slots);
     hipLaunchKernelGGL(csr_to_ell_slotmajor_kernel, dim3((op.rows + 255) / 256), dim3(256), 0,
                        kDefaultStream, src.view, op.width, op.idx, op.val);
     HIP_CHECK(hipStreamSynchronize(kDefaultStream));
