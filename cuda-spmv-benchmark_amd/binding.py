@@ -620,11 +620,13 @@ class CgSlab:
 
     def placement(self):
         """What the placement of the coefficient stream at creation did, or None if it did not run."""
-        v = (C.c_double * 3)()
+        v = (C.c_double * 4)()
         lib().spmv_amd_cg_slab_placement.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
-        if lib().spmv_amd_cg_slab_placement(self.h, v, 3) != 3:
+        if lib().spmv_amd_cg_slab_placement(self.h, v, 4) != 4:
             return None
-        return {"candidates": int(v[0]), "spmv_ms_before": float(v[1]), "spmv_ms_kept": float(v[2])}
+        if v[0] == 1.0:
+            return {"kind": "class pool", "chunks_created": int(v[1]), "chunks_in_vectors": int(v[2]), "coefficients_in_pool": bool(v[3])}
+        return {"kind": "coefficient candidates", "candidates": int(v[1]), "spmv_ms_before": float(v[2]), "spmv_ms_kept": float(v[3])}
 
     def spmv_launch_ms(self):
         """The timed in-loop SpMV launches of the last solve, one by one (ms)."""

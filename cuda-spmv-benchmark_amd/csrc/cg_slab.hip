@@ -43,6 +43,7 @@
 #include <mutex>
 #include <vector>
 
+#include "class_pool.hpp"
 #include "comm.hpp"
 #include "device_runtime.hpp"
 #include "stencil_geometry.hpp"
@@ -85,7 +86,15 @@ struct SpmvAmdCgSlab {
     // not take part (40 B/row against 8 B/row: not in lock step; r04_arena_spmv_mix.txt), so the CSR arrays stay where they are.
     double* vec_arena = nullptr;
     bool x_b_x0_in_arena = false;
-    std::vector<double> placement;  // place_coefficients: {candidates timed, SpMV ms before, SpMV ms kept}
+    // Class pool (class_pool.hpp; opt-in, SPMV_AMD_CLASS_POOL=1): on single-rank slabs of >= 1e8 rows the vectors are not
+    // carved out of an arena but built from physical chunks of a chosen class -- Ap and r in one class, the direction buffers
+    // and the coefficient stream outside it: the layout that measured 103.3 ms where the arena gives 104.3
+    // (profiles/r04_loop_regions.txt). Null where it is off, does not apply or could not deliver (then the arena is used).
+    ClassPool* pool = nullptr;
+    int pool_v_class = -1;
+    int pool_plan[3] = {-1, -1, -1};  // class of [Ap | r], of the direction buffers, of the coefficients
+    // place_coefficients: {0, candidates timed, SpMV ms before, SpMV ms kept} or {1, pool chunks created, chunks in vectors, coefficients in the pool}
+    std::vector<double> placement;
     double* p_alloc = nullptr;  // [pad | prev halo | local | next halo]
     double* p = nullptr;        // local part of the CURRENT direction vector, 16-byte aligned
     // Direction ring (deferred x update). With ring_slots > 1 the direction update is written out of place into
@@ -273,24 +282,84 @@ void make_common(SpmvAmdCgSlab* s) {
         const size_t budget = s->op != nullptr ? free_b / 4 : (free_b > keep_free + fixed ? free_b - keep_free - fixed : 0);
         while (want > 1 && (size_t)(want - 1) * per_slot > budget) --want;
         if (want < asked && want < 4) want = 1;  // a ring cut short by memory flushes too often to pay
-        const size_t arena_slots = (size_t)(2 + want) + (arena_all ? 3 : 0);
-        s->vec_arena = device_alloc<double>(arena_slots * pitch);
-        HIP_CHECK(hipMemset(s->vec_arena, 0, arena_slots * pitch * sizeof(double)));
-        if (arena_all) {
-            s->x0_alloc = s->vec_arena + (size_t)(2 + want) * pitch;
-            s->x0 = s->x0_alloc + lead;
-            s->b = s->vec_arena + (size_t)(3 + want) * pitch;
-            s->x = s->vec_arena + (size_t)(4 + want) * pitch;
-            s->x_b_x0_in_arena = true;
+        const bool try_pool = s->op == nullptr && !s->comm->exchanges_halos() && !arena_all && nl >= 100000000 && want >= 4;
+        if (try_pool) {
+            // Ap and r from one class, the direction buffers from the class with the most chunks, the coefficient stream (later,
+            // place_coefficients) from any class but Ap's. Twice the chunks needed are created and sorted; if the classes that
+            // came up cannot serve the plan, half as many again, twice; then the arena takes over.
+            ClassPool* pool = new ClassPool(slot_doubles * sizeof(double), s->compute);
+            bool ok = pool->usable() && s->A.values != nullptr;
+            const size_t need_ring = ok ? (size_t)want * pool->chunks_for(slot_doubles * sizeof(double)) : 0;
+            const size_t need_pair = ok ? 2 * pool->chunks_for(nl * sizeof(double)) : 0;
+            const size_t need_v = ok ? pool->chunks_for((size_t)s->A.view.nnz_local * sizeof(double)) : 0;
+            const size_t need = need_ring + need_pair + need_v;
+            int ring_cls = -1, pair_cls = -1, v_cls = -1;
+            ok = ok && pool->grow((int)(2 * need + 8)) > 0;
+            for (int attempt = 0; ok && attempt < 3; ++attempt) {
+                ring_cls = pair_cls = v_cls = -1;
+                for (int c = 0; c < pool->classes(); ++c)
+                    if ((size_t)pool->available(c) >= need_ring && (ring_cls < 0 || pool->available(c) > pool->available(ring_cls))) ring_cls = c;
+                for (int c = 0; c < pool->classes(); ++c)
+                    if (c != ring_cls && (size_t)pool->available(c) >= need_pair && (pair_cls < 0 || pool->available(c) < pool->available(pair_cls))) pair_cls = c;
+                for (int c = 0; c < pool->classes(); ++c) {
+                    if (c == pair_cls) continue;
+                    const size_t spare = (size_t)pool->available(c) - (c == ring_cls ? need_ring : 0);
+                    if ((size_t)pool->available(c) >= (c == ring_cls ? need_ring : 0) + need_v &&
+                        (v_cls < 0 || spare > (size_t)pool->available(v_cls) - (v_cls == ring_cls ? need_ring : 0)))
+                        v_cls = c;
+                }
+                if (ring_cls >= 0 && pair_cls >= 0 && v_cls >= 0) break;
+                if (attempt == 2 || pool->grow((int)(need / 2 + 4)) <= 0) ok = false;
+            }
+            ok = ok && ring_cls >= 0 && pair_cls >= 0 && v_cls >= 0;
+            double *ap = nullptr, *r = nullptr;
+            std::vector<double*> slots;
+            if (ok) ok = (ap = pool->vector(nl * sizeof(double), pair_cls)) != nullptr;
+            if (ok) ok = (r = pool->vector(nl * sizeof(double), pair_cls)) != nullptr;
+            for (int k = 0; k < want && ok; ++k) {
+                double* a = pool->vector(slot_doubles * sizeof(double), ring_cls);
+                ok = a != nullptr;
+                if (ok) slots.push_back(a);
+            }
+            if (ok) {
+                s->pool = pool;
+                s->pool_v_class = v_cls;
+                s->pool_plan[0] = pair_cls, s->pool_plan[1] = ring_cls, s->pool_plan[2] = v_cls;
+                s->Ap = ap;
+                s->r = r;
+                s->ring_alloc = slots;
+                s->ring.clear();
+                for (double* a : slots) s->ring.push_back(a + lead);
+            } else {
+                if (getenv("SPMV_AMD_PLACEMENT_VERBOSE")) {
+                    fprintf(stderr, "[cg-slab] class pool gave up (usable %d): %d chunks in %d classes, %d set aside, fast mode %.4f ms; available per class:",
+                            (int)pool->usable(), pool->chunks_created(), pool->classes(), pool->chunks_set_aside(), pool->fast_ms());
+                    for (int c = 0; c < pool->classes(); ++c) fprintf(stderr, " %d", pool->available(c));
+                    fprintf(stderr, "; needed %zu + %zu + %zu\n", need_ring, need_pair, need_v);
+                }
+                delete pool;  // gives back everything it created; the arena below takes over
+            }
         }
-        s->r = s->vec_arena;
-        s->Ap = s->vec_arena + pitch;
-        s->ring_alloc.clear();
-        s->ring.clear();
-        for (int k = 0; k < want; ++k) {
-            double* a = s->vec_arena + (size_t)(2 + k) * pitch;
-            s->ring_alloc.push_back(a);
-            s->ring.push_back(a + lead);
+        if (s->pool == nullptr) {
+            const size_t arena_slots = (size_t)(2 + want) + (arena_all ? 3 : 0);
+            s->vec_arena = device_alloc<double>(arena_slots * pitch);
+            HIP_CHECK(hipMemset(s->vec_arena, 0, arena_slots * pitch * sizeof(double)));
+            if (arena_all) {
+                s->x0_alloc = s->vec_arena + (size_t)(2 + want) * pitch;
+                s->x0 = s->x0_alloc + lead;
+                s->b = s->vec_arena + (size_t)(3 + want) * pitch;
+                s->x = s->vec_arena + (size_t)(4 + want) * pitch;
+                s->x_b_x0_in_arena = true;
+            }
+            s->r = s->vec_arena;
+            s->Ap = s->vec_arena + pitch;
+            s->ring_alloc.clear();
+            s->ring.clear();
+            for (int k = 0; k < want; ++k) {
+                double* a = s->vec_arena + (size_t)(2 + k) * pitch;
+                s->ring_alloc.push_back(a);
+                s->ring.push_back(a + lead);
+            }
         }
         s->p_alloc = s->ring_alloc[0];
         s->p = s->ring[0];
@@ -376,6 +445,30 @@ void make_common(SpmvAmdCgSlab* s) {
 // cg_solver_mgpu_partitioned.cu:303-413); the values are copied, never changed. Slabs of >= 16 Mi rows that own their matrix.
 void place_coefficients(SpmvAmdCgSlab* s) {
     const size_t nl = (size_t)s->n_local;
+    if (s->pool != nullptr && s->A.values != nullptr && s->A.view.planes == nullptr) {
+        hipStream_t q = s->compute;
+        const size_t count = (size_t)s->A.view.nnz_local;
+        // with a class pool the coefficients simply go where the direction buffers are: outside the class of Ap and r
+        double* v = s->pool->vector(count * sizeof(double), s->pool_v_class);
+        if (v != nullptr) {
+            HIP_CHECK(hipMemcpyAsync(v, s->A.values, count * sizeof(double), hipMemcpyDeviceToDevice, q));
+            HIP_CHECK(hipStreamSynchronize(q));
+            s->A.borrow_values(v);
+        }
+        const int classes_found = s->pool->classes();
+        s->pool->trim();
+        s->placement = {1.0, (double)s->pool->chunks_created(), (double)s->pool->chunks_in_vectors(), v != nullptr ? 1.0 : 0.0};
+        if (getenv("SPMV_AMD_PLACEMENT_VERBOSE"))
+            fprintf(stderr, "[cg-slab] class pool: %d chunks of %zu MiB created in %d classes, %d in vectors, %d set aside; pair kernel fast mode %.4f ms; "
+                            "Ap and r in class %d, direction buffers in class %d, coefficients %s (class %d)\n",
+                    s->pool->chunks_created(), s->pool->chunk_bytes() >> 20, classes_found, s->pool->chunks_in_vectors(), s->pool->chunks_set_aside(),
+                    s->pool->fast_ms(), s->pool_plan[0], s->pool_plan[1], v != nullptr ? "in the pool" : "left where they were", s->pool_plan[2]);
+        return;
+    }
+    if (s->pool != nullptr) {
+        s->pool->trim();
+        return;
+    }
     if (s->op != nullptr || nl < ((size_t)16 << 20) || s->ring.size() < 4 || placement_candidates() <= 1 || s->A.values == nullptr ||
         s->A.view.planes != nullptr)
         return;
@@ -422,7 +515,7 @@ void place_coefficients(SpmvAmdCgSlab* s) {
     s->A.view.values = s->A.values;
     for (double* a : s->ring_alloc) HIP_CHECK(hipMemsetAsync(a, 0, s->slot_doubles * sizeof(double), q));
     HIP_CHECK(hipStreamSynchronize(q));
-    s->placement = {(double)(tried + 1), before, s->A.values == best ? after : before};
+    s->placement = {0.0, (double)(tried + 1), before, s->A.values == best ? after : before};
     if (getenv("SPMV_AMD_PLACEMENT_VERBOSE"))
         fprintf(stderr, "[cg-slab] coefficient placement: %d candidates, SpMV %.4f ms where they were, %.4f ms on the best candidate: %s\n", tried, before,
                 after, s->A.values == best ? "moved" : "kept");
@@ -1239,8 +1332,9 @@ extern "C" int spmv_amd_cg_slab_lab_direction(SpmvAmdCgSlab* s, const double* r,
     return 0;
 }
 
-// What the placement of the coefficient stream at creation did: {candidates timed, SpMV ms (mean of an early and a late
-// direction buffer as x) where the coefficients were, ms where they are now}; 0 values = it did not run.
+// What placement at creation did. {0, candidates timed, SpMV ms (mean of an early and a late direction buffer as x) where the
+// coefficients were, ms where they are now}: the coefficient stream was placed by timing candidates; {1, chunks created, chunks in
+// vectors, 1 if the coefficients are in the pool too}: the vectors were built by the class pool. 0 values = neither ran.
 extern "C" int spmv_amd_cg_slab_placement(const SpmvAmdCgSlab* s, double* out, int cap) {
     const int count = (int)s->placement.size();
     for (int i = 0; i < count && i < cap; ++i) out[i] = s->placement[i];
@@ -1303,6 +1397,8 @@ extern "C" void spmv_amd_cg_slab_destroy(SpmvAmdCgSlab* s) {
     s->x0 = nullptr;
     device_release(s->vec_arena);  // r, Ap and the direction buffers
     s->r = s->Ap = s->p_alloc = s->p = nullptr;
+    delete s->pool;  // after s->A.release(): a borrowed coefficient stream is the pool's
+    s->pool = nullptr;
     s->ring_alloc.clear();
     s->ring.clear();
     device_release(s->r2);

@@ -87,10 +87,19 @@ void DeviceCsr::allocate(size_t n_local, size_t local_nnz) {
 
 void DeviceCsr::replace_values(double* fresh) {
     if (values_moved != nullptr) device_release(values_moved);
-    if (block == nullptr) device_release(values);
+    else if (block == nullptr && !values_borrowed) device_release(values);
+    values_borrowed = false;
     values_moved = fresh;
     values = fresh;
     view.values = fresh;
+}
+
+void DeviceCsr::borrow_values(double* theirs) {
+    if (values_moved != nullptr) device_release(values_moved);
+    else if (block == nullptr && !values_borrowed) device_release(values);
+    values_borrowed = true;
+    values = theirs;
+    view.values = theirs;
 }
 
 void DeviceCsr::upload_slab(const CSRMatrix& host, int row_offset, int n_local, int grid_size) {
@@ -183,16 +192,14 @@ void DeviceCsr::release() {
         block = nullptr;
         row_ptr = nullptr;
         col_idx = nullptr;
-        if (values_moved == nullptr) values = nullptr;
     } else {
         device_release(row_ptr);
         device_release(col_idx);
-        if (values_moved == nullptr) device_release(values);
+        if (values_moved == nullptr && !values_borrowed) device_release(values);
     }
-    if (values_moved != nullptr) {
-        device_release(values_moved);
-        values = nullptr;
-    }
+    if (values_moved != nullptr) device_release(values_moved);
+    values = nullptr;
+    values_borrowed = false;
     view = SlabCsr{};
 }
 

@@ -150,6 +150,9 @@ struct DeviceCsr {
     void allocate(size_t n_local, size_t local_nnz);
     // `values` := fresh (same contents, the caller copied them); the array inside the block stays allocated and unused
     void replace_values(double* fresh);
+    // `values` := memory somebody else owns and keeps alive (a ClassPool vector), same contents
+    void borrow_values(double* theirs);
+    bool values_borrowed = false;
     double* planes = nullptr;  // optional plane copy of a verified stencil's coefficients (SlabCsr::planes)
     SlabCsr view;  // non-owning descriptor handed to the kernels
 

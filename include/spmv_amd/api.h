@@ -353,8 +353,11 @@ int spmv_amd_cg_slab_lab_spmv(SpmvAmdCgSlab* s, double* values, double* x, doubl
 int spmv_amd_cg_slab_lab_pair(SpmvAmdCgSlab* s, const double* a, double* b, size_t n, int reps, float* ms_each);
 int spmv_amd_cg_slab_lab_rebind(SpmvAmdCgSlab* s, double* Ap, double* r, double* values, double* const* ring, int ring_count);
 int spmv_amd_cg_slab_lab_direction(SpmvAmdCgSlab* s, const double* r, const double* p_in, double* p_out, size_t n, int reps, float* ms_each);
-/* Placement of the slab's coefficient stream at creation (csrc/cg_slab.hip, place_coefficients): {candidates timed, SpMV ms where
- * the coefficients were first allocated, SpMV ms where they are now}. Returns 3, or 0 if it did not run. */
+/* Placement at creation (csrc/cg_slab.hip, csrc/class_pool.hpp). Slabs of >= 16 Mi rows place their coefficient stream by timing
+ * candidates: {0, candidates timed, SpMV ms before, SpMV ms kept}. With SPMV_AMD_CLASS_POOL=1 (opt-in) single-rank slabs of
+ * >= 1e8 rows instead build r, Ap, the direction buffers and the coefficient stream from physical chunks of chosen classes of
+ * address regions (HIP virtual-memory API): {1, chunks created, chunks in vectors, 1 if the coefficients are in the pool}.
+ * Returns 4, or 0 if neither ran. Addresses only: results never change. */
 int spmv_amd_cg_slab_placement(const SpmvAmdCgSlab* s, double* out, int cap);
 /* The timed in-loop SpMV launches of the last solve, one by one (ms, iteration order). Returns their number. */
 int spmv_amd_cg_slab_spmv_launch_ms(const SpmvAmdCgSlab* s, float* out, int cap);

@@ -241,6 +241,59 @@ def test_a_failing_run_device_is_a_status_not_the_end_of_the_callers_process(B, 
     real.free()
 
 
+def test_placement_at_set_up_changes_addresses_only(B, O, fresh_host_matrices, monkeypatch):
+    """Round 4's set-up work -- the vector arena, the placement of the coefficient stream (slabs) and of the vector run_timed's
+    kernel writes (operators), both by timing a few allocations one 32 GiB region apart -- may change where data lies and nothing
+    else. A grid large enough for the trials to run (4200^2 = 17.6 M rows >= 16 Mi): with 3 candidates and with the trials
+    off, the operator's y and the solver's history and solution are bit-identical, and the records say what was done."""
+    n = 4200
+    out = {}
+    for cand in ("3", "1"):
+        monkeypatch.setenv("SPMV_AMD_PLACEMENT_CANDIDATES", cand)
+        op = B.Operator("stencil5-csr")
+        assert op.init_synthetic(n) == 0
+        placed = op.placement()
+        assert placed is not None and placed[0] == int(cand) and placed[1] > 0.9
+        ms = op.time_device(None, None, 3)  # the operator's own vectors: x = 1
+        assert len(ms) == 3 and np.all(ms > 0)
+        dx, dy = B.DeviceVector(n * n, fill=1.0), B.DeviceVector(n * n, fill=0.0)
+        op.run_device(dx, dy)
+        y = dy.to_host()
+        assert y.sum() == n * n + 4 * n  # the generator stencil's analytic checksum (SURVEY 8c)
+        dx.free(), dy.free(), op.free()
+        slab = B.CgSlab.stencil5(n)
+        rec = slab.placement()
+        assert (rec is None) if cand == "1" else (rec["kind"] == "coefficient candidates" and rec["candidates"] == 4 and rec["spmv_ms_kept"] <= rec["spmv_ms_before"] * 1.001)
+        st = slab.solve()
+        each = slab.spmv_launch_ms()
+        assert 0 < len(each) <= st.iterations and np.all(each > 0)
+        out[cand] = (y, slab.history().copy(), slab.gather(), st.iterations)
+        slab.destroy()
+    assert np.array_equal(out["3"][0], out["1"][0]) and np.array_equal(out["3"][1], out["1"][1])
+    assert np.array_equal(out["3"][2], out["1"][2]) and out["3"][3] == out["1"][3]
+
+
+def test_class_pool_vectors_change_no_bit(B, monkeypatch):
+    """SPMV_AMD_CLASS_POOL=1: r, Ap, the direction buffers and the coefficient stream mapped from physical chunks of chosen
+    classes (HIP virtual-memory API) instead of carved out of the arena. The slab must be large enough for the pool to apply
+    (1e8 rows: grid 10 000); history and solution are bit-identical to the arena's, the record says which ran, and a pool
+    that cannot deliver falls back silently to the arena."""
+    n = 10000
+    out = {}
+    for pool in ("0", "1"):
+        monkeypatch.setenv("SPMV_AMD_CLASS_POOL", pool)
+        slab = B.CgSlab.stencil5(n)
+        rec = slab.placement()
+        st = slab.solve()
+        st2 = slab.solve()
+        assert st.iterations == st2.iterations == 14 and st.converged == 1
+        out[pool] = (rec, slab.history().copy(), slab.gather())
+        slab.destroy()
+    assert out["0"][0]["kind"] == "coefficient candidates"
+    assert out["1"][0]["kind"] in ("class pool", "coefficient candidates")  # the second only if the pool had to give up
+    assert np.array_equal(out["0"][1], out["1"][1]) and np.array_equal(out["0"][2], out["1"][2])
+
+
 def test_slab_timeline_accounts_for_the_solve(B, O, fresh_host_matrices):
     """spmv_amd_cg_slab_set_timeline: stage-boundary events without host syncs. The stages of an iteration add up to the
     iteration, the iterations (+ initial residual + flush) to the solve, and the numbers are those of a plain solve."""

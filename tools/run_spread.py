@@ -25,6 +25,9 @@ for k in range(runs):
             continue
         line = json.loads(lines[-1])
         res[name].append(line)
+        for l in out.stderr.splitlines():
+            if l.startswith("[cg-slab] class pool") or l.startswith("[cg-slab] coefficient"):
+                print("      " + l[:260])
         st = line["roofline"].get("stages", {})
         print(f"   {name:24s} {line['value']:.2f} it/s  {line['ms_per_step']:.3f} ms/solve  in-loop SpMV {line['roofline']['avg_launch_ms']:.4f} ms "
               f"(frac {line['roofline']['frac']:.3f}, of ceiling {line['roofline'].get('frac_of_ceiling', 0):.3f})  standalone SpMV {line['spmv']['median_ms']:.4f} ms  "
