@@ -757,17 +757,22 @@ def main():
                  | {"breakdown": breakdown_summary(leg["breakdown"])})
         leave(0)
 
-    spmv = None
-    if world == 1 and not args.no_spmv:
-        spmv = spmv_headline(B, n)
-
-    # headline leg: north_star's path (RCCL send/recv halos + ncclAllReduce); SPMV_AMD_BENCH_ALLREDUCE=mailbox swaps the legs
+    # headline leg FIRST: the slab is then the first large allocation of the process and gets the device's free memory in one
+    # piece (what a solver run by itself gets; behind another leg's allocations and frees the same solve measured 0.5 % slower,
+    # profiles/r04_class_pool_clean_process.txt against r04_class_pool_1gib_chunks.txt). north_star's path (RCCL send/recv halos + ncclAllReduce); SPMV_AMD_BENCH_ALLREDUCE=mailbox swaps the legs
     headline_kind = "mailbox" if os.environ.get("SPMV_AMD_BENCH_ALLREDUCE", "rccl") == "mailbox" else "rccl"
     try:
         leg = measure_leg(c, headline_kind)
     except Unmeasured as e:
         give_up(str(e))
     transport, allreduce, degraded, dt, iterations = leg["transport"], leg["allreduce"], leg["degraded"], leg["dt"], leg["iterations"]
+
+    spmv = None
+    if world == 1 and not multi and not args.no_spmv:
+        try:
+            spmv = spmv_headline(B, n)
+        except Exception as e:  # the CG measurement above stands whatever happens to this leg
+            spmv = {"error": repr(e)}
 
     # template arguments: <kMode = 1 (SpMV + p.Ap partials), kWeLds = W/E neighbours from LDS (the default)>
     rowlds = "stencil5_rowlds_kernel<1, true>" if os.environ.get("SPMV_AMD_ROWLDS_WE_LDS", "1") != "0" else "stencil5_rowlds_kernel<1, false>"
