@@ -17,9 +17,11 @@
 //
 // OPT-IN (SPMV_AMD_CLASS_POOL=1). Measured on the 4e8-row slab (profiles/r04_class_pool_*.txt): in a process whose first large
 // allocation is the slab, 103.35-104.03 ms per solve against the arena's 103.87-104.81 (in-loop SpMV 3.56-3.58 ms = 0.78 of
-// 8 TB/s, flat from launch to launch, against 3.64-3.67); behind bench.py's SpMV leg, whose allocations and frees leave the
-// device's free memory in pieces, a quarter of the 1 GiB chunks fit no class cleanly and the gain shrinks to 0.2 %; with
-// 256 MiB chunks the SpMV falls to 3.90 ms (vectors made of many small physical pieces). Two lessons kept in the code: an
+// 8 TB/s, flat from launch to launch, against 3.64-3.67), through bench.py 104.10-104.59 against 104.79-105.62; behind other
+// large allocations and frees, which leave the device's free memory in pieces, a quarter of the 1 GiB chunks fit no class
+// cleanly and the gain shrinks to 0.2 %; with 256 MiB chunks the SpMV falls to 3.90 ms (vectors made of many small physical
+// pieces). Set-up: 2.2 s for the first slab of a process, 17.8 s for a second one -- the reference's benchmark wrapper creates
+// thirteen (cg_benchmark_with_stats_mgpu_partitioned): hence not the default. Two lessons kept in the code: an
 // address is never mapped twice in a row (a chunk mapped where another had just been unmapped was timed as if it were the
 // earlier one: every chunk "joined" the reference's class), and a pair time that implies more than 7.5 TB/s is no yardstick.
 #pragma once
