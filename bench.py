@@ -21,9 +21,10 @@ configuration of reference docs/PROBLEM_SIZE_SCALING_RESULTS.md:40-47, on N row 
             with ideal accesses on this GPU in this run (csrc/stream_ceiling.hip), so the line carries the
             fraction of the data-sheet peak AND of what the part sustains. traffic: fabric bytes per launch
             from profiles/hbm_traffic.json, only while that file's hash of csrc/spmv_kernels.hip matches.
-  spmv      (N = 1 only) the reference's other headline: stencil5-csr operator, x = 1, 5 warm-ups
-            + 10 timed launches, >2 sigma outliers dropped, median -> "effective" GB/s by both of
-            the reference's byte formulas (spmv_metrics.cu:85-101 and the published 12*nnz+16*rows).
+  spmv      (N = 1 only; runs AFTER the CG leg, so that the solver's slab is the first large allocation of the process)
+            the reference's other headline: stencil5-csr operator on its own staging vectors (the ones run_timed's kernel
+            works on), x = 1, 5 warm-ups + 10 timed launches, >2 sigma outliers dropped, median -> "effective" GB/s by both
+            of the reference's byte formulas (spmv_metrics.cu:85-101 and the published 12*nnz+16*rows).
   scaling_probe  (N = 1 only; a PROJECTION, never part of `value`) the real per-rank slabs of a 2 / 4 / 8-GPU
             run of this problem (rows [r*N/P, (r+1)*N/P), 160 KB halos), edge rank and a two-neighbour rank,
             each solved for the full iteration count on this GPU through the complete RCCL pipeline with the
