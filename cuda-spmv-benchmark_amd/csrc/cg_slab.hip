@@ -28,7 +28,15 @@
 //  * (round 3) the direction update runs on the slab's first / last grid row FIRST and the exchange starts behind that
 //    launch: the RCCL send / recv kernel, which otherwise competes for CUs with a SpMV that fills the chip and ends after
 //    it, is over long before the interior rows are (early halo; SPMV_AMD_EARLY_HALO=0 = the old order, same bits);
-//  * every wait on another rank is bounded (watchdog.hpp): a wedged peer becomes a report and a non-zero exit.
+//  * every wait on another rank is bounded (watchdog.hpp): a wedged peer becomes a report and a non-zero exit;
+//  * (round 4) WHERE the vectors lie is part of the design: on MI355X kernels that walk several vectors in lock step lose 6.5 %
+//    when the vectors lie in different classes of 32 GiB address regions, and only hipMalloc decides the class. r, Ap and the
+//    direction ring are therefore carved out of ONE allocation (vector arena), the coefficient stream is placed by timing three
+//    allocations one region apart (place_coefficients), and a class-aware allocator on HIP's virtual-memory API can build every
+//    vector from physical chunks of a chosen class (class_pool.hpp, opt-in). All of it at creation, outside the timed region;
+//  * (round 4) the direction update of an iteration is enqueued as a lead piece + -- once the status record says the loop goes
+//    on -- the rest (late bulk, slabs of >= 1e8 rows): the converging iteration no longer dispatches 3 M workgroups that only
+//    read a flag.
 //
 // The same loop also serves the reference's SINGLE-GPU entry point, cg_solve_device (cg_solver.cu:436-706): a slab that
 // borrows the caller's SpmvOperator instead of owning a CSR (cg_solve_on_operator, near the end of this file), and it can
