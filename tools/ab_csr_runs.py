@@ -34,6 +34,8 @@ else:
     settings = [(256, 0)] + [(256, g) for g in (1, 4, 8, 16, max(2, round((n + 1100) / (8 * 256))))]
 if rows_only:
     settings = [(r, 1) for r in rows_only]
+if os.environ.get("AB_CSR_SETTINGS"):  # "rows:group,rows:group,..."
+    settings = [(176, 1)] + [tuple(int(v) for v in item.split(":")) for item in os.environ["AB_CSR_SETTINGS"].split(",")]
 settings = list(dict.fromkeys(settings))
 dx, dy = B.DeviceVector(rows, fill=1.0), B.DeviceVector(rows, fill=0.0)
 op = B.Operator(mode)
