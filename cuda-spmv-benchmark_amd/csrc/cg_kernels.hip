@@ -22,14 +22,14 @@
 
 #include <stdlib.h>
 
-#include "mailbox_device.hpp"
+#include "reduce_device.hpp"
+#include "spmv_amd/hip_check.h"
 
 namespace spmv_amd {
 namespace {
 
-constexpr int kBlock = 256;   // the reduction kernels
-constexpr int kStream = 64;   // the streaming kernels: one wavefront per workgroup
-constexpr int kReduceStageBlocks = 256;
+constexpr int kBlock = kReduceBlock;  // the reduction kernels (reduce_device.hpp)
+constexpr int kStream = 64;           // the streaming kernels: one wavefront per workgroup
 
 typedef double d2 __attribute__((ext_vector_type(2)));
 
@@ -137,104 +137,54 @@ __global__ __launch_bounds__(kStream) void dot_partials_kernel(size_t n, const d
     block_partial(acc, partials);
 }
 
-// Single block: thread t sums partials t, t+256, ... then a 256-wide tree in LDS.
-// Stage one of a wide reduction: block b sums the contiguous slice [b*slice, (b+1)*slice) of the
-// partials into stage[b] (thread-strided order, then the 256-wide tree). Fixed shape.
-__global__ __launch_bounds__(kBlock) void reduce_slices_kernel(const double* __restrict__ partials,
-                                                               int count, int slice,
-                                                               double* __restrict__ stage,
-                                                               const int* __restrict__ skip_flag) {
+// ---- reductions (reduce_device.hpp has the shape and the one-launch hand-over) ----
+
+// One launch: `blocks` slice workgroups, the one that finishes last runs the second stage and the tail.
+__global__ __launch_bounds__(kBlock) void reduce_one_launch_kernel(const double* __restrict__ partials, int count, int slice,
+                                                                   const double* extra, int extra_count, ReduceStage stage, ReduceTail tail) {
+    __shared__ double s[kBlock];
+    __shared__ int s_last;
+    if (tail.skip_flag != nullptr && *tail.skip_flag != 0) {
+        reduce_skipped(tail, blockIdx.x == 0);
+        return;
+    }
+    reduce_slice_block(partials, count, slice, (int)blockIdx.x, (int)gridDim.x, reinterpret_cast<const unsigned long long*>(extra), extra_count,
+                       (int)gridDim.x, stage, tail, s, &s_last);
+}
+
+// Two launches (SPMV_AMD_REDUCE_ONE_LAUNCH=0, the form of rounds 2-4): stage one ...
+__global__ __launch_bounds__(kBlock) void reduce_slices_kernel(const double* __restrict__ partials, int count, int slice,
+                                                               double* __restrict__ sums, const int* __restrict__ skip_flag) {
     __shared__ double s[kBlock];
     if (skip_flag != nullptr && *skip_flag != 0) return;
     const int lo = blockIdx.x * slice;
-    const int hi = min(lo + slice, count);
-    double acc = 0.0;
-    for (int i = lo + threadIdx.x; i < hi; i += kBlock) acc += partials[i];
-    s[threadIdx.x] = acc;
-    __syncthreads();
-    for (int stride = kBlock / 2; stride > 0; stride >>= 1) {
-        if ((int)threadIdx.x < stride) s[threadIdx.x] += s[threadIdx.x + stride];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) stage[blockIdx.x] = s[0];
+    block_tree(strided_sum(partials, lo, min(lo + slice, count)), s);
+    if (threadIdx.x == 0) sums[blockIdx.x] = s[0];
 }
 
-// The CG scalar step (see cg_scalars_step_kernel below), callable from the tail of a reduction.
-__device__ __forceinline__ void cg_scalars_step(CgScalars* s, double tol, double* history, int* host_record,
-                                                int sequence, double* alpha_ring, int ring_slots) {
-    if (!s->converged) {
-        s->alpha = s->rr_old / s->pAp;  // the alpha update_r used (same division), kept for the x update
-        const double res = sqrt(s->rr_new);
-        s->residual = res;
-        s->iterations += 1;
-        if (alpha_ring != nullptr) alpha_ring[(s->iterations - 1) % ring_slots] = s->alpha;
-        if (history != nullptr && s->iterations < s->max_history) history[s->iterations] = res;
-        if (res / s->b_norm < tol) {
-            s->converged = 1;
-        } else {
-            s->beta = s->rr_new / s->rr_old;
-            s->rr_old = s->rr_new;
-        }
-    }
-    if (host_record != nullptr) {
-        // status record in host-coherent pinned memory: payload first, then the sequence number with
-        // system-scope release, so a host that sees `sequence` sees this iteration's payload
-        host_record[1] = s->converged;
-        host_record[2] = s->iterations;
-        __hip_atomic_store(&host_record[0], sequence, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-}
-
-// The CG scalar step, optional, in the tail of the last reduction stage (StepArgs.scalars == nullptr: none).
-struct StepArgs {
-    CgScalars* scalars;
-    double tol;
-    double* history;
-    int* host_record;
-    int sequence;
-    double* alpha_ring;
-    int ring_slots;
-};
-
-// Last stage of every dot product. Single block: thread t sums partials t, t+256, ... then a 256-wide tree in LDS.
-//  * mailbox (may be null): the sum is completed ACROSS THE RANKS here, by the block's first wave, through the peer
-//    mailbox (comm.hpp) -- no separate all-reduce launch, no host involvement;
-//  * step.scalars (may be null): the CG scalar step runs on the finished sum in the same launch;
-//  * host_progress (may be null): an int in host-coherent pinned memory that receives progress_value once the local
-//    sum is known -- the solver's watchdog reads it to say how far the GPU got when a rank stops making progress.
-// A launch enqueued past convergence (skip_flag set; identical on all ranks, since it derives from all-reduced
-// values) sums nothing and exchanges nothing, but still publishes a pending status record.
-__global__ __launch_bounds__(kBlock) void reduce_partials_kernel(const double* __restrict__ partials,
-                                                                 int count, double* __restrict__ out,
-                                                                 const int* __restrict__ skip_flag,
-                                                                 int* host_progress, int progress_value,
-                                                                 const PeerMailbox* mailbox, StepArgs step) {
+// ... and stage two over [sums | extra].
+__global__ __launch_bounds__(kBlock) void reduce_final_kernel(const double* __restrict__ sums, int blocks, const double* __restrict__ extra,
+                                                              int extra_count, ReduceTail tail) {
     __shared__ double s[kBlock];
-    if (skip_flag != nullptr && *skip_flag != 0) {
-        if (step.scalars != nullptr && threadIdx.x == 0)
-            cg_scalars_step(step.scalars, step.tol, step.history, step.host_record, step.sequence, step.alpha_ring,
-                            step.ring_slots);
+    if (tail.skip_flag != nullptr && *tail.skip_flag != 0) {
+        reduce_skipped(tail, true);
         return;
     }
-    double acc = 0.0;
-    for (int i = threadIdx.x; i < count; i += kBlock) acc += partials[i];
-    s[threadIdx.x] = acc;
+    reduce_finish(blocks + extra_count, [&](int i) { return i < blocks ? sums[i] : extra[i - blocks]; }, s, tail);
+}
+
+// A short list of partials (count <= 1024): one workgroup does both stages -- the one slice, then [its sum | extra].
+__global__ __launch_bounds__(kBlock) void reduce_single_kernel(const double* __restrict__ partials, int count, const double* __restrict__ extra,
+                                                               int extra_count, ReduceTail tail) {
+    __shared__ double s[kBlock];
+    if (tail.skip_flag != nullptr && *tail.skip_flag != 0) {
+        reduce_skipped(tail, true);
+        return;
+    }
+    block_tree(strided_sum(partials, 0, count), s);
+    const double slice_sum = s[0];
     __syncthreads();
-    for (int stride = kBlock / 2; stride > 0; stride >>= 1) {
-        if ((int)threadIdx.x < stride) s[threadIdx.x] += s[threadIdx.x + stride];
-        __syncthreads();
-    }
-    if (threadIdx.x >= 64) return;  // the first wave finishes
-    double total = s[0];
-    if (threadIdx.x == 0 && host_progress != nullptr)
-        __hip_atomic_store(host_progress, progress_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (mailbox != nullptr) total = mailbox_allreduce_wave(*mailbox, total);
-    if (threadIdx.x == 0) {
-        *out = total;
-        if (step.scalars != nullptr)
-            cg_scalars_step(step.scalars, step.tol, step.history, step.host_record, step.sequence, step.alpha_ring,
-                            step.ring_slots);
-    }
+    reduce_finish(1 + extra_count, [&](int i) { return i == 0 ? slice_sum : extra[i - 1]; }, s, tail);
 }
 
 __global__ void scalar_divide_kernel(const double* num, const double* den, double* out) {
@@ -278,12 +228,11 @@ __global__ __launch_bounds__(kStream) void cg_init_residual_kernel(size_t n, con
     block_partial(acc, partials);
 }
 
-// r -= alpha*Ap with the r.r partials (axpy_kernel(-alpha, Ap, r) + the dot, mgpu :612,627). r_out may be r_in (the
-// reference's in-place update) or a second buffer (SPMV_AMD_R_PINGPONG, an A/B aid): every element is loaded before it
-// is stored, so neither pointer is declared restrict.
+// r -= alpha*Ap with the r.r partials (axpy_kernel(-alpha, Ap, r) + the dot, mgpu :612,627), in place like the reference's
+// (an out-of-place form measured slower in round 4: profiles/r04_ab_r_pingpong.txt).
 __global__ __launch_bounds__(kStream) void cg_update_r_kernel(size_t n, const CgScalars* __restrict__ s,
                                                              const double* __restrict__ Ap,
-                                                             const double* r_in, double* r,
+                                                             double* __restrict__ r,
                                                              double* __restrict__ partials, int reverse) {
     // The vector loads are issued BEFORE the scalars are looked at: a wave does not wait for the scalar loads, the
     // convergence test and an fp64 division ahead of its first memory request (a launch enqueued past convergence
@@ -295,7 +244,7 @@ __global__ __launch_bounds__(kStream) void cg_update_r_kernel(size_t n, const Cg
     d2 av = {0.0, 0.0}, rv = {0.0, 0.0};
     if (i < pairs) {
         av = load_once(Ap, i);
-        rv = load_once(r_in, i);
+        rv = load_once(r, i);
     }
     const int converged = s->converged;
     const double rr_old = s->rr_old, pAp = s->pAp;
@@ -310,7 +259,7 @@ __global__ __launch_bounds__(kStream) void cg_update_r_kernel(size_t n, const Cg
         acc = fma(rv.y, rv.y, acc);
     }
     if ((n & 1) && block == 0 && threadIdx.x == 0) {
-        const double rl = fma(-alpha, Ap[n - 1], r_in[n - 1]);
+        const double rl = fma(-alpha, Ap[n - 1], r[n - 1]);
         r[n - 1] = rl;
         acc = fma(rl, rl, acc);
     }
@@ -498,15 +447,15 @@ void launch_update_p_dev(size_t n, const double* r, const double* d_b, double* p
     hipLaunchKernelGGL(update_p_dev_kernel, dim3(stream_grid(n)), dim3(kStream), 0, stream, n, r, d_b, p);
 }
 
-size_t dot_scratch_doubles(size_t n) { return (size_t)stream_grid(n) + kReduceStageBlocks + 1; }
+size_t dot_scratch_doubles(size_t n) { return (size_t)stream_grid(n) + (size_t)reduce_scratch_doubles(); }
 int cg_partial_count(size_t n) { return (int)stream_grid(n); }
 
 void launch_dot(size_t n, const double* x, const double* y, double* scratch, double* d_result,
                 hipStream_t stream) {
-    // scratch = [one partial per block | kReduceStageBlocks stage slots]
+    // scratch = [one partial per block | the reduction's own scratch]
     const unsigned blocks = stream_grid(n);
     hipLaunchKernelGGL(dot_partials_kernel, dim3(blocks), dim3(kStream), 0, stream, n, x, y, scratch);
-    launch_reduce_partials(scratch, (int)blocks, d_result, nullptr, stream, scratch + blocks);
+    launch_reduce_partials(scratch, (int)blocks, d_result, nullptr, stream, ReduceScratch{scratch + blocks, true});
 }
 
 void launch_scalar_divide(const double* d_num, const double* d_den, double* d_out, hipStream_t stream) {
@@ -526,8 +475,8 @@ void launch_cg_init_residual(size_t n, const double* b, const double* Ap, double
 }
 
 void launch_cg_update_r(size_t n, const CgScalars* s, const double* Ap, double* r, double* partials,
-                        hipStream_t stream, bool reverse, const double* r_in) {
-    hipLaunchKernelGGL(cg_update_r_kernel, dim3(stream_grid(n)), dim3(kStream), 0, stream, n, s, Ap, r_in ? r_in : r, r, partials,
+                        hipStream_t stream, bool reverse) {
+    hipLaunchKernelGGL(cg_update_r_kernel, dim3(stream_grid(n)), dim3(kStream), 0, stream, n, s, Ap, r, partials,
                        reverse ? 1 : 0);
 }
 
@@ -550,48 +499,61 @@ void launch_cg_update_p_ring_two_ranges(size_t count_a, size_t second, size_t co
                        p_out, iteration, 0, fma_form ? 1 : 0, count_a >> 1, (second - count_a) >> 1);
 }
 
-// Two launches. A one-launch form (every block publishes its slice sum with agent-scope atomics, the block that draws
-// the last ticket finishes) was built in round 2 and measured SLOWER on MI355X -- 16.07 vs 15.98 ms per 15-iteration
-// solve at 50 M rows, ~6 us per iteration, although it removes three launches: the agent-scope release / acquire of 256
-// blocks (L2 write-back + invalidate each) costs more than the ~2 us kernel boundaries it saves. Removed in round 3.
-
 namespace {
 const StepArgs kNoStep{nullptr, 0.0, nullptr, nullptr, 0, nullptr, 0};
 
-void reduce_impl(const double* partials, int count, double* d_out, const int* d_skip_flag, hipStream_t stream, double* stage,
-                 int* host_progress, int progress_value, const PeerMailbox* mailbox, const StepArgs& step) {
-    // One block walking tens of thousands of partials is latency-bound (0.3 ms for 200k on MI355X);
-    // with a stage buffer the sum is split over kReduceStageBlocks blocks first. Both shapes are fixed.
-    if (stage != nullptr && count > 4 * kBlock) {
-        const int slice = (count + kReduceStageBlocks - 1) / kReduceStageBlocks;
-        const int blocks = (count + slice - 1) / slice;
-        hipLaunchKernelGGL(reduce_slices_kernel, dim3(blocks), dim3(kBlock), 0, stream, partials, count, slice,
-                           stage, d_skip_flag);
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(kBlock), 0, stream, stage, blocks, d_out,
-                           d_skip_flag, host_progress, progress_value, mailbox, step);
-        return;
+void reduce_impl(const double* partials, int count, const double* extra, int extra_count, double* d_out, const int* d_skip_flag,
+                 hipStream_t stream, const ReduceScratch& scratch, int* host_progress, int progress_value, const PeerMailbox* mailbox,
+                 const StepArgs& step) {
+    const ReduceTail tail{d_out, d_skip_flag, host_progress, progress_value, mailbox, step};
+    // One block walking tens of thousands of partials is latency-bound (0.3 ms for 200k on MI355X): beyond 1024 partials
+    // the sum is split over up to kReduceStageBlocks slice workgroups first. Both shapes are fixed.
+    int slice = 0, blocks = 0;
+    reduce_geometry(count, &slice, &blocks);
+    if (blocks > 1 && scratch.base == nullptr) {
+        fprintf(stderr, "[reduce] %d partials need a scratch buffer\n", count);
+        exit(EXIT_FAILURE);
     }
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(kBlock), 0, stream, partials, count, d_out,
-                       d_skip_flag, host_progress, progress_value, mailbox, step);
+    if (blocks <= 1) {
+        hipLaunchKernelGGL(reduce_single_kernel, dim3(1), dim3(kBlock), 0, stream, partials, count, extra, extra_count, tail);
+    } else if (scratch.one_launch) {
+        hipLaunchKernelGGL(reduce_one_launch_kernel, dim3(blocks), dim3(kBlock), 0, stream, partials, count, slice, extra, extra_count,
+                           reduce_stage_of(scratch.base), tail);
+    } else {
+        hipLaunchKernelGGL(reduce_slices_kernel, dim3(blocks), dim3(kBlock), 0, stream, partials, count, slice, scratch.base, d_skip_flag);
+        hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(kBlock), 0, stream, scratch.base, blocks, extra, extra_count, tail);
+    }
 }
 }  // namespace
 
 void launch_reduce_partials(const double* partials, int count, double* d_out, const int* d_skip_flag,
-                            hipStream_t stream, double* stage, int* host_progress, int progress_value,
-                            const PeerMailbox* mailbox) {
-    reduce_impl(partials, count, d_out, d_skip_flag, stream, stage, host_progress, progress_value, mailbox, kNoStep);
+                            hipStream_t stream, const ReduceScratch& scratch, int* host_progress, int progress_value,
+                            const PeerMailbox* mailbox, const double* extra, int extra_count) {
+    reduce_impl(partials, count, extra, extra_count, d_out, d_skip_flag, stream, scratch, host_progress, progress_value, mailbox, kNoStep);
 }
 
 void launch_reduce_partials_and_step(const double* partials, int count, double* d_out, const int* d_skip_flag,
-                                     hipStream_t stream, double* stage, CgScalars* s, double tol, double* history,
+                                     hipStream_t stream, const ReduceScratch& scratch, CgScalars* s, double tol, double* history,
                                      int* host_record, int sequence, double* alpha_ring, int ring_slots,
                                      const PeerMailbox* mailbox, int* host_progress, int progress_value) {
-    reduce_impl(partials, count, d_out, d_skip_flag, stream, stage, host_progress, progress_value, mailbox,
+    reduce_impl(partials, count, nullptr, 0, d_out, d_skip_flag, stream, scratch, host_progress, progress_value, mailbox,
                 StepArgs{s, tol, history, host_record, sequence, alpha_ring, ring_slots});
 }
 
-// stage values + one slot for the ticket counter, which must be ZERO before the first launch
-int reduce_stage_doubles() { return kReduceStageBlocks + 1; }
+int reduce_scratch_doubles() { return kReduceStageBlocks + kReduceExtraMax + 1; }
+
+double* reduce_scratch_alloc() {
+    // uncached device memory where the runtime offers it: the slice sums and the ticket are handed between workgroups on
+    // different XCDs inside one launch (reduce_device.hpp); plain device memory works through the same sc1 accesses
+    void* p = nullptr;
+    const size_t bytes = (size_t)reduce_scratch_doubles() * sizeof(double);
+    if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached) != hipSuccess) {
+        (void)hipGetLastError();
+        HIP_CHECK(hipMalloc(&p, bytes));
+    }
+    HIP_CHECK(hipMemset(p, 0, bytes));
+    return static_cast<double*>(p);
+}
 
 void launch_cg_scalars_init(CgScalars* s, double* history, hipStream_t stream) {
     hipLaunchKernelGGL(cg_scalars_init_kernel, dim3(1), dim3(1), 0, stream, s, history);

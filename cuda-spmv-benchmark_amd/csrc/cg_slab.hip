@@ -31,9 +31,10 @@
 //  * every wait on another rank is bounded (watchdog.hpp): a wedged peer becomes a report and a non-zero exit;
 //  * (round 4) WHERE the vectors lie is part of the design: on MI355X kernels that walk several vectors in lock step lose 6.5 %
 //    when the vectors lie in different classes of 32 GiB address regions, and only hipMalloc decides the class. r, Ap and the
-//    direction ring are therefore carved out of ONE allocation (vector arena), the coefficient stream is placed by timing three
-//    allocations one region apart (place_coefficients), and a class-aware allocator on HIP's virtual-memory API can build every
-//    vector from physical chunks of a chosen class (class_pool.hpp, opt-in). All of it at creation, outside the timed region;
+//    direction ring are therefore carved out of ONE allocation (vector arena) and the coefficient stream is placed by timing
+//    three allocations one region apart (place_coefficients). All of it at creation, outside the timed region. (The class-aware
+//    allocator on HIP's virtual-memory API of round 4 -- -0.7 % in a clean process, 17.8 s of set-up for a second slab -- was
+//    removed in round 5: profiles/r04_class_pool_*.txt, history up to commit 258dcef.);
 //  * (round 4) the direction update of an iteration is enqueued as a lead piece + -- once the status record says the loop goes
 //    on -- the rest (late bulk, slabs of >= 1e8 rows): the converging iteration no longer dispatches 3 M workgroups that only
 //    read a flag.
@@ -49,9 +50,9 @@
 #include <algorithm>
 #include <chrono>
 #include <mutex>
+#include <thread>
 #include <vector>
 
-#include "class_pool.hpp"
 #include "comm.hpp"
 #include "device_runtime.hpp"
 #include "stencil_geometry.hpp"
@@ -93,15 +94,7 @@ struct SpmvAmdCgSlab {
     // neighbours inside one allocation share a region except where it crosses a boundary. The SpMV's coefficient stream does
     // not take part (40 B/row against 8 B/row: not in lock step; r04_arena_spmv_mix.txt), so the CSR arrays stay where they are.
     double* vec_arena = nullptr;
-    bool x_b_x0_in_arena = false;
-    // Class pool (class_pool.hpp; opt-in, SPMV_AMD_CLASS_POOL=1): on single-rank slabs of >= 1e8 rows the vectors are not
-    // carved out of an arena but built from physical chunks of a chosen class -- Ap and r in one class, the direction buffers
-    // and the coefficient stream outside it: the layout that measured 103.3 ms where the arena gives 104.3
-    // (profiles/r04_loop_regions.txt). Null where it is off, does not apply or could not deliver (then the arena is used).
-    ClassPool* pool = nullptr;
-    int pool_v_class = -1;
-    int pool_plan[3] = {-1, -1, -1};  // class of [Ap | r], of the direction buffers, of the coefficients
-    // place_coefficients: {0, candidates timed, SpMV ms before, SpMV ms kept} or {1, pool chunks created, chunks in vectors, coefficients in the pool}
+    // place_coefficients: {0, candidates timed, SpMV ms before, SpMV ms kept}
     std::vector<double> placement;
     double* p_alloc = nullptr;  // [pad | prev halo | local | next halo]
     double* p = nullptr;        // local part of the CURRENT direction vector, 16-byte aligned
@@ -118,7 +111,12 @@ struct SpmvAmdCgSlab {
     double* d_alpha_ring = nullptr;
     double* partials_spmv = nullptr;  // dot partials of the SpMV launches (interior, head, tail back to back)
     double* partials_blas = nullptr;
-    double* reduce_stage = nullptr;
+    double* reduce_stage = nullptr;  // scratch of this slab's reductions (kernels.hpp, ReduceScratch)
+    // One launch per dot product (round 5, reduce_device.hpp); SPMV_AMD_REDUCE_ONE_LAUNCH=0 / set_option("reduce_one_launch", 0):
+    // the two launches of rounds 2-4, same sums bit for bit (A/B aid). With it the boundary rows of a split SpMV ride in the
+    // launch that reduces the SpMV's partials (launch_stencil5_edges_and_reduce).
+    bool reduce_one_launch = true;
+    ReduceScratch scratch() const { return ReduceScratch{reduce_stage, reduce_one_launch}; }
     CgScalars* d_s = nullptr;
     double* d_hist = nullptr;
     int hist_cap = 0;
@@ -146,6 +144,7 @@ struct SpmvAmdCgSlab {
     // launch plans, made once at creation: the whole slab, the rows that need no halo, the first / last grid row
     Stencil5Plan plan_whole, plan_interior, plan_head, plan_tail;
     int partials_cap = 0;
+    int spmv_split_at = -1;  // set by slab_spmv: partials written by the interior launch of a split SpMV (-1: one launch)
     const char* variant_name = "";
     bool fused_dot = false;
     bool fuse_init_residual = false;  // r0 = b - A x0, p0, r0.r0 written by the first SpMV's launches (row-lds slabs)
@@ -177,10 +176,6 @@ struct SpmvAmdCgSlab {
     // SPMV_AMD_LATE_BULK=0/1 forces. Ring mode only.
     bool late_bulk = false;
     size_t lead_rows = (size_t)1 << 24;
-    // A/B aid (SPMV_AMD_R_PINGPONG=1): the r update writes into a second buffer instead of in place (+8 B/row of HBM).
-    // Measured SLOWER at 4e8 rows: r update 1.446 -> 1.473 ms, solve +0.5 % (profiles/r04_ab_r_pingpong.txt); off.
-    bool r_pingpong = false;
-    double* r2 = nullptr;
     int poll_sequence = 0;
     double last_spmv_ms = 0.0;
     int last_spmv_launches = 0;
@@ -256,16 +251,11 @@ void make_common(SpmvAmdCgSlab* s) {
     const size_t slot_doubles = lead + nl + (size_t)s->halo + 2;
     s->slot_doubles = slot_doubles;
     s->slot_lead = lead;
-    // SPMV_AMD_ARENA_ALL=1 (A/B aid): x0, b and x join the arena behind the direction buffers
-    const char* arena_all_env = getenv("SPMV_AMD_ARENA_ALL");
-    const bool arena_all = arena_all_env != nullptr && arena_all_env[0] == '1';
-    if (!arena_all) {
-        s->x = device_alloc<double>(nl);
-        s->b = device_alloc<double>(nl);
-        s->x0_alloc = device_alloc<double>(slot_doubles);
-        s->x0 = s->x0_alloc + lead;
-        HIP_CHECK(hipMemset(s->x0_alloc, 0, slot_doubles * sizeof(double)));
-    }
+    s->x = device_alloc<double>(nl);
+    s->b = device_alloc<double>(nl);
+    s->x0_alloc = device_alloc<double>(slot_doubles);
+    s->x0 = s->x0_alloc + lead;
+    HIP_CHECK(hipMemset(s->x0_alloc, 0, slot_doubles * sizeof(double)));
     {
         // as many direction buffers as fit comfortably (default 16, SPMV_AMD_P_RING=1 keeps the in-place update)
         int want = kMaxRingSlots;
@@ -286,88 +276,20 @@ void make_common(SpmvAmdCgSlab* s) {
         // operator's free() or spmv_amd_cg_release_workspace()) next to a caller who goes on allocating -- a second operator,
         // say -- so its ring is held to a quarter of what is free now: 16 slots of 3.2 GB at 4e8 rows on an otherwise idle
         // MI355X, fewer on a fuller device, the in-place form when even four do not fit.
-        const size_t fixed = (arena_all ? 6 : 3) * per_slot;  // r, Ap, the first direction buffer (+ x0, b, x)
+        const size_t fixed = 3 * per_slot;  // r, Ap, the first direction buffer
         const size_t budget = s->op != nullptr ? free_b / 4 : (free_b > keep_free + fixed ? free_b - keep_free - fixed : 0);
         while (want > 1 && (size_t)(want - 1) * per_slot > budget) --want;
         if (want < asked && want < 4) want = 1;  // a ring cut short by memory flushes too often to pay
-        const bool try_pool = s->op == nullptr && !s->comm->exchanges_halos() && !arena_all && nl >= 100000000 && want >= 4;
-        if (try_pool) {
-            // Ap and r from one class, the direction buffers from the class with the most chunks, the coefficient stream (later,
-            // place_coefficients) from any class but Ap's. Twice the chunks needed are created and sorted; if the classes that
-            // came up cannot serve the plan, half as many again, twice; then the arena takes over.
-            ClassPool* pool = new ClassPool(slot_doubles * sizeof(double), s->compute);
-            bool ok = pool->usable() && s->A.values != nullptr;
-            const size_t need_ring = ok ? (size_t)want * pool->chunks_for(slot_doubles * sizeof(double)) : 0;
-            const size_t need_pair = ok ? 2 * pool->chunks_for(nl * sizeof(double)) : 0;
-            const size_t need_v = ok ? pool->chunks_for((size_t)s->A.view.nnz_local * sizeof(double)) : 0;
-            const size_t need = need_ring + need_pair + need_v;
-            int ring_cls = -1, pair_cls = -1, v_cls = -1;
-            ok = ok && pool->grow((int)(2 * need + 8)) > 0;
-            for (int attempt = 0; ok && attempt < 3; ++attempt) {
-                ring_cls = pair_cls = v_cls = -1;
-                for (int c = 0; c < pool->classes(); ++c)
-                    if ((size_t)pool->available(c) >= need_ring && (ring_cls < 0 || pool->available(c) > pool->available(ring_cls))) ring_cls = c;
-                for (int c = 0; c < pool->classes(); ++c)
-                    if (c != ring_cls && (size_t)pool->available(c) >= need_pair && (pair_cls < 0 || pool->available(c) < pool->available(pair_cls))) pair_cls = c;
-                for (int c = 0; c < pool->classes(); ++c) {
-                    if (c == pair_cls) continue;
-                    const size_t spare = (size_t)pool->available(c) - (c == ring_cls ? need_ring : 0);
-                    if ((size_t)pool->available(c) >= (c == ring_cls ? need_ring : 0) + need_v &&
-                        (v_cls < 0 || spare > (size_t)pool->available(v_cls) - (v_cls == ring_cls ? need_ring : 0)))
-                        v_cls = c;
-                }
-                if (ring_cls >= 0 && pair_cls >= 0 && v_cls >= 0) break;
-                if (attempt == 2 || pool->grow((int)(need / 2 + 4)) <= 0) ok = false;
-            }
-            ok = ok && ring_cls >= 0 && pair_cls >= 0 && v_cls >= 0;
-            double *ap = nullptr, *r = nullptr;
-            std::vector<double*> slots;
-            if (ok) ok = (ap = pool->vector(nl * sizeof(double), pair_cls)) != nullptr;
-            if (ok) ok = (r = pool->vector(nl * sizeof(double), pair_cls)) != nullptr;
-            for (int k = 0; k < want && ok; ++k) {
-                double* a = pool->vector(slot_doubles * sizeof(double), ring_cls);
-                ok = a != nullptr;
-                if (ok) slots.push_back(a);
-            }
-            if (ok) {
-                s->pool = pool;
-                s->pool_v_class = v_cls;
-                s->pool_plan[0] = pair_cls, s->pool_plan[1] = ring_cls, s->pool_plan[2] = v_cls;
-                s->Ap = ap;
-                s->r = r;
-                s->ring_alloc = slots;
-                s->ring.clear();
-                for (double* a : slots) s->ring.push_back(a + lead);
-            } else {
-                if (getenv("SPMV_AMD_PLACEMENT_VERBOSE")) {
-                    fprintf(stderr, "[cg-slab] class pool gave up (usable %d): %d chunks in %d classes, %d set aside, fast mode %.4f ms; available per class:",
-                            (int)pool->usable(), pool->chunks_created(), pool->classes(), pool->chunks_set_aside(), pool->fast_ms());
-                    for (int c = 0; c < pool->classes(); ++c) fprintf(stderr, " %d", pool->available(c));
-                    fprintf(stderr, "; needed %zu + %zu + %zu\n", need_ring, need_pair, need_v);
-                }
-                delete pool;  // gives back everything it created; the arena below takes over
-            }
-        }
-        if (s->pool == nullptr) {
-            const size_t arena_slots = (size_t)(2 + want) + (arena_all ? 3 : 0);
-            s->vec_arena = device_alloc<double>(arena_slots * pitch);
-            HIP_CHECK(hipMemset(s->vec_arena, 0, arena_slots * pitch * sizeof(double)));
-            if (arena_all) {
-                s->x0_alloc = s->vec_arena + (size_t)(2 + want) * pitch;
-                s->x0 = s->x0_alloc + lead;
-                s->b = s->vec_arena + (size_t)(3 + want) * pitch;
-                s->x = s->vec_arena + (size_t)(4 + want) * pitch;
-                s->x_b_x0_in_arena = true;
-            }
-            s->r = s->vec_arena;
-            s->Ap = s->vec_arena + pitch;
-            s->ring_alloc.clear();
-            s->ring.clear();
-            for (int k = 0; k < want; ++k) {
-                double* a = s->vec_arena + (size_t)(2 + k) * pitch;
-                s->ring_alloc.push_back(a);
-                s->ring.push_back(a + lead);
-            }
+        s->vec_arena = device_alloc<double>((size_t)(2 + want) * pitch);
+        HIP_CHECK(hipMemset(s->vec_arena, 0, (size_t)(2 + want) * pitch * sizeof(double)));
+        s->r = s->vec_arena;
+        s->Ap = s->vec_arena + pitch;
+        s->ring_alloc.clear();
+        s->ring.clear();
+        for (int k = 0; k < want; ++k) {
+            double* a = s->vec_arena + (size_t)(2 + k) * pitch;
+            s->ring_alloc.push_back(a);
+            s->ring.push_back(a + lead);
         }
         s->p_alloc = s->ring_alloc[0];
         s->p = s->ring[0];
@@ -377,23 +299,19 @@ void make_common(SpmvAmdCgSlab* s) {
     }
     s->shape = current_launch_shape();
     // every launch is timed on big slabs; below 100 M rows (multi-GPU slabs: an iteration under 2 ms) every 4th, since
-    // each event pair puts ~7 us of queue barriers next to the SpMV (rocprofv3 timeline, profiles/r02_slab_timeline.txt)
+    // each event pair puts ~7 us of queue barriers next to the SpMV (rocprofv3 timeline, profiles/r02_slab_timeline.txt);
+    // set_option("spmv_event_stride") changes it
     s->spmv_event_stride = nl >= 100000000 ? 1 : 4;
-    if (const char* v = getenv("SPMV_AMD_SPMV_EVENT_STRIDE")) s->spmv_event_stride = atoi(v);
     if (const char* v = getenv("SPMV_AMD_PINGPONG")) s->pingpong = v[0] == '1';
     if (const char* v = getenv("SPMV_AMD_NO_OVERLAP")) s->no_overlap = v[0] == '1';
     if (const char* v = getenv("SPMV_AMD_EARLY_HALO")) s->early_halo = v[0] != '0';
     if (const char* v = getenv("SPMV_AMD_ROCTX")) s->roctx_always = v[0] == '1';
     s->late_bulk = nl >= 100000000;
     if (const char* v = getenv("SPMV_AMD_LATE_BULK")) s->late_bulk = v[0] == '1';
-    if (const char* v = getenv("SPMV_AMD_LEAD_ROWS")) s->lead_rows = (size_t)atoll(v) / 512 * 512;
-    if (s->lead_rows < 512) s->lead_rows = 512;
-    if (const char* v = getenv("SPMV_AMD_R_PINGPONG")) s->r_pingpong = v[0] == '1';
+    if (const char* v = getenv("SPMV_AMD_REDUCE_ONE_LAUNCH")) s->reduce_one_launch = v[0] != '0';
     s->partials_blas = device_alloc<double>(dot_scratch_doubles(nl));
-    s->reduce_stage = device_alloc<double>((size_t)reduce_stage_doubles());
-    // (their last slot was the ticket counter of round 2's one-launch reduction; kept zeroed, unused)
     HIP_CHECK(hipMemset(s->partials_blas, 0, dot_scratch_doubles(nl) * sizeof(double)));
-    HIP_CHECK(hipMemset(s->reduce_stage, 0, (size_t)reduce_stage_doubles() * sizeof(double)));
+    s->reduce_stage = reduce_scratch_alloc();
     s->d_s = device_alloc<CgScalars>(1);
     HIP_CHECK(hipMemset(s->d_s, 0, sizeof(CgScalars)));
     HIP_CHECK(hipHostMalloc((void**)&s->h_poll, sizeof(*s->h_poll), hipHostMallocCoherent | hipHostMallocMapped));
@@ -406,12 +324,6 @@ void make_common(SpmvAmdCgSlab* s) {
         return;
     }
     s->A.verify_stencil(s->compute);
-    // SPMV_AMD_SLAB_PLANES=1 (off by default: measured slower in the loop, spmv_kernels.hip): a verified stencil slab
-    // made of whole grid rows also keeps its coefficients as five planes and runs the row-planes kernel (+40 B/row
-    // of HBM, built once here, outside every timed region like the rest of the set-up).
-    if (s->shape.knobs.slab_planes != 0 && s->A.view.verified_stencil && s->grid >= s->shape.knobs.rowlds_min_grid &&
-        s->row_offset % s->grid == 0 && s->n_local % s->grid == 0)
-        s->A.build_planes(s->compute);
     {
         // dot partials: one slot per launched wave; the launch geometry is a fixed function of the
         // slab and the row range, so size for the larger of the two ways a SpMV is issued
@@ -430,11 +342,10 @@ void make_common(SpmvAmdCgSlab* s) {
         HIP_CHECK(hipMemset(s->partials_spmv, 0, (size_t)s->partials_cap * sizeof(double)));
         s->variant_name = s->plan_whole.name;
         // unverified / unaligned slabs run the row-generic kernel and use the plain dot kernel
-        s->fused_dot = strstr(s->variant_name, "row-generic") == nullptr;
+        s->fused_dot = s->plan_whole.variant != Stencil5Variant::RowGeneric;
         // the initial residual rides in the first SpMV where every launch of the slab is a row-lds launch
-        const auto tiled = [](const Stencil5Plan& p) { return p.variant == Stencil5Variant::RowLds || p.variant == Stencil5Variant::RowPlanes; };
-        const auto rowlds = [&](const Stencil5Plan& p) { return p.last_row <= p.first_row || tiled(p); };
-        s->fuse_init_residual = tiled(s->plan_whole) && rowlds(s->plan_interior) && rowlds(s->plan_head) && rowlds(s->plan_tail);
+        const auto rowlds = [&](const Stencil5Plan& p) { return p.last_row <= p.first_row || p.variant == Stencil5Variant::RowLds; };
+        s->fuse_init_residual = s->plan_whole.variant == Stencil5Variant::RowLds && rowlds(s->plan_interior) && rowlds(s->plan_head) && rowlds(s->plan_tail);
     }
     place_coefficients(s);
     launch_fill(s->b, nl, 1.0, s->compute);   // default right-hand side b = 1
@@ -448,38 +359,16 @@ void make_common(SpmvAmdCgSlab* s) {
 // a solve between 103.3 and 109.4 ms. In the vector arena Ap shares its region with the first direction buffers and not with the
 // later ones, so the one thing left to chance is whether V lies in Ap's class: if it does, every iteration on a later buffer runs
 // in the slow mode (in-loop average 3.75-3.80 ms instead of 3.60-3.65: the process that is 2 % slow). So the coefficients are
-// offered three allocations one region apart, each timed on the SpMV from an early and from a late direction buffer, and the
-// fastest is kept. Set-up work (the reference builds and uploads its CSR before its timed region,
+// offered up to two MORE allocations one region apart, each timed on the SpMV from an early and from a late direction buffer,
+// and the fastest is kept. Set-up work (the reference builds and uploads its CSR before its timed region,
 // cg_solver_mgpu_partitioned.cu:303-413); the values are copied, never changed. Slabs of >= 16 Mi rows that own their matrix.
+// The trial is optional in every respect: a candidate the device cannot provide ends it with the array as it was, and the
+// copy that loses is freed (DeviceCsr::separate_values).
+bool wants_coefficient_placement(size_t n_local) { return n_local >= ((size_t)16 << 20) && placement_candidates() > 1; }
+
 void place_coefficients(SpmvAmdCgSlab* s) {
     const size_t nl = (size_t)s->n_local;
-    if (s->pool != nullptr && s->A.values != nullptr && s->A.view.planes == nullptr) {
-        hipStream_t q = s->compute;
-        const size_t count = (size_t)s->A.view.nnz_local;
-        // with a class pool the coefficients simply go where the direction buffers are: outside the class of Ap and r
-        double* v = s->pool->vector(count * sizeof(double), s->pool_v_class);
-        if (v != nullptr) {
-            HIP_CHECK(hipMemcpyAsync(v, s->A.values, count * sizeof(double), hipMemcpyDeviceToDevice, q));
-            HIP_CHECK(hipStreamSynchronize(q));
-            s->A.borrow_values(v);
-        }
-        const int classes_found = s->pool->classes();
-        s->pool->trim();
-        s->placement = {1.0, (double)s->pool->chunks_created(), (double)s->pool->chunks_in_vectors(), v != nullptr ? 1.0 : 0.0};
-        if (getenv("SPMV_AMD_PLACEMENT_VERBOSE"))
-            fprintf(stderr, "[cg-slab] class pool: %d chunks of %zu MiB created in %d classes, %d in vectors, %d set aside; pair kernel fast mode %.4f ms; "
-                            "Ap and r in class %d, direction buffers in class %d, coefficients %s (class %d)\n",
-                    s->pool->chunks_created(), s->pool->chunk_bytes() >> 20, classes_found, s->pool->chunks_in_vectors(), s->pool->chunks_set_aside(),
-                    s->pool->fast_ms(), s->pool_plan[0], s->pool_plan[1], v != nullptr ? "in the pool" : "left where they were", s->pool_plan[2]);
-        return;
-    }
-    if (s->pool != nullptr) {
-        s->pool->trim();
-        return;
-    }
-    if (s->op != nullptr || nl < ((size_t)16 << 20) || s->ring.size() < 4 || placement_candidates() <= 1 || s->A.values == nullptr ||
-        s->A.view.planes != nullptr)
-        return;
+    if (s->op != nullptr || !wants_coefficient_placement(nl) || s->ring.size() < 4 || s->A.values == nullptr) return;
     hipStream_t q = s->compute;
     const size_t count = (size_t)s->A.view.nnz_local;
     const double* early = s->ring[1];
@@ -507,26 +396,24 @@ void place_coefficients(SpmvAmdCgSlab* s) {
         s->A.view.values = original;
         return 0.5 * total;
     };
-    const double before = cost(original);
     int tried = 0;
+    double before = 0.0, after = 0.0;
     double* best = device_alloc_best_of<double>(count, 0, [&](double* cand) {
-        HIP_CHECK(hipMemcpyAsync(cand, original, count * sizeof(double), hipMemcpyDeviceToDevice, q));
-        return cost(cand);
-    }, &tried);
-    const double after = cost(best);
-    if (after < 0.99 * before) {
-        HIP_CHECK(hipStreamSynchronize(q));
-        s->A.replace_values(best);
-    } else {
-        device_release(best);
+        if (cand != original) HIP_CHECK(hipMemcpyAsync(cand, original, count * sizeof(double), hipMemcpyDeviceToDevice, q));
+        const double ms = cost(cand);
+        if (cand == original) before = ms;
+        return ms;
+    }, &tried, nullptr, original, /*release_first=*/false);
+    after = best == original ? before : cost(best);
+    HIP_CHECK(hipStreamSynchronize(q));
+    if (best != original) {
+        if (after < 0.99 * before) s->A.replace_values(best);  // frees `original` when it is an allocation of its own
+        else device_release(best);
     }
     s->A.view.values = s->A.values;
     for (double* a : s->ring_alloc) HIP_CHECK(hipMemsetAsync(a, 0, s->slot_doubles * sizeof(double), q));
     HIP_CHECK(hipStreamSynchronize(q));
-    s->placement = {0.0, (double)(tried + 1), before, s->A.values == best ? after : before};
-    if (getenv("SPMV_AMD_PLACEMENT_VERBOSE"))
-        fprintf(stderr, "[cg-slab] coefficient placement: %d candidates, SpMV %.4f ms where they were, %.4f ms on the best candidate: %s\n", tried, before,
-                after, s->A.values == best ? "moved" : "kept");
+    s->placement = {0.0, (double)tried, before, s->A.values == original ? before : after};
 }
 
 bool partition_ok(const SpmvAmdComm* comm, int n, int grid, int n_local) {
@@ -550,19 +437,24 @@ int slab_boundary_spmv(SpmvAmdCgSlab* s, const double* in, double* part, const i
     const SlabCsr& A = s->A.view;
     const int lo = s->has_prev ? s->halo : 0;
     const int hi = s->n_local - (s->has_next ? s->halo : 0);
-    LaunchShape forward = s->shape;
-    forward.reverse = false;
     double* at = part ? part + (hi > lo ? s->plan_interior.partials : 0) : nullptr;
     int used = 0;
     if (lo > 0 && hi < s->n_local && lo == A.grid_size && s->n_local - hi == A.grid_size) {
         // a rank with two neighbours: its first and last grid row in one launch
-        used += launch_stencil5_spmv_first_and_last_gridrow(A, s->plan_head, in, s->Ap, 1.0, at, skip, forward, stream, init);
+        used += launch_stencil5_spmv_first_and_last_gridrow(A, s->plan_head, s->plan_tail, in, s->Ap, 1.0, at, skip, stream, init);
     } else {
         if (lo > 0) used += launch_stencil5_spmv(A, s->plan_head, in, s->Ap, 1.0, at, skip, false, stream, init);
         if (hi < s->n_local)
             used += launch_stencil5_spmv(A, s->plan_tail, in, s->Ap, 1.0, at ? at + used : nullptr, skip, false, stream, init);
     }
     return part ? used : 0;
+}
+
+// Sum of the partials the last slab_spmv wrote (`used` of them): a split SpMV's boundary-row partials as extra values.
+void reduce_spmv_partials(SpmvAmdCgSlab* s, int used, double* d_out, const int* skip, int* progress, int progress_value, const PeerMailbox* mailbox) {
+    const int first = s->spmv_split_at >= 0 && s->spmv_split_at < used ? s->spmv_split_at : used;
+    launch_reduce_partials(s->partials_spmv, first, d_out, skip, s->compute, s->scratch(), progress, progress_value, mailbox,
+                           s->partials_spmv + first, used - first);
 }
 
 // SpMV of the slab on p (halos must be current or in flight on the side stream).
@@ -578,6 +470,7 @@ int slab_spmv(SpmvAmdCgSlab* s, bool with_dot, bool overlap, const int* skip,
     const int lo = s->has_prev ? s->halo : 0;
     const int hi = s->n_local - (s->has_next ? s->halo : 0);
     int used = 0;
+    s->spmv_split_at = -1;
     if (s->op != nullptr) {
         // the caller's operator: its fused launch when it has one (this library's stencil5-csr), else the vtable
         if (part != nullptr) {
@@ -589,7 +482,8 @@ int slab_spmv(SpmvAmdCgSlab* s, bool with_dot, bool overlap, const int* skip,
             s->op_failed = true;
         }
         if (s->tl_after_interior) HIP_CHECK(hipEventRecord(s->tl_after_interior, s->compute));
-    } else if (!overlap || hi <= lo || (lo == 0 && hi == s->n_local)) {
+    } else if (hi <= lo || (lo == 0 && hi == s->n_local) || (part == nullptr && !overlap)) {
+        // one launch: a slab without halo rows, or of one or two grid rows, or a plain y = A x with the halos already in place
         if (overlap) HIP_CHECK(hipStreamWaitEvent(s->compute, s->ev_halo_done, 0));
         used = launch_stencil5_spmv(A, s->plan_whole, in, s->Ap, 1.0, part, skip, s->shape.reverse, s->compute, init);
         if (s->tl_after_interior) HIP_CHECK(hipEventRecord(s->tl_after_interior, s->compute));
@@ -597,17 +491,30 @@ int slab_spmv(SpmvAmdCgSlab* s, bool with_dot, bool overlap, const int* skip,
         // rows whose north and south neighbours are local run under the halo exchange; the first / last grid
         // row of the slab once the halo rows have landed. (Launching those two rows behind the exchange on the
         // side stream instead, so that this stream only waits for an event, measured slower: 15.77 vs 15.59 ms
-        // per solve at 50 M rows with the rank as its own neighbour.)
+        // per solve at 50 M rows with the rank as its own neighbour.) A launch that writes dot partials is split in this way
+        // even when the exchange is NOT overlapped (detailed timers, SPMV_AMD_NO_OVERLAP): the sum's shape -- slices of the
+        // interior partials, then [slice sums | boundary rows' partials] -- must not depend on how the halos travelled.
         used = launch_stencil5_spmv(A, s->plan_interior, in, s->Ap, 1.0, part, skip, s->shape.reverse, s->compute, init);
+        s->spmv_split_at = used;  // the boundary rows' partials follow: they enter the sum as extra values (reduce_device.hpp)
         if (s->tl_after_interior) HIP_CHECK(hipEventRecord(s->tl_after_interior, s->compute));
-        HIP_CHECK(hipStreamWaitEvent(s->compute, s->ev_halo_done, 0));
+        // in-loop SpMV: the boundary rows ride in the launch that reduces the partials (one launch instead of three); the
+        // launch timer and the timeline's boundary-row mark then stop behind the interior rows (all but one or two grid rows
+        // of the slab), and the stage "reduce_pAp" holds the halo wait, the boundary rows and the sum
+        const bool fused_tail = with_dot && part != nullptr && init == nullptr && s->reduce_one_launch && lo % A.grid_size == 0 &&
+                                (s->n_local - hi) % A.grid_size == 0 && lo <= A.grid_size && s->n_local - hi <= A.grid_size;
+        if (fused_tail && spmv_done) HIP_CHECK(hipEventRecord(spmv_done, s->compute));
+        if (overlap) HIP_CHECK(hipStreamWaitEvent(s->compute, s->ev_halo_done, 0));
+        if (fused_tail && launch_stencil5_edges_and_reduce(A, s->plan_interior, lo > 0, hi < s->n_local, in, s->Ap, 1.0, part, &s->d_s->pAp, skip,
+                                                           s->scratch(), s->spmv_progress, s->spmv_progress_value, s->reduce_mailbox, s->compute)) {
+            return used;
+        }
+        if (fused_tail) spmv_done = nullptr;  // already recorded
         used += slab_boundary_spmv(s, in, part, skip, s->compute, init);
     }
     if (spmv_done) HIP_CHECK(hipEventRecord(spmv_done, s->compute));
     if (with_dot) {
         if (part)
-            launch_reduce_partials(part, used, &s->d_s->pAp, skip, s->compute, s->reduce_stage, s->spmv_progress,
-                                   s->spmv_progress_value, s->reduce_mailbox);
+            reduce_spmv_partials(s, used, &s->d_s->pAp, skip, s->spmv_progress, s->spmv_progress_value, s->reduce_mailbox);
         else
             launch_dot((size_t)s->n_local, s->p, s->Ap, s->partials_blas, &s->d_s->pAp, s->compute);
     }
@@ -704,6 +611,7 @@ extern "C" SpmvAmdCgSlab* spmv_amd_cg_slab_create(MatrixData* mat, SpmvAmdComm* 
     s->grid = mat->grid_size;
     s->row_offset = row_offset;
     s->n_local = n_local;
+    s->A.separate_values = wants_coefficient_placement((size_t)n_local);  // the copy that loses the placement trial can then be freed
     s->A.upload_slab(csr_mat, row_offset, n_local, mat->grid_size);
     make_common(s);
     return s;
@@ -726,6 +634,7 @@ SpmvAmdCgSlab* create_stencil5_slab(int n, int part_rank, int part_world, SpmvAm
     s->grid = n;
     s->row_offset = row_offset;
     s->n_local = n_local;
+    s->A.separate_values = wants_coefficient_placement((size_t)n_local);
     s->A.generate_stencil5(n, row_offset, n_local, 5.0, -1.0, nullptr);
     HIP_CHECK(hipStreamSynchronize(nullptr));
     make_common(s);
@@ -867,7 +776,7 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
             used = slab_spmv(s, /*with_dot=*/false, /*overlap=*/x0_halo_on_side, nullptr, s->x0, nullptr, &init);
         });
         timed(&stats->time_dot_rs_initial_ms, nullptr, [&] {
-            launch_reduce_partials(s->partials_spmv, used, &s->d_s->rr_new, nullptr, s->compute, s->reduce_stage, nullptr, 0, mailbox);
+            reduce_spmv_partials(s, used, &s->d_s->rr_new, nullptr, nullptr, 0, mailbox);
         });
     } else {
         slab_spmv(s, /*with_dot=*/false, /*overlap=*/x0_halo_on_side, nullptr, s->x0);
@@ -875,7 +784,7 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
             launch_cg_init_residual(nl, s->b, s->Ap, s->r, s->p, s->partials_blas, s->compute);
         });
         timed(&stats->time_dot_rs_initial_ms, nullptr, [&] {
-            launch_reduce_partials(s->partials_blas, cg_partial_count(nl), &s->d_s->rr_new, nullptr, s->compute, s->reduce_stage,
+            launch_reduce_partials(s->partials_blas, cg_partial_count(nl), &s->d_s->rr_new, nullptr, s->compute, s->scratch(),
                                    nullptr, 0, mailbox);
         });
     }
@@ -911,9 +820,7 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
     start_p_halo();
 
     // ---- iterations ----
-    if (s->r_pingpong && s->r2 == nullptr) s->r2 = device_alloc<double>(nl);
-    double* r_cur = s->r;  // the residual of the iteration being enqueued; with r_pingpong the update alternates r / r2
-    double* r_alt = s->r_pingpong ? s->r2 : nullptr;
+    double* const r_cur = s->r;
     // (ring mode only: with the in-place form the x update of the converging iteration rides in that very launch)
     const bool late = s->late_bulk && !detail && slots > 1;
     int enqueued = 0, sampled = 0;
@@ -967,9 +874,7 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
         s->enqueued_stage = "r update";
         trace.push("BLAS_AXPY");
         timed(&stats->time_blas1_ms, &stats->time_axpy_update_r_ms, [&] {
-            double* r_out = r_alt ? r_alt : r_cur;
-            launch_cg_update_r(nl, s->d_s, s->Ap, r_out, s->partials_blas, s->compute, s->pingpong && !backward, r_cur);
-            if (r_alt) r_alt = r_cur, r_cur = r_out;
+            launch_cg_update_r(nl, s->d_s, s->Ap, r_cur, s->partials_blas, s->compute, s->pingpong && !backward);
         });
         trace.pop();
         mark(enqueued, 4);
@@ -980,7 +885,7 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
         trace.push("Dot_Product");
         if (separate) {
             timed(&stats->time_reductions_ms, &stats->time_dot_rs_new_ms, [&] {
-                launch_reduce_partials(s->partials_blas, cg_partial_count(nl), &s->d_s->rr_new, skip, s->compute, s->reduce_stage,
+                launch_reduce_partials(s->partials_blas, cg_partial_count(nl), &s->d_s->rr_new, skip, s->compute, s->scratch(),
                                        &s->h_poll->progress, 4 * s->poll_sequence + 2);
             });
             s->enqueued_stage = "all-reduce of r.r";
@@ -994,7 +899,7 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
             timed(&stats->time_reductions_ms, &stats->time_dot_rs_new_ms, [&] {
                 // single rank, or mailbox: sum (completed across the ranks in place) and scalar step in one launch
                 launch_reduce_partials_and_step(s->partials_blas, cg_partial_count(nl), &s->d_s->rr_new, skip, s->compute,
-                                                s->reduce_stage, s->d_s, config->tolerance, s->d_hist,
+                                                s->scratch(), s->d_s, config->tolerance, s->d_hist,
                                                 &s->h_poll->sequence, s->poll_sequence, s->d_alpha_ring, slots, mailbox,
                                                 &s->h_poll->progress, 4 * s->poll_sequence + 2);
             });
@@ -1257,92 +1162,8 @@ extern "C" void spmv_amd_cg_slab_info(const SpmvAmdCgSlab* s, int* row_offset, i
 
 extern "C" const char* spmv_amd_cg_slab_variant(const SpmvAmdCgSlab* s) { return s->variant_name; }
 
-// Measurement aids (tools/spmv_regions.py): the slab's own SpMV kernel and its r-update kernel on CALLER-CHOSEN addresses, to
-// find out how their rates depend on where the coefficient stream, x and y lie relative to one another (profiles/r04_*).
-//  lab_spmv: `values` (null = the slab's own array; else the slab's coefficients are copied there first), x and y are device
-//  pointers with room for n_local doubles (single-rank slabs: no halo rows); x is filled with 1.0. reps launches, each timed.
-extern "C" int spmv_amd_cg_slab_lab_spmv(SpmvAmdCgSlab* s, double* values, double* x, double* y, int reverse, int reps, float* ms_each) {
-    if (s->op != nullptr || s->has_prev || s->has_next) return -1;
-    const double* own = s->A.view.values;
-    if (values != nullptr && values != own)
-        HIP_CHECK(hipMemcpyAsync(values, own, (size_t)s->A.view.nnz_local * sizeof(double), hipMemcpyDeviceToDevice, s->compute));
-    launch_fill(x, (size_t)s->n_local, 1.0, s->compute);
-    HIP_CHECK(hipMemsetAsync(&s->d_s->converged, 0, sizeof(int), s->compute));
-    if (values != nullptr) s->A.view.values = values;
-    EventTimer t;
-    for (int i = 0; i < reps + 1; ++i) {
-        t.begin(s->compute);
-        (void)launch_stencil5_spmv(s->A.view, s->plan_whole, x, y, 1.0, s->fused_dot ? s->partials_spmv : nullptr, nullptr, reverse != 0, s->compute);
-        t.end(s->compute);
-        const float ms = t.elapsed_ms();
-        if (i > 0) ms_each[i - 1] = ms;
-    }
-    s->A.view.values = own;
-    HIP_CHECK(hipGetLastError());
-    return 0;
-}
-//  lab_pair: the r-update kernel (alpha = 0: b is read and written back unchanged) on (a, b), n doubles each.
-extern "C" int spmv_amd_cg_slab_lab_pair(SpmvAmdCgSlab* s, const double* a, double* b, size_t n, int reps, float* ms_each) {
-    CgScalars sc;
-    memset(&sc, 0, sizeof sc);
-    sc.pAp = 1.0;
-    sc.iterations = 1;
-    HIP_CHECK(hipMemcpy(s->d_s, &sc, sizeof sc, hipMemcpyHostToDevice));
-    if (n > (size_t)s->n_local) return -1;
-    EventTimer t;
-    for (int i = 0; i < reps + 1; ++i) {
-        t.begin(s->compute);
-        launch_cg_update_r(n, s->d_s, a, b, s->partials_blas, s->compute, false);
-        t.end(s->compute);
-        const float ms = t.elapsed_ms();
-        if (i > 0) ms_each[i - 1] = ms;
-    }
-    HIP_CHECK(hipMemset(s->d_s, 0, sizeof(CgScalars)));
-    return 0;
-}
-
-//  lab_rebind: points the slab's loop vectors at caller-owned storage (NULL = leave as it is): Ap, r, the coefficient stream
-//  (the slab's coefficients are copied there) and the local parts of the first `ring_count` direction buffers. The caller keeps
-//  the storage alive until the slab is destroyed; the slab's own allocations stay allocated and unused. Single-rank slabs.
-extern "C" int spmv_amd_cg_slab_lab_rebind(SpmvAmdCgSlab* s, double* Ap, double* r, double* values, double* const* ring, int ring_count) {
-    if (s->op != nullptr || s->has_prev || s->has_next || ring_count > (int)s->ring.size()) return -1;
-    HIP_CHECK(hipDeviceSynchronize());
-    if (Ap) s->Ap = Ap;
-    if (r) s->r = r;
-    if (values) {
-        HIP_CHECK(hipMemcpy(values, s->A.view.values, (size_t)s->A.view.nnz_local * sizeof(double), hipMemcpyDeviceToDevice));
-        s->A.view.values = values;
-    }
-    for (int k = 0; k < ring_count; ++k)
-        if (ring[k]) s->ring[(size_t)k] = ring[k];
-    s->p = s->ring[0];
-    return 0;
-}
-
-//  lab_direction: the direction-update kernel p_out = r + 0 * p_in on caller-chosen vectors, n doubles each.
-extern "C" int spmv_amd_cg_slab_lab_direction(SpmvAmdCgSlab* s, const double* r, const double* p_in, double* p_out, size_t n, int reps,
-                                              float* ms_each) {
-    CgScalars sc;
-    memset(&sc, 0, sizeof sc);
-    sc.pAp = 1.0;
-    sc.iterations = 1;
-    HIP_CHECK(hipMemcpy(s->d_s, &sc, sizeof sc, hipMemcpyHostToDevice));
-    if (n > (size_t)s->n_local) return -1;
-    EventTimer t;
-    for (int i = 0; i < reps + 1; ++i) {
-        t.begin(s->compute);
-        launch_cg_update_p_ring(n, s->d_s, r, p_in, p_out, 1, s->compute, false, s->device_form);
-        t.end(s->compute);
-        const float ms = t.elapsed_ms();
-        if (i > 0) ms_each[i - 1] = ms;
-    }
-    HIP_CHECK(hipMemset(s->d_s, 0, sizeof(CgScalars)));
-    return 0;
-}
-
-// What placement at creation did. {0, candidates timed, SpMV ms (mean of an early and a late direction buffer as x) where the
-// coefficients were, ms where they are now}: the coefficient stream was placed by timing candidates; {1, chunks created, chunks in
-// vectors, 1 if the coefficients are in the pool too}: the vectors were built by the class pool. 0 values = neither ran.
+// What placement at creation did: {0, candidates timed, SpMV ms (mean of an early and a late direction buffer as x) where the
+// coefficients were, ms where they are now}. 0 values = it did not run.
 extern "C" int spmv_amd_cg_slab_placement(const SpmvAmdCgSlab* s, double* out, int cap) {
     const int count = (int)s->placement.size();
     for (int i = 0; i < count && i < cap; ++i) out[i] = s->placement[i];
@@ -1367,7 +1188,9 @@ extern "C" int spmv_amd_cg_slab_set_option(SpmvAmdCgSlab* s, const char* name, l
     else if (strcmp(name, "lead_rows") == 0) s->lead_rows = value < 512 ? 512 : (size_t)value / 512 * 512;
     else if (strcmp(name, "early_halo") == 0) s->early_halo = value != 0;
     else if (strcmp(name, "pingpong") == 0) s->pingpong = value != 0;
-    else if (strcmp(name, "r_pingpong") == 0) s->r_pingpong = value != 0;
+    else if (strcmp(name, "reduce_one_launch") == 0) s->reduce_one_launch = value != 0;
+    else if (strcmp(name, "no_overlap") == 0) s->no_overlap = value != 0;
+    else if (strcmp(name, "spmv_event_stride") == 0) s->spmv_event_stride = (int)value;
     else return -1;
     return 0;
 }
@@ -1397,19 +1220,14 @@ extern "C" void spmv_amd_cg_slab_destroy(SpmvAmdCgSlab* s) {
     (void)hipStreamSynchronize(s->compute);
     (void)hipStreamSynchronize(s->side);
     s->A.release();
-    if (!s->x_b_x0_in_arena) {
-        device_release(s->x);
-        device_release(s->x0_alloc);
-        device_release(s->b);
-    }
+    device_release(s->x);
+    device_release(s->x0_alloc);
+    device_release(s->b);
     s->x0 = nullptr;
     device_release(s->vec_arena);  // r, Ap and the direction buffers
     s->r = s->Ap = s->p_alloc = s->p = nullptr;
-    delete s->pool;  // after s->A.release(): a borrowed coefficient stream is the pool's
-    s->pool = nullptr;
     s->ring_alloc.clear();
     s->ring.clear();
-    device_release(s->r2);
     device_release(s->d_alpha_ring);
     device_release(s->partials_spmv);
     device_release(s->partials_blas);
@@ -1438,6 +1256,12 @@ int g_workspace_device = -1;
 // one solve at a time on the shared workspace (the reference's operators are not re-entrant either, SURVEY 8b "Threading";
 // two host threads calling cg_solve_device are serialised here instead of racing on the buffers)
 std::mutex g_workspace_lock;
+// The thread inside cg_solve_on_operator (it holds the lock for the whole solve, callbacks into a foreign run_device included).
+// A release asked for BY THAT THREAD -- a caller's run_device that calls spmv_amd_cg_release_workspace() or an operator's
+// free() -- cannot take the lock again and must not pull the vectors from under the running loop: it is noted and carried
+// out when the solve returns.
+std::thread::id g_workspace_owner;
+bool g_release_pending = false;
 void release_cg_workspace_locked() {
     if (g_workspace == nullptr) return;
     spmv_amd_cg_slab_destroy(g_workspace);
@@ -1448,6 +1272,10 @@ void release_cg_workspace_locked() {
 namespace spmv_amd {
 
 void release_cg_workspace() {
+    if (g_workspace_owner == std::this_thread::get_id()) {  // only ever equal on the thread that set it: no lock needed to compare
+        g_release_pending = true;
+        return;
+    }
     std::lock_guard<std::mutex> guard(g_workspace_lock);
     release_cg_workspace_locked();
 }
@@ -1462,6 +1290,14 @@ void release_cg_workspace() {
 int cg_solve_on_operator(SpmvOperator* op, int n, const double* b, double* x, const CGConfig& config, CGStats* stats,
                          std::vector<double>* history) {
     std::lock_guard<std::mutex> guard(g_workspace_lock);
+    struct Owner {  // marks this thread as the one inside the solve; a release it asked for meanwhile is carried out on the way out
+        Owner() { g_workspace_owner = std::this_thread::get_id(), g_release_pending = false; }
+        ~Owner() {
+            g_workspace_owner = std::thread::id();
+            if (g_release_pending) release_cg_workspace_locked();
+            g_release_pending = false;
+        }
+    } owner;
     int device = 0;
     HIP_CHECK(hipGetDevice(&device));
     if (g_workspace != nullptr && (g_workspace->n != n || g_workspace_device != device)) release_cg_workspace_locked();

@@ -21,85 +21,40 @@ int placement_candidates() {
     const int k = env_int("SPMV_AMD_PLACEMENT_CANDIDATES", 3);
     return k < 1 ? 1 : (k > 16 ? 16 : k);
 }
-
-namespace {
-// The SPMV_AMD_* measurement switches of the launch paths (tools/README.md), out-of-range values replaced by the
-// defaults. Called when an operator is initialised or a solver slab is created, never per launch.
-Tunables read_tunables() {
-    Tunables k;
-    k.rowlds_min_grid = env_int("SPMV_AMD_ROWLDS_MIN_GRID", k.rowlds_min_grid);
-    k.rowlds_group = env_int("SPMV_AMD_ROWLDS_GROUP", k.rowlds_group);
-    if (k.rowlds_group < 0 || k.rowlds_group > 64) k.rowlds_group = 0;
-    k.rowlds_we_lds = env_int("SPMV_AMD_ROWLDS_WE_LDS", k.rowlds_we_lds);
-    k.rowlds_rows = env_int("SPMV_AMD_ROWLDS_ROWS", k.rowlds_rows);
-    if (k.rowlds_rows != 2 && k.rowlds_rows != 4) k.rowlds_rows = 1;
-    k.slab_planes = env_int("SPMV_AMD_SLAB_PLANES", k.slab_planes);
-    k.direct_rows = env_int("SPMV_AMD_DIRECT_ROWS", k.direct_rows);
-    if (k.direct_rows != 2 && k.direct_rows != 4) k.direct_rows = 1;
-    k.wavetile_oneshot = env_int("SPMV_AMD_WAVETILE_ONESHOT", k.wavetile_oneshot);
-    k.march_blocks_per_cu = env_int("SPMV_AMD_MARCH_BLOCKS_PER_CU", k.march_blocks_per_cu);
-    k.march_max_rows = env_int("SPMV_AMD_MARCH_MAX_ROWS", k.march_max_rows);
-    k.march_rows_per_task = env_int("SPMV_AMD_ROWS_PER_TASK", 0);
-    k.csr_stream_shape = env_int("SPMV_AMD_CSR_STREAM_SHAPE", k.csr_stream_shape);
-    k.csr_stream_rows = env_int("SPMV_AMD_CSR_STREAM_ROWS", 0);
-    k.ell_shape = env_int("SPMV_AMD_ELL_SHAPE", k.ell_shape);
-    k.xcd_group = env_int("SPMV_AMD_XCD_GROUP", k.xcd_group);
-    if (k.xcd_group < 0 || k.xcd_group > 512) k.xcd_group = 0;
-    return k;
-}
-}  // namespace
+int placement_fail_after() { return env_int("SPMV_AMD_PLACEMENT_FAIL_AFTER", 0); }
 
 LaunchShape current_launch_shape() {
-    static int cached_device = -1;
-    static LaunchShape cached;
-    int dev = 0;
-    HIP_CHECK(hipGetDevice(&dev));
-    if (dev != cached_device) {
-        hipDeviceProp_t prop;
-        HIP_CHECK(hipGetDeviceProperties(&prop, dev));
-        cached.compute_units = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-        // 5248 B of LDS per wave x 4 waves per block: seven blocks (28 waves) fit one CU's 160 KiB
-        cached.blocks_per_cu = 7;
-        cached_device = dev;
-    }
-    cached.knobs = read_tunables();
-    cached.reverse = false;
-    return cached;
+    // the launch switches (kernels.hpp, Tunables), out-of-range values replaced by the defaults: read when an operator is
+    // initialised or a solver slab is created, never per launch
+    LaunchShape shape;
+    shape.knobs.rowlds_min_grid = env_int("SPMV_AMD_ROWLDS_MIN_GRID", shape.knobs.rowlds_min_grid);
+    shape.knobs.rowlds_group = env_int("SPMV_AMD_ROWLDS_GROUP", shape.knobs.rowlds_group);
+    if (shape.knobs.rowlds_group < 0 || shape.knobs.rowlds_group > 64) shape.knobs.rowlds_group = 0;
+    return shape;
 }
 
+// values | col_idx | row_ptr in ONE allocation, values first: the CSR kernels read values[e] and col_idx[e] in lock step,
+// and lock-step streams in different 32 GiB classes of the address space run ~6 % slower (device_runtime.hpp).
+// separate_values (solver slabs whose coefficient stream may be re-placed, cg_slab.hip): `values` is an allocation of its
+// own, so that the copy that loses a placement trial can be freed (16 GB at 4e8 rows).
 void DeviceCsr::allocate(size_t n_local, size_t local_nnz) {
-    const char* v = getenv("SPMV_AMD_CSR_ARENA");
-    if (v != nullptr && v[0] == '0') {
-        row_ptr = device_alloc<int>(n_local + 1);
-        col_idx = device_alloc<int>(local_nnz);
-        values = device_alloc<double>(local_nnz);
-        return;
-    }
     constexpr size_t k4KiB = 4096;
     auto up = [](size_t bytes) { return (bytes + k4KiB - 1) / k4KiB * k4KiB; };
-    const size_t v_bytes = up((local_nnz ? local_nnz : 1) * sizeof(double)), c_bytes = up((local_nnz ? local_nnz : 1) * sizeof(int)),
-                 r_bytes = up((n_local + 1) * sizeof(int));
+    const size_t v_bytes = separate_values ? 0 : up((local_nnz ? local_nnz : 1) * sizeof(double)),
+                 c_bytes = up((local_nnz ? local_nnz : 1) * sizeof(int)), r_bytes = up((n_local + 1) * sizeof(int));
+    if (separate_values) values_own = device_alloc<double>(local_nnz);
     block = device_alloc<char>(v_bytes + c_bytes + r_bytes);
-    values = reinterpret_cast<double*>(block);
-    col_idx = reinterpret_cast<int*>(static_cast<char*>(block) + v_bytes);
-    row_ptr = reinterpret_cast<int*>(static_cast<char*>(block) + v_bytes + c_bytes);
+    values = separate_values ? values_own : reinterpret_cast<double*>(block);
+    col_idx = reinterpret_cast<int*>(block + v_bytes);
+    row_ptr = reinterpret_cast<int*>(block + v_bytes + c_bytes);
 }
 
+// `values` := fresh (same contents, the caller copied them); the previous array is freed if it was an allocation of its own.
 void DeviceCsr::replace_values(double* fresh) {
-    if (values_moved != nullptr) device_release(values_moved);
-    else if (block == nullptr && !values_borrowed) device_release(values);
-    values_borrowed = false;
-    values_moved = fresh;
+    device_release(values_own);
+    values_own = fresh;
     values = fresh;
     view.values = fresh;
-}
-
-void DeviceCsr::borrow_values(double* theirs) {
-    if (values_moved != nullptr) device_release(values_moved);
-    else if (block == nullptr && !values_borrowed) device_release(values);
-    values_borrowed = true;
-    values = theirs;
-    view.values = theirs;
 }
 
 void DeviceCsr::upload_slab(const CSRMatrix& host, int row_offset, int n_local, int grid_size) {
@@ -174,32 +129,12 @@ void DeviceCsr::verify_stencil(hipStream_t stream) {
     view.verified_stencil = (h_flag == 0);
 }
 
-void DeviceCsr::build_planes(hipStream_t stream) {
-    if (!view.verified_stencil || view.grid_size < 2 || view.n_local <= 0) return;
-    device_release(planes);
-    planes = device_alloc<double>(5 * (size_t)view.n_local);
-    launch_build_stencil5_planes(view, planes, stream);
-    HIP_CHECK(hipStreamSynchronize(stream));
-    HIP_CHECK(hipGetLastError());
-    view.planes = planes;
-}
-
 void DeviceCsr::release() {
-    device_release(planes);
-    if (block != nullptr) {
-        char* b = static_cast<char*>(block);
-        device_release(b);
-        block = nullptr;
-        row_ptr = nullptr;
-        col_idx = nullptr;
-    } else {
-        device_release(row_ptr);
-        device_release(col_idx);
-        if (values_moved == nullptr && !values_borrowed) device_release(values);
-    }
-    if (values_moved != nullptr) device_release(values_moved);
+    device_release(block);
+    device_release(values_own);
+    row_ptr = nullptr;
+    col_idx = nullptr;
     values = nullptr;
-    values_borrowed = false;
     view = SlabCsr{};
 }
 

@@ -10,8 +10,20 @@
 
 namespace spmv_amd {
 
-// Launch geometry for the persistent SpMV kernel on the current device.
+// The launch switches of the environment (kernels.hpp, Tunables), read now.
 LaunchShape current_launch_shape();
+
+// hipMalloc that reports instead of exiting: nullptr when the device cannot provide `count` T (optional buffers only --
+// placement candidates, spacers; everything a solve needs goes through device_alloc and fails loudly).
+template <class T>
+inline T* device_try_alloc(size_t count) {
+    void* p = nullptr;
+    if (hipMalloc(&p, (count ? count : 1) * sizeof(T)) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return static_cast<T*>(p);
+}
 
 template <class T>
 inline T* device_alloc(size_t count) {
@@ -55,45 +67,52 @@ inline void download(T* h_dst, const T* d_src, size_t count) {
 // choice is made -- so that three candidates see all three classes.
 // SPMV_AMD_PLACEMENT_CANDIDATES=<k> (default 3; 1 = take the first allocation as it comes).
 int placement_candidates();
-// Allocates up to placement_candidates() buffers of `count` T, one region apart, evaluates cost_ms(candidate) on each, keeps the
-// cheapest and frees the others. Buffers below min_count are not worth a trial. *tried / *gain (optional): how many candidates
-// were timed, and the cost of the first over the cost of the one kept.
+// Placement trial for ONE buffer of `count` T. `first` is the buffer as it is now (may be null: it is then allocated here,
+// fatally on failure, like any buffer a solve cannot do without). Up to placement_candidates() - 1 FURTHER buffers, one
+// region apart, are tried with plain hipMalloc: a candidate (or spacer) the device cannot provide ends the trial -- an
+// optional copy must never abort a solve that fits without it -- and so does free memory below
+// bytes + spacer + 4 GiB. cost_ms(candidate) is evaluated on each; the cheapest is returned, the others are freed -- `first`
+// too if it lost and release_first is set. *tried / *gain (optional): candidates timed, cost of the first over the one kept.
+// SPMV_AMD_PLACEMENT_FAIL_AFTER=<k> (test hook): the k-th further candidate "does not fit".
+int placement_fail_after();
 template <class T, class Cost>
-inline T* device_alloc_best_of(size_t count, size_t min_count, Cost&& cost_ms, int* tried = nullptr, double* gain = nullptr) {
+inline T* device_alloc_best_of(size_t count, size_t min_count, Cost&& cost_ms, int* tried = nullptr, double* gain = nullptr,
+                               T* first = nullptr, bool release_first = true) {
     const int want = count >= min_count ? placement_candidates() : 1;
     if (tried) *tried = 1;
     if (gain) *gain = 1.0;
-    if (want <= 1) return device_alloc<T>(count);
+    if (first == nullptr) first = device_alloc<T>(count);
+    if (want <= 1) return first;
     constexpr size_t kRegion = (size_t)32 << 30;
     const size_t bytes = count * sizeof(T);
     const size_t spacer_bytes = bytes < kRegion ? kRegion - bytes : 0;
+    const int fail_after = placement_fail_after();
     T* cand[16];
     void* spacer[16];
     double cost[16];
-    int n = 0, spacers = 0;
+    int n = 1, spacers = 0;
+    cand[0] = first;
+    cost[0] = cost_ms(first);
     for (; n < want && n < 16; ++n) {
-        if (n > 0) {
-            size_t free_b = 0, total_b = 0;
-            HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
-            if (free_b < spacer_bytes + bytes + ((size_t)4 << 30)) break;
-            if (spacer_bytes > 0) {
-                void* sp = nullptr;
-                if (hipMalloc(&sp, spacer_bytes) != hipSuccess) {
-                    (void)hipGetLastError();
-                    break;
-                }
-                spacer[spacers++] = sp;
-            }
+        size_t free_b = 0, total_b = 0;
+        HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+        if (free_b < spacer_bytes + bytes + ((size_t)4 << 30)) break;
+        if (spacer_bytes > 0) {
+            void* sp = device_try_alloc<char>(spacer_bytes);
+            if (sp == nullptr) break;
+            spacer[spacers++] = sp;
         }
-        cand[n] = device_alloc<T>(count);
-        cost[n] = cost_ms(cand[n]);
+        T* c = (fail_after > 0 && n >= fail_after) ? nullptr : device_try_alloc<T>(count);
+        if (c == nullptr) break;  // another rank on this device took the memory in between, or the test hook says so
+        cand[n] = c;
+        cost[n] = cost_ms(c);
     }
     int best = 0;
     for (int k = 1; k < n; ++k)
         if (cost[k] < cost[best]) best = k;
     for (int k = 0; k < spacers; ++k) HIP_CHECK(hipFree(spacer[k]));
     for (int k = 0; k < n; ++k)
-        if (k != best) device_release(cand[k]);
+        if (k != best && (k > 0 || release_first)) device_release(cand[k]);
     if (tried) *tried = n;
     if (gain) *gain = cost[best] > 0.0 ? cost[0] / cost[best] : 1.0;
     return cand[best];
@@ -137,23 +156,14 @@ void release_cg_workspace();
 
 // Device-resident CSR of one operator or one slab (owning).
 struct DeviceCsr {
-    // The three arrays are carved out of ONE allocation, values first: the CSR kernels read values[e] and col_idx[e] in lock
-    // step, and lock-step streams in different 32 GiB classes of the address space run ~6 % slower (see device_alloc_best_of
-    // below); neighbours in one allocation share a region except where it crosses a boundary. SPMV_AMD_CSR_ARENA=0: three
-    // allocations, as before round 4.
-    void* block = nullptr;          // owner of row_ptr / col_idx / values when non-null
-    double* values_moved = nullptr;  // owner of `values` after replace_values()
+    char* block = nullptr;         // ONE allocation: [values |] col_idx | row_ptr (allocate())
+    bool separate_values = false;  // set before the arrays are made: `values` outside the block (replace_values can then free the loser)
+    double* values_own = nullptr;  // `values` when it is an allocation of its own (separate_values, or after replace_values)
     int* row_ptr = nullptr;
     int* col_idx = nullptr;
     double* values = nullptr;
-    // allocates the three arrays for n_local rows and local_nnz entries (one block, or three allocations)
     void allocate(size_t n_local, size_t local_nnz);
-    // `values` := fresh (same contents, the caller copied them); the array inside the block stays allocated and unused
     void replace_values(double* fresh);
-    // `values` := memory somebody else owns and keeps alive (a ClassPool vector), same contents
-    void borrow_values(double* theirs);
-    bool values_borrowed = false;
-    double* planes = nullptr;  // optional plane copy of a verified stencil's coefficients (SlabCsr::planes)
     SlabCsr view;  // non-owning descriptor handed to the kernels
 
     // Uploads rows [row_offset, row_offset + n_local) of a host CSR, rebasing row_ptr to 0.
@@ -163,8 +173,6 @@ struct DeviceCsr {
                            hipStream_t stream);
     // Runs the structure check and records the verdict in view.verified_stencil.
     void verify_stencil(hipStream_t stream);
-    // After a successful verify_stencil: builds the five coefficient planes and publishes them in view.planes.
-    void build_planes(hipStream_t stream);
     void release();
 };
 

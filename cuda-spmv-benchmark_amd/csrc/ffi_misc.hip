@@ -128,8 +128,7 @@ extern "C" int spmv_amd_cg_fused_step(int which, size_t n, const double* scalars
     upload(d_s, &h, 1);
     double* partials = device_alloc<double>(dot_scratch_doubles(n));
     HIP_CHECK(hipMemset(partials, 0, dot_scratch_doubles(n) * sizeof(double)));
-    double* stage = device_alloc<double>((size_t)reduce_stage_doubles());
-    HIP_CHECK(hipMemset(stage, 0, (size_t)reduce_stage_doubles() * sizeof(double)));
+    double* stage = reduce_scratch_alloc();
     double* d_out = device_alloc<double>(1);
     bool has_dot = false;
     if (which == 0) {  // d_a = Ap, d_b = r (in place)
@@ -144,7 +143,7 @@ extern "C" int spmv_amd_cg_fused_step(int which, size_t n, const double* scalars
         return 1;
     }
     if (has_dot) {
-        launch_reduce_partials(partials, cg_partial_count(n), d_out, nullptr, nullptr, stage);
+        launch_reduce_partials(partials, cg_partial_count(n), d_out, nullptr, nullptr, ReduceScratch{stage, true});
         HIP_CHECK(hipDeviceSynchronize());
         if (dot_out) download(dot_out, d_out, 1);
     }

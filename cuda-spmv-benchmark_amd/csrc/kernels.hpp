@@ -23,37 +23,17 @@ struct SlabCsr {
     int n_global = 0;                // rows of the whole matrix
     int grid_size = -1;              // n of the n x n stencil, <= 0 if not a stencil
     bool verified_stencil = false;   // structure checked against the complete 5-point pattern
-    // Optional second copy of a verified stencil's coefficients as five planes [N | W | C | E | S], plane k of local
-    // row r at planes[k * n_local + r], absent entries 0 (solver slabs only, launch_build_stencil5_planes): every
-    // coefficient load becomes a 4 KiB-aligned, fully coalesced stream with no transpose behind it.
-    const double* planes = nullptr;
     // x is addressed as x[col - row_offset]; indices in [-halo_before, n_local + halo_after)
     // are readable, anything else contributes 0 (reference halo kernel semantics).
     int halo_before = 0;
     int halo_after = 0;
 };
 
-// Measurement switches (SPMV_AMD_* environment variables, tools/README.md). They are read ONCE, when an operator
-// is initialised or a solver slab is created (current_launch_shape()), into this struct; nothing on a launch path
-// calls getenv. Defaults are the measured optima quoted next to the kernels.
+// Launch switches (SPMV_AMD_* environment variables, tools/README.md). They are read ONCE, when an operator is initialised or
+// a solver slab is created (current_launch_shape()), into this struct; nothing on a launch path calls getenv.
 struct Tunables {
-    int rowlds_min_grid = 512;    // smallest grid that takes row-lds automatically
-    int rowlds_group = 0;         // consecutive row-lds tiles per XCD; 0 = derived from the grid (xcd_run_group())
-    int slab_planes = 0;          // 1: solver slabs keep a plane copy of a verified stencil's coefficients and run
-                                  // row-planes (measured slower in the CG loop than row-lds, see spmv_kernels.hip; off)
-    int rowlds_rows = 1;          // row-lds march: grid rows a wave walks with x rotating in registers (1 = the one-row kernel, 2, 4)
-    int rowlds_we_lds = 1;        // row-lds: W / E neighbours from an LDS copy of the tile's x values (0 = two more global
-                                  // loads per row): 20 000^2 3.67-3.71 -> 3.65-3.68 ms, 10 000^2 0.950 -> 0.925 ms, same bits
-    int direct_rows = 1;          // grid rows per thread in row-direct (1, 2, 4)
-    int wavetile_oneshot = 1;     // 0 = persistent XCD-banded walk
-    int march_blocks_per_cu = 20;
-    int march_max_rows = 16;
-    int march_rows_per_task = 0;  // 0 = derived
-    int csr_stream_shape = 0;     // 0: 256 x 4, 1: 64 x 6, 2: 64 x 8, 3: 128 x 5
-    int csr_stream_rows = 0;      // 0 = derived from the mean row length
-    int ell_shape = 2;            // bit 0: one-wave workgroups, bit 1: nontemporal planes / y
-    int xcd_group = 0;            // SPMV_AMD_XCD_GROUP: consecutive logical blocks per XCD in the CSR-stream / ELLPACK kernels;
-                                  // 0 = per-kernel default (ELLPACK: derived from the grid or 8, CSR-stream 1 = dispatch order)
+    int rowlds_min_grid = 512;    // SPMV_AMD_ROWLDS_MIN_GRID: smallest grid that takes row-lds automatically (tests force it down)
+    int rowlds_group = 0;         // SPMV_AMD_ROWLDS_GROUP: consecutive row-lds tiles per XCD; 0 = derived from the grid (xcd_run_group())
 };
 
 // How many consecutive logical blocks (each `block_columns` grid columns wide) one XCD takes of every run of
@@ -68,8 +48,6 @@ inline int xcd_run_group(int n, int block_columns, int small_grid_group) {
 }
 
 struct LaunchShape {
-    int compute_units = 256;
-    int blocks_per_cu = 7;
     Tunables knobs;
     // walk the tiles from the last to the first (row-lds kernel): results are identical, only the order in
     // which addresses are touched changes (sweep direction alternation of the CG loop, cg_slab.hip)
@@ -86,30 +64,21 @@ void launch_generate_stencil5_csr(int n, int row_offset, int n_local, long long 
 // from the complete 5-point pattern of an n x n grid.
 void launch_verify_stencil5_csr(const SlabCsr& m, int* d_mismatch, hipStream_t stream);
 
-// Fills planes[5 * n_local] from the CSR values of a VERIFIED stencil slab (see SlabCsr::planes).
-void launch_build_stencil5_planes(const SlabCsr& m, double* planes, hipStream_t stream);
-
 // ---- STENCIL5 SpMV ----
 // y[r] = alpha * (A x)[r]. d_dot_partials, if non-null, receives one partial of
 // sum_r x[r]*y_unscaled[r] per launched wave (count: stencil5_partials_needed()).
-enum class Stencil5Variant { Auto, RowDirect, ColumnMarch, WaveTile, RowGeneric, RowLds, RowPlanes };
+enum class Stencil5Variant { Auto, RowDirect, RowGeneric, RowLds };
 // Everything about one STENCIL5 launch over local rows [first_row, last_row) that does not depend on the vectors:
 // which kernel, its grid, how many dot partials it writes. Computed once per (slab, row range) -- by an operator's
 // init, by a solver slab's creation -- and reused for every launch.
 struct Stencil5Plan {
     Stencil5Variant variant = Stencil5Variant::RowGeneric;
     int first_row = 0, last_row = 0;
-    // column-march: the range splits into up to two global-boundary grid rows (row kernel) and
-    // the grid rows [gi_lo, gi_hi) in between
-    bool head_rows = false, tail_rows = false;
-    int gi_lo = 0, gi_hi = 0, rows_per_task = 0, strips = 0, march_blocks = 0;
-    int row_blocks = 0;  // blocks of one boundary-grid-row launch
-    int tile_blocks = 0;
-    bool oneshot = true;
-    bool we_from_lds = false;  // row-lds: W / E neighbours from an LDS copy of the tile's x values
-    int lds_march_rows = 1;    // row-lds: > 1 = the march kernel, a wave walks this many consecutive grid rows
-    int partials = 0;        // dot-partial slots one launch writes
-    const char* name = "";   // "stencil5/row-lds", ...
+    int gi_lo = 0, gi_hi = 0;  // row-direct / row-lds: the local grid rows of the range
+    int row_blocks = 0;        // row-generic: workgroups of the launch; row-direct / row-lds: workgroups per grid row
+    int xcd_run = 0;           // row-lds: consecutive tiles one XCD takes of every run of 8 * xcd_run
+    int partials = 0;          // dot-partial slots one launch writes (a fixed function of the slab and the range)
+    const char* name = "";     // "stencil5/row-lds", ...
 };
 Stencil5Plan plan_stencil5(const SlabCsr& m, int first_row, int last_row, Stencil5Variant variant,
                            const LaunchShape& shape);
@@ -125,12 +94,6 @@ struct ResidualOut {
 int launch_stencil5_spmv(const SlabCsr& m, const Stencil5Plan& plan, const double* x, double* y, double alpha,
                          double* d_dot_partials, const int* d_skip_flag, bool reverse, hipStream_t stream,
                          const ResidualOut* init = nullptr);
-// Partial-sum slots a launch over [first_row, last_row) writes (a fixed function of the slab, the
-// range and the launch shape, so reductions keep one shape for the life of a solver).
-int stencil5_partials_needed(const SlabCsr& m, int first_row, int last_row, Stencil5Variant variant,
-                             const LaunchShape& shape);
-const char* stencil5_variant_name(const SlabCsr& m, int first_row, int last_row,
-                                  Stencil5Variant variant, const LaunchShape& shape);
 // first_row/last_row restrict the launch to local rows [first_row, last_row); used to split
 // interior rows from halo-dependent rows. Returns the number of dot partials written (0 when
 // d_dot_partials is null).
@@ -141,34 +104,33 @@ int launch_stencil5_spmv(const SlabCsr& m, const double* x, double* y, double al
 
 // The first and the last grid row of a slab made of whole grid rows (the rows that wait for the halos), in one
 // launch where the row-lds kernel applies, in two otherwise. Partial slots: first grid row's, then last grid row's.
-// `head` = plan_stencil5(m, 0, grid_size, ...), the plan of the slab's first grid row.
-int launch_stencil5_spmv_first_and_last_gridrow(const SlabCsr& m, const Stencil5Plan& head, const double* x, double* y,
-                                                double alpha, double* d_dot_partials, const int* d_skip_flag,
-                                                const LaunchShape& shape, hipStream_t stream,
-                                                const ResidualOut* init = nullptr);
+// `head` / `tail` = the plans of the slab's first / last grid row.
+int launch_stencil5_spmv_first_and_last_gridrow(const SlabCsr& m, const Stencil5Plan& head, const Stencil5Plan& tail, const double* x,
+                                                double* y, double alpha, double* d_dot_partials, const int* d_skip_flag,
+                                                hipStream_t stream, const ResidualOut* init = nullptr);
 
 // ---- CSR SpMV ----
-enum class CsrVariant { Auto, Stream, Adaptive, RowScalar, Wavefront, SubWave4, SubWave8, SubWave16, SubWave32 };
+enum class CsrVariant { Auto, Stream, Adaptive, RowScalar, Wavefront };
 CsrVariant csr_auto_variant(const SlabCsr& m);
 // d_dot_partials (may be null; stream / adaptive variants of SQUARE matrices only): one partial of x . (A x) per logical block,
 // csr_fused_dot_partials() of them (0 = the variant has no fused form).
 void launch_csr_spmv(const SlabCsr& m, const double* x, double* y, double alpha,
-                     CsrVariant variant, const Tunables& knobs, hipStream_t stream, double* d_dot_partials = nullptr);
-int csr_fused_dot_partials(const SlabCsr& m, CsrVariant variant, const Tunables& knobs);
+                     CsrVariant variant, hipStream_t stream, double* d_dot_partials = nullptr);
+int csr_fused_dot_partials(const SlabCsr& m, CsrVariant variant);
 
 // ---- ELLPACK SpMV (device layout: slot-major, element (r,k) at [k * rows + r]) ----
 void launch_ell_transpose(int rows, int width, const int* idx_rowmajor, const double* val_rowmajor,
                           int* idx_slotmajor, double* val_slotmajor, hipStream_t stream);
 // grid_hint: n if the matrix is known to be an n x n stencil (block -> XCD relabelling is sized to a grid row), else 0.
 void launch_ell_spmv(int rows, int width, const int* idx, const double* val, const double* x,
-                     double* y, double alpha, double beta, const Tunables& knobs, hipStream_t stream,
+                     double* y, double alpha, double beta, hipStream_t stream,
                      int grid_hint = 0, double* d_dot_partials = nullptr);
 // d_dot_partials (may be null; square matrices): one partial of x . (A x) per workgroup, ell_fused_dot_partials() of them.
-int ell_fused_dot_partials(int rows, const Tunables& knobs);
+int ell_fused_dot_partials(int rows);
 // Interior rows take W,C,E,N,S from slots 1,2,3,0,4 with computed columns; others walk slots.
 void launch_ell_stencil5_spmv(int rows, int width, int grid_size, const int* idx,
                               const double* val, const double* x, double* y, double alpha,
-                              double beta, const Tunables& knobs, hipStream_t stream, double* d_dot_partials = nullptr);
+                              double beta, hipStream_t stream, double* d_dot_partials = nullptr);
 
 // ---- BLAS1 + reductions for CG ----
 // Device scalars of one CG solve, laid out in one small allocation.
@@ -209,15 +171,34 @@ void launch_scalar_divide(const double* d_num, const double* d_den, double* d_ou
 void launch_check_convergence(const double* d_rr_new, double b_norm, double tol, int* d_converged,
                               double* d_residual, hipStream_t stream);
 
+// ---- reductions of the CG loop ----
+// Scratch of the reductions of ONE stream (slice sums, boundary-row extras, ticket; reduce_device.hpp): reduce_scratch_doubles()
+// doubles, zero before the first use (every reduction leaves it ready for the next).
+struct ReduceScratch {
+    double* base = nullptr;  // null: a single workgroup sums everything (short lists only)
+    bool one_launch = true;  // false: slices and final sum as two launches, the form of rounds 2-4 (SPMV_AMD_REDUCE_ONE_LAUNCH=0)
+};
+int reduce_scratch_doubles();
+double* reduce_scratch_alloc();  // uncached device memory where the runtime offers it, zeroed; hipFree releases it
+
+// The first and / or last grid row of a solver slab (the rows that wait for the halos) AND the reduction of the SpMV's p.Ap
+// partials -- the interior launch's d_interior_partials plus these rows' own -- into *d_out, in ONE launch (spmv_kernels.hip).
+// `interior` = the plan of the launch over the other rows. Returns false, having launched nothing, where the fused form does
+// not apply (not a row-lds slab, two-launch reductions asked for, a slab of fewer than three grid rows): the caller then
+// launches the rows and the reduction separately.
+bool launch_stencil5_edges_and_reduce(const SlabCsr& m, const Stencil5Plan& interior, bool first_gridrow, bool last_gridrow, const double* x,
+                                      double* y, double alpha, const double* d_interior_partials, double* d_out, const int* d_skip_flag,
+                                      const ReduceScratch& scratch, int* host_progress, int progress_value, const PeerMailbox* mailbox,
+                                      hipStream_t stream);
+
 // ---- fused CG steps of the slab solver (all skip their work when s->converged) ----
 // r = b - Ap ; p = r ; partials of r.r
 void launch_cg_init_residual(size_t n, const double* b, const double* Ap, double* r, double* p,
                              double* partials, hipStream_t stream);
 // alpha = rr_old / pAp (per thread, from the scalars) ; r -= alpha Ap ; partials of r.r
 // reverse: workgroups walk the vectors from the end (same results, same partial slots).
-// r_in (optional): read the old residual from there and write the new one to r (out of place); null = in place.
 void launch_cg_update_r(size_t n, const CgScalars* s, const double* Ap, double* r, double* partials,
-                        hipStream_t stream, bool reverse = false, const double* r_in = nullptr);
+                        hipStream_t stream, bool reverse = false);
 // x += alpha p (the update of iteration `iteration`), then p = 1.0*r + beta*p unless that iteration
 // converged; one pass over p (axpy + axpby of cg_solver_mgpu_partitioned.cu:598,682 fused).
 // x = x_in + alpha p: x_in is x, or the stored initial guess in the first iteration of a solve.
@@ -245,21 +226,19 @@ struct RingSlots {
 void launch_cg_flush_x(size_t n, const double* alphas, const RingSlots& ring, int slots, int first_slot, int count,
                        const double* x_in, double* x, hipStream_t stream);
 int cg_partial_count(size_t n);  // partial slots written by the two reducing kernels above
-// *d_out = sum of partials[0..count) in a fixed order. `stage` (reduce_stage_doubles() doubles,
-// may be null; its LAST slot is a ticket counter and must be zero before the first use) lets
-// large counts be summed by many blocks first, in the same launch.
-int reduce_stage_doubles();
-// host_progress (may be null): int in host-coherent pinned memory, set to progress_value once the sum is stored
-// (two-launch and single-block forms only); read by the solver's watchdog report.
-// mailbox (may be null; comm.hpp): the sum is completed across the ranks inside the last stage's launch.
+// *d_out = sum of partials[0..count) and extra[0..extra_count) in a fixed order (reduce_device.hpp: slices of `partials`, then
+// [slice sums | extra]), in ONE launch. extra: the partials of a split SpMV's boundary rows (may be null).
+// host_progress (may be null): int in host-coherent pinned memory, set to progress_value once the sum is stored;
+// read by the solver's watchdog report.
+// mailbox (may be null; comm.hpp): the sum is completed across the ranks inside the same launch.
 void launch_reduce_partials(const double* partials, int count, double* d_out,
-                            const int* d_skip_flag, hipStream_t stream, double* stage = nullptr,
+                            const int* d_skip_flag, hipStream_t stream, const ReduceScratch& scratch = ReduceScratch{},
                             int* host_progress = nullptr, int progress_value = 0,
-                            const PeerMailbox* mailbox = nullptr);
-// The same reduction followed by launch_cg_scalars_step(), in one launch when the wide path is taken
+                            const PeerMailbox* mailbox = nullptr, const double* extra = nullptr, int extra_count = 0);
+// The same reduction followed by launch_cg_scalars_step() in the same launch
 // (only valid when no all-reduce has to happen between the sum and the step).
 void launch_reduce_partials_and_step(const double* partials, int count, double* d_out, const int* d_skip_flag,
-                                     hipStream_t stream, double* stage, CgScalars* s, double tol, double* history,
+                                     hipStream_t stream, const ReduceScratch& scratch, CgScalars* s, double tol, double* history,
                                      int* host_record, int sequence, double* alpha_ring = nullptr, int ring_slots = 0,
                                      const PeerMailbox* mailbox = nullptr, int* host_progress = nullptr,
                                      int progress_value = 0);

@@ -28,7 +28,7 @@ constexpr hipStream_t kDefaultStream = nullptr;  // the reference launches on th
 
 struct CsrBackedOperator {
     const char* tag;
-    LaunchShape shape;        // device geometry + the SPMV_AMD_* switches, read when a variant is picked
+    LaunchShape shape;        // the launch switches (kernels.hpp), read when a variant is picked
     Stencil5Plan plan;        // stencil5-csr: the launch plan of the whole matrix, made once per init / variant change
     DeviceCsr A;
     double* dX = nullptr;
@@ -36,7 +36,6 @@ struct CsrBackedOperator {
     int rows = 0, cols = 0;
     bool ready = false;
     Stencil5Variant stencil_variant = Stencil5Variant::Auto;
-    int march_rows = 0;  // stencil5-csr, variants "row-lds-march2" / "row-lds-march4": grid rows a row-lds wave walks (0 = SPMV_AMD_ROWLDS_ROWS / 1)
     CsrVariant csr_variant = CsrVariant::Auto;
     const char* variant_name = "uninitialised";
 
@@ -111,11 +110,8 @@ CsrBackedOperator g_csr{"cusparse-csr"};
 
 void stencil_pick_variant() {
     g_stencil.shape = current_launch_shape();
-    if (g_stencil.march_rows > 0) g_stencil.shape.knobs.rowlds_rows = g_stencil.march_rows;
     g_stencil.plan = plan_stencil5(g_stencil.A.view, 0, g_stencil.rows, g_stencil.stencil_variant, g_stencil.shape);
-    g_stencil.variant_name = g_stencil.plan.lds_march_rows == 2   ? "stencil5/row-lds-march2"
-                             : g_stencil.plan.lds_march_rows == 4 ? "stencil5/row-lds-march4"
-                                                                  : g_stencil.plan.name;
+    g_stencil.variant_name = g_stencil.plan.name;
     if (g_stencil.dY == nullptr)  // once per init: the class a good output vector lies in does not depend on the variant
         g_stencil.place_output([](const double* x, double* y) {
             (void)launch_stencil5_spmv(g_stencil.A.view, g_stencil.plan, x, y, 1.0, nullptr, nullptr, false, kDefaultStream);
@@ -179,10 +175,6 @@ const char* csr_variant_name(CsrVariant v, const SlabCsr& m) {
         case CsrVariant::Stream: return "csr/stream";
         case CsrVariant::Adaptive: return "csr/adaptive";
         case CsrVariant::RowScalar: return "csr/row-scalar";
-        case CsrVariant::SubWave4: return "csr/subwave4";
-        case CsrVariant::SubWave8: return "csr/subwave8";
-        case CsrVariant::SubWave16: return "csr/subwave16";
-        case CsrVariant::SubWave32: return "csr/subwave32";
         default: return "csr/wavefront";
     }
 }
@@ -191,7 +183,6 @@ void csr_place_output();
 
 int csr_init(MatrixData* mat) {
     if (g_csr.init_from_host(mat) != 0) return EXIT_FAILURE;
-    g_csr.shape = current_launch_shape();
     g_csr.variant_name = csr_variant_name(g_csr.csr_variant, g_csr.A.view);
     csr_place_output();
     printf("[cusparse-csr] %d rows, %d nnz, variant %s\n", csr_mat.nb_rows, csr_mat.nb_nonzeros,
@@ -202,7 +193,7 @@ int csr_init(MatrixData* mat) {
 void csr_place_output() {
     if (g_csr.dY == nullptr)
         g_csr.place_output([](const double* x, double* y) {
-            launch_csr_spmv(g_csr.A.view, x, y, 1.0, g_csr.csr_variant, g_csr.shape.knobs, kDefaultStream);
+            launch_csr_spmv(g_csr.A.view, x, y, 1.0, g_csr.csr_variant, kDefaultStream);
         });
 }
 
@@ -211,7 +202,7 @@ int csr_run_device(const double* d_x, double* d_y) {
         fprintf(stderr, "[cusparse-csr] run before init\n");
         return EXIT_FAILURE;
     }
-    launch_csr_spmv(g_csr.A.view, d_x, d_y, /*alpha=*/1.0, g_csr.csr_variant, g_csr.shape.knobs, kDefaultStream);
+    launch_csr_spmv(g_csr.A.view, d_x, d_y, /*alpha=*/1.0, g_csr.csr_variant, kDefaultStream);
     return EXIT_SUCCESS;
 }
 
@@ -220,8 +211,8 @@ int csr_run_device(const double* d_x, double* d_y) {
 // convergence), no sweep direction, no fused initial residual.
 int csr_fused_launch(const double* d_x, double* d_y, double* d_partials, const int*, bool, const ResidualOut* init, hipStream_t stream) {
     if (init != nullptr) return -1;
-    launch_csr_spmv(g_csr.A.view, d_x, d_y, /*alpha=*/1.0, g_csr.csr_variant, g_csr.shape.knobs, stream, d_partials);
-    return csr_fused_dot_partials(g_csr.A.view, g_csr.csr_variant, g_csr.shape.knobs);
+    launch_csr_spmv(g_csr.A.view, d_x, d_y, /*alpha=*/1.0, g_csr.csr_variant, stream, d_partials);
+    return csr_fused_dot_partials(g_csr.A.view, g_csr.csr_variant);
 }
 
 void csr_free() {
@@ -236,17 +227,11 @@ struct EllOperator {
     const char* tag;
     bool stencil_fast_path;
     // slot-major planes, both carved out of ONE allocation (val first): the kernel reads val[k][r] and idx[k][r] in lock step
-    // (DeviceCsr has the reason; SPMV_AMD_CSR_ARENA=0: two allocations)
+    // (DeviceCsr::allocate has the reason)
     char* planes_block = nullptr;
     int* idx = nullptr;
     double* val = nullptr;
     void alloc_planes(size_t slots) {
-        const char* v = getenv("SPMV_AMD_CSR_ARENA");
-        if (v != nullptr && v[0] == '0') {
-            idx = device_alloc<int>(slots);
-            val = device_alloc<double>(slots);
-            return;
-        }
         const size_t v_bytes = (slots * sizeof(double) + 4095) / 4096 * 4096;
         planes_block = device_alloc<char>(v_bytes + slots * sizeof(int));
         val = reinterpret_cast<double*>(planes_block);
@@ -261,22 +246,15 @@ struct EllOperator {
     int y_candidates = 1;  // output placement (device_runtime.hpp)
     double y_gain = 1.0;
     void drop() {
-        if (planes_block != nullptr) {
-            device_release(planes_block);
-            idx = nullptr;
-            val = nullptr;
-        } else {
-            device_release(idx);
-            device_release(val);
-        }
+        device_release(planes_block);
+        idx = nullptr;
+        val = nullptr;
         device_release(dX);
         device_release(dY);
         ready = false;
         variant_name = "uninitialised";
     }
-    Tunables knobs;
     void pick() {
-        knobs = current_launch_shape().knobs;
         variant_name = (stencil_fast_path && verified && grid_size >= 3) ? "ell/stencil5-direct"
                                                                         : "ell/slot-major";
     }
@@ -381,11 +359,9 @@ int ell_run(EllOperator& op, const double* d_x, double* d_y, double alpha, doubl
         return EXIT_FAILURE;
     }
     if (op.stencil_fast_path && op.verified)
-        launch_ell_stencil5_spmv(op.rows, op.width, op.grid_size, op.idx, op.val, d_x, d_y, alpha, beta, op.knobs,
-                                 kDefaultStream);
+        launch_ell_stencil5_spmv(op.rows, op.width, op.grid_size, op.idx, op.val, d_x, d_y, alpha, beta, kDefaultStream);
     else
-        launch_ell_spmv(op.rows, op.width, op.idx, op.val, d_x, d_y, alpha, beta, op.knobs, kDefaultStream,
-                        op.verified ? op.grid_size : 0);
+        launch_ell_spmv(op.rows, op.width, op.idx, op.val, d_x, d_y, alpha, beta, kDefaultStream, op.verified ? op.grid_size : 0);
     return 0;
 }
 
@@ -406,11 +382,10 @@ template <EllOperator* Op>
 int ell_fused_launch(const double* d_x, double* d_y, double* d_partials, const int*, bool, const ResidualOut* init, hipStream_t stream) {
     if (init != nullptr || !Op->ready) return -1;
     if (Op->stencil_fast_path && Op->verified)
-        launch_ell_stencil5_spmv(Op->rows, Op->width, Op->grid_size, Op->idx, Op->val, d_x, d_y, 1.0, 0.0, Op->knobs, stream, d_partials);
+        launch_ell_stencil5_spmv(Op->rows, Op->width, Op->grid_size, Op->idx, Op->val, d_x, d_y, 1.0, 0.0, stream, d_partials);
     else
-        launch_ell_spmv(Op->rows, Op->width, Op->idx, Op->val, d_x, d_y, 1.0, 0.0, Op->knobs, stream, Op->verified ? Op->grid_size : 0,
-                        d_partials);
-    return ell_fused_dot_partials(Op->rows, Op->knobs);
+        launch_ell_spmv(Op->rows, Op->width, Op->idx, Op->val, d_x, d_y, 1.0, 0.0, stream, Op->verified ? Op->grid_size : 0, d_partials);
+    return ell_fused_dot_partials(Op->rows);
 }
 
 int ellg_init(MatrixData* m) { return ell_init_common(g_ell, m); }
@@ -465,16 +440,16 @@ FusedSpmv fused_spmv_of(const SpmvOperator* op) {
     if ((op == &SPMV_STENCIL5_CSR || op == &SPMV_STENCIL_HALO_MGPU) && g_stencil.ready && g_stencil.plan.partials > 0 &&
         g_stencil.plan.variant != Stencil5Variant::RowGeneric) {
         f.partials = g_stencil.plan.partials;
-        f.can_init = g_stencil.plan.variant == Stencil5Variant::RowLds || g_stencil.plan.variant == Stencil5Variant::RowPlanes;
+        f.can_init = g_stencil.plan.variant == Stencil5Variant::RowLds;
         f.launch = stencil_fused_launch;
     } else if (op == &SPMV_CSR && g_csr.ready && g_csr.rows == g_csr.cols) {
-        f.partials = csr_fused_dot_partials(g_csr.A.view, g_csr.csr_variant, g_csr.shape.knobs);
+        f.partials = csr_fused_dot_partials(g_csr.A.view, g_csr.csr_variant);
         f.launch = f.partials > 0 ? csr_fused_launch : nullptr;
     } else if (op == &SPMV_ELLPACK && g_ell.ready && g_ell.rows == g_ell.cols) {
-        f.partials = ell_fused_dot_partials(g_ell.rows, g_ell.knobs);
+        f.partials = ell_fused_dot_partials(g_ell.rows);
         f.launch = ell_fused_launch<&g_ell>;
     } else if (op == &SPMV_STENCIL5_ELLPACK && g_ell_stencil.ready && g_ell_stencil.rows == g_ell_stencil.cols) {
-        f.partials = ell_fused_dot_partials(g_ell_stencil.rows, g_ell_stencil.knobs);
+        f.partials = ell_fused_dot_partials(g_ell_stencil.rows);
         f.launch = ell_fused_launch<&g_ell_stencil>;
     }
     return f;
@@ -503,8 +478,7 @@ extern "C" int spmv_amd_init_stencil5_synthetic(const char* mode, int n) {
         case Which::Csr:
             if (g_csr.init_synthetic(n) != 0) return EXIT_FAILURE;
             HIP_CHECK(hipStreamSynchronize(kDefaultStream));
-            g_csr.shape = current_launch_shape();
-            g_csr.variant_name = csr_variant_name(g_csr.csr_variant, g_csr.A.view);
+                    g_csr.variant_name = csr_variant_name(g_csr.csr_variant, g_csr.A.view);
             csr_place_output();
             return 0;
         case Which::Ell: return ell_init_synthetic(g_ell, n);
@@ -605,14 +579,9 @@ extern "C" int spmv_amd_operator_select_variant(const char* mode, const char* va
     const bool automatic = variant == nullptr || !strcmp(variant, "auto");
     switch (which_operator(mode)) {
         case Which::Stencil:
-            g_stencil.march_rows = 0;
             if (automatic) g_stencil.stencil_variant = Stencil5Variant::Auto;
-            else if (!strcmp(variant, "row-lds")) g_stencil.stencil_variant = Stencil5Variant::RowLds, g_stencil.march_rows = 1;
-            else if (!strcmp(variant, "row-lds-march2")) g_stencil.stencil_variant = Stencil5Variant::RowLds, g_stencil.march_rows = 2;
-            else if (!strcmp(variant, "row-lds-march4")) g_stencil.stencil_variant = Stencil5Variant::RowLds, g_stencil.march_rows = 4;
+            else if (!strcmp(variant, "row-lds")) g_stencil.stencil_variant = Stencil5Variant::RowLds;
             else if (!strcmp(variant, "row-direct")) g_stencil.stencil_variant = Stencil5Variant::RowDirect;
-            else if (!strcmp(variant, "column-march")) g_stencil.stencil_variant = Stencil5Variant::ColumnMarch;
-            else if (!strcmp(variant, "wave-tile")) g_stencil.stencil_variant = Stencil5Variant::WaveTile;
             else if (!strcmp(variant, "row-generic")) g_stencil.stencil_variant = Stencil5Variant::RowGeneric;
             else return EXIT_FAILURE;
             if (g_stencil.ready) stencil_pick_variant();
@@ -624,23 +593,16 @@ extern "C" int spmv_amd_operator_select_variant(const char* mode, const char* va
             else if (!strcmp(variant, "adaptive")) v = CsrVariant::Adaptive;
             else if (!strcmp(variant, "row-scalar")) v = CsrVariant::RowScalar;
             else if (!strcmp(variant, "wavefront")) v = CsrVariant::Wavefront;
-            else if (!strcmp(variant, "subwave4")) v = CsrVariant::SubWave4;
-            else if (!strcmp(variant, "subwave8")) v = CsrVariant::SubWave8;
-            else if (!strcmp(variant, "subwave16")) v = CsrVariant::SubWave16;
-            else if (!strcmp(variant, "subwave32")) v = CsrVariant::SubWave32;
             else return EXIT_FAILURE;
             g_csr.csr_variant = v;
             if (g_csr.ready) {
-                // the tunables (SPMV_AMD_XCD_GROUP, SPMV_AMD_CSR_STREAM_ROWS, ...) are re-read: an A/B of launch geometries
-                // can then run on ONE initialised operator, i.e. on the same allocations (tools/ab_csr_runs.py)
-                g_csr.shape = current_launch_shape();
                 g_csr.variant_name = csr_variant_name(v, g_csr.A.view);
             }
             return 0;
         }
         case Which::Ell:
         case Which::EllStencil: {
-            // one kernel each: "auto" only, which re-reads the tunables (same reason as above)
+            // one kernel each: "auto" only
             if (!automatic) return EXIT_FAILURE;
             EllOperator& e = which_operator(mode) == Which::Ell ? g_ell : g_ell_stencil;
             if (e.ready) e.pick();

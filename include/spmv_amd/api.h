@@ -348,21 +348,16 @@ int spmv_amd_cg_slab_time_spmv(SpmvAmdCgSlab* s, int reps, float* ms_each);
  * The direction-update stage is averaged over the launches that did work ("direction_updates": the converging
  * iteration's update is never needed -- the reference tests convergence before its p update, :652-676). */
 void spmv_amd_cg_slab_set_timeline(SpmvAmdCgSlab* s, int on);
-/* Measurement aids (tools/spmv_regions.py): the slab's SpMV kernel / r-update kernel on caller-chosen device addresses. */
-int spmv_amd_cg_slab_lab_spmv(SpmvAmdCgSlab* s, double* values, double* x, double* y, int reverse, int reps, float* ms_each);
-int spmv_amd_cg_slab_lab_pair(SpmvAmdCgSlab* s, const double* a, double* b, size_t n, int reps, float* ms_each);
-int spmv_amd_cg_slab_lab_rebind(SpmvAmdCgSlab* s, double* Ap, double* r, double* values, double* const* ring, int ring_count);
-int spmv_amd_cg_slab_lab_direction(SpmvAmdCgSlab* s, const double* r, const double* p_in, double* p_out, size_t n, int reps, float* ms_each);
-/* Placement at creation (csrc/cg_slab.hip, csrc/class_pool.hpp). Slabs of >= 16 Mi rows place their coefficient stream by timing
- * candidates: {0, candidates timed, SpMV ms before, SpMV ms kept}. With SPMV_AMD_CLASS_POOL=1 (opt-in) single-rank slabs of
- * >= 1e8 rows instead build r, Ap, the direction buffers and the coefficient stream from physical chunks of chosen classes of
- * address regions (HIP virtual-memory API): {1, chunks created, chunks in vectors, 1 if the coefficients are in the pool}.
- * Returns 4, or 0 if neither ran. Addresses only: results never change. */
+/* Placement at creation (csrc/cg_slab.hip). Slabs of >= 16 Mi rows place their coefficient stream by timing up to three
+ * allocations one region apart: {0, candidates timed, SpMV ms before, SpMV ms kept}. Returns 4, or 0 if it did not run.
+ * Addresses only: results never change; a candidate that does not fit ends the trial, never the process. */
 int spmv_amd_cg_slab_placement(const SpmvAmdCgSlab* s, double* out, int cap);
 /* The timed in-loop SpMV launches of the last solve, one by one (ms, iteration order). Returns their number. */
 int spmv_amd_cg_slab_spmv_launch_ms(const SpmvAmdCgSlab* s, float* out, int cap);
-/* Loop options of an existing slab (measurement aid: A/B runs on the same allocations; results are bit-identical under
- * every option): "late_bulk" 0/1, "lead_rows" N, "early_halo" 0/1, "pingpong" 0/1, "r_pingpong" 0/1. 0, or -1 = unknown name. */
+/* Loop options of an existing slab (A/B runs on the same allocations; results are bit-identical under every option):
+ * "late_bulk" 0/1, "lead_rows" N, "early_halo" 0/1, "pingpong" 0/1, "reduce_one_launch" 0/1 (0 = the two-launch reductions of
+ * rounds 2-4 and a separate boundary-row launch), "no_overlap" 0/1 (1 = halo exchange on the compute stream),
+ * "spmv_event_stride" N (time every N-th in-loop SpMV launch, 0 = none). 0, or -1 = unknown name. */
 int spmv_amd_cg_slab_set_option(SpmvAmdCgSlab* s, const char* name, long long value);
 const char* spmv_amd_cg_slab_timeline_names(void);
 int spmv_amd_cg_slab_timeline(const SpmvAmdCgSlab* s, double* out, int cap);

@@ -273,24 +273,22 @@ def test_placement_at_set_up_changes_addresses_only(B, O, fresh_host_matrices, m
     assert np.array_equal(out["3"][2], out["1"][2]) and out["3"][3] == out["1"][3]
 
 
-def test_class_pool_vectors_change_no_bit(B, monkeypatch):
-    """SPMV_AMD_CLASS_POOL=1: r, Ap, the direction buffers and the coefficient stream mapped from physical chunks of chosen
-    classes (HIP virtual-memory API) instead of carved out of the arena. The slab must be large enough for the pool to apply
-    (1e8 rows: grid 10 000); history and solution are bit-identical to the arena's, the record says which ran, and a pool
-    that cannot deliver falls back silently to the arena."""
-    n = 10000
+def test_a_placement_candidate_that_does_not_fit_ends_the_trial_not_the_process(B, monkeypatch):
+    """every further candidate of the coefficient placement is an OPTIONAL copy -- when the device cannot provide
+    it (SPMV_AMD_PLACEMENT_FAIL_AFTER=1: the first further candidate "does not fit") the slab keeps the array it has, says so
+    in its record and solves to the same bits."""
+    n = 5000  # 2.5e7 rows: above the 16 Mi-row threshold of the trial
     out = {}
-    for pool in ("0", "1"):
-        monkeypatch.setenv("SPMV_AMD_CLASS_POOL", pool)
+    for fail in ("0", "1"):
+        monkeypatch.setenv("SPMV_AMD_PLACEMENT_FAIL_AFTER", fail)
         slab = B.CgSlab.stencil5(n)
         rec = slab.placement()
         st = slab.solve()
-        st2 = slab.solve()
-        assert st.iterations == st2.iterations == 14 and st.converged == 1
-        out[pool] = (rec, slab.history().copy(), slab.gather())
+        assert st.converged == 1
+        out[fail] = (rec, slab.history().copy(), slab.gather())
         slab.destroy()
-    assert out["0"][0]["kind"] == "coefficient candidates"
-    assert out["1"][0]["kind"] in ("class pool", "coefficient candidates")  # the second only if the pool had to give up
+    assert out["0"][0]["candidates"] >= 1 and out["1"][0]["candidates"] == 1
+    assert out["1"][0]["spmv_ms_kept"] == out["1"][0]["spmv_ms_before"]
     assert np.array_equal(out["0"][1], out["1"][1]) and np.array_equal(out["0"][2], out["1"][2])
 
 
@@ -326,12 +324,15 @@ def test_slab_timeline_accounts_for_the_solve(B, O, fresh_host_matrices):
     slab.destroy()
 
 
-@pytest.mark.parametrize("n,P,r", [(1024, 1, 0), (1000, 1, 0), (1024, 4, 1), (1024, 2, 0), (1001, 1, 0)])
-def test_late_bulk_and_out_of_place_r_leave_every_bit_alone(B, monkeypatch, n, P, r):
-    """Round 4's loop options on one slab: the direction update split into a lead piece + (after the status record) the rest,
-    forced on with a lead of 50 000 rows so that small grids take the path in both sweep directions; the r update written out
-    of place. History and solution must be bit-identical to the plain loop, with the direction ring and with the in-place
-    x / p update, on a plain slab (even and odd row counts) and on stand-in slabs of a larger job (early halo + late bulk)."""
+@pytest.mark.parametrize("n,P,r", [(1024, 1, 0), (1000, 1, 0), (1024, 4, 1), (1024, 2, 0), (1024, 2, 1), (1001, 1, 0), (2048, 8, 3)])
+def test_loop_options_leave_every_bit_alone(B, monkeypatch, n, P, r):
+    """The loop options on one slab. Round 4: the direction update split into a lead piece + (after the status record) the rest,
+    forced on with a lead of 50 000 rows so that small grids take the path in both sweep directions. Round 5: every dot product
+    reduced by ONE launch (the workgroup that finishes last sums the slice sums) and, on slabs with neighbours, the boundary
+    rows of the split SpMV evaluated inside that launch -- against the two-launch reductions and the separate boundary-row
+    launch of rounds 2-4 (reduce_one_launch = 0); halo exchange on the compute stream (no_overlap). History and solution must be
+    bit-identical under every combination, with the direction ring and with the in-place x / p update, on a plain slab (even
+    and odd row counts) and on stand-in slabs of a larger job (one and two neighbours)."""
     comm = None
     if P > 1:
         monkeypatch.setenv("SPMV_AMD_SELF_NEIGHBOUR", "1")
@@ -346,11 +347,13 @@ def test_late_bulk_and_out_of_place_r_leave_every_bit_alone(B, monkeypatch, n, P
             slab = B.CgSlab.stencil5(n)
             kw = {}
         slab.set_option("late_bulk", 0)
+        slab.set_option("reduce_one_launch", 0)
         st0 = slab.solve(**kw)
         h0, x0 = slab.history().copy(), slab.gather() if P == 1 else None
-        for opts in ({"late_bulk": 1, "lead_rows": 50000}, {"late_bulk": 1, "lead_rows": 512}, {"late_bulk": 0, "r_pingpong": 1},
-                     {"late_bulk": 1, "lead_rows": 50000, "r_pingpong": 1}):
-            for k in ("late_bulk", "r_pingpong"):
+        for opts in ({"late_bulk": 1, "lead_rows": 50000}, {"late_bulk": 1, "lead_rows": 512}, {"late_bulk": 0, "reduce_one_launch": 1},
+                     {"late_bulk": 1, "lead_rows": 50000, "reduce_one_launch": 1}, {"reduce_one_launch": 1, "no_overlap": 1},
+                     {"reduce_one_launch": 0, "no_overlap": 1}):
+            for k in ("late_bulk", "reduce_one_launch", "no_overlap"):
                 slab.set_option(k, opts.get(k, 0))
             slab.set_option("lead_rows", opts.get("lead_rows", 1 << 24))
             st = slab.solve(**kw)
@@ -385,22 +388,16 @@ def test_reference_entry_point_cg_solve_mgpu_partitioned(B, O, fresh_host_matric
     assert np.array_equal(x2, x) and st2.time_spmv_ms > 0 and st2.time_blas1_ms > 0
 
 
-@pytest.mark.parametrize("planes", ["1", "0"])
 @pytest.mark.parametrize("n,rowlds_min_grid,variant", [(256, None, "stencil5/row-direct"), (640, None, "stencil5/row-lds"),
                                                        (130, "2", "stencil5/row-lds"), (260, "2", "stencil5/row-lds"),
                                                        (64, "2", "stencil5/row-lds")])
-def test_slab_spmv_matches_halo_oracle(B, O, fresh_host_matrices, monkeypatch, n, rowlds_min_grid, variant, planes):
+def test_slab_spmv_matches_halo_oracle(B, O, fresh_host_matrices, monkeypatch, n, rowlds_min_grid, variant):
     """Slab-local SpMV with halos for every rank of a 1/2/4-way split, one rank at a time on this
     GPU (staged communicator with trivial callbacks: spmv() fills the halos from the full vector).
     Random coefficients, so a coefficient taken from the wrong CSR position cannot go unnoticed; the
     row-lds kernel is also forced onto small grids (one or two clamped tiles per grid row)."""
     if rowlds_min_grid is not None:
         monkeypatch.setenv("SPMV_AMD_ROWLDS_MIN_GRID", rowlds_min_grid)
-    # planes = "1": slabs that would run row-lds keep a five-plane copy of the coefficients and run row-planes instead
-    # (a measured, not adopted layout); "0" (default): the CSR-only row-lds path. Both bit-identical to the oracle.
-    monkeypatch.setenv("SPMV_AMD_SLAB_PLANES", planes)
-    if planes == "1" and variant == "stencil5/row-lds":
-        variant = "stencil5/row-planes"
     e = O.stencil5_coo(n)
     rng = np.random.default_rng(1)
     e["value"] = rng.uniform(-3, 3, len(e))
@@ -414,7 +411,7 @@ def test_slab_spmv_matches_halo_oracle(B, O, fresh_host_matrices, monkeypatch, n
             slab = B.CgSlab.from_matrix(m, comm)
             off, nl = O.partition_rows(n * n, world, rank)
             assert (slab.row_offset, slab.n_local) == (off, nl)
-            if (n * n) % (world * n) == 0:  # slabs of whole grid rows; others run wave-tile / row-generic
+            if (n * n) % (world * n) == 0:  # slabs of whole grid rows; others run row-generic
                 assert slab.variant() == variant
             base = rp[off]
             lrp = (rp[off:off + nl + 1] - base).astype(np.int32)

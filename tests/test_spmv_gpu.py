@@ -40,9 +40,9 @@ def test_stencil5_csr_bit_exact_random_values(B, O, fresh_host_matrices, n):
     assert op.run_device(Shift(dx), Shift(dy)) == 0
     assert np.array_equal(dy.to_host()[1:], want)
     # the same matrix forced through the other kernel variants (aligned and odd-address vectors)
-    for forced in ("row-lds", "row-lds-march2", "row-lds-march4", "row-direct", "column-march", "wave-tile", "row-generic"):
+    for forced in ("row-lds", "row-direct", "row-generic"):
         op.select_variant(forced)
-        if n >= 128 and not (forced.startswith("row-lds-march") and n < int(forced[-1])):
+        if n >= 2:
             assert op.variant() == "stencil5/" + forced
         got2, _ = op.run_timed(x)
         assert np.array_equal(got2, want), forced
@@ -97,7 +97,7 @@ def test_stencil5_csr_non_stencil_inputs_take_the_csr_loop(B, O, fresh_host_matr
         op.free()
 
 
-@pytest.mark.parametrize("variant", [None, "stream", "adaptive", "row-scalar", "subwave4", "subwave8", "subwave16", "subwave32", "wavefront"])
+@pytest.mark.parametrize("variant", [None, "stream", "adaptive", "row-scalar", "wavefront"])
 def test_csr_operator(B, O, fresh_host_matrices, variant):
     op = B.Operator("cusparse-csr")
     op.select_variant(variant)
@@ -256,59 +256,28 @@ def test_ellpack_alpha_beta_contract(B, O, fresh_host_matrices, name):
     op.free()
 
 
-@pytest.mark.parametrize("rows", [2, 4])
 @pytest.mark.parametrize("n,min_grid", [(640, None), (513, None), (1029, None), (130, "2"), (259, "2"), (7, "2")])
-def test_rowlds_march_is_bit_exact(B, O, fresh_host_matrices, monkeypatch, rows, n, min_grid):
-    """SPMV_AMD_ROWLDS_ROWS = 2 / 4: a wave walks that many consecutive grid rows with north / centre / south x values
-    rotating in registers. Same per-row arithmetic, so bit-exact against the oracle on random coefficients -- grids whose
-    row count is not a multiple of the march (remainder group), whose first / last row falls inside a group, edge tiles
-    that are clamped, and grids narrower than one tile (forced onto row-lds through SPMV_AMD_ROWLDS_MIN_GRID)."""
-    monkeypatch.setenv("SPMV_AMD_ROWLDS_ROWS", str(rows))
+def test_rowlds_edge_geometry_is_bit_exact(B, O, fresh_host_matrices, monkeypatch, n, min_grid):
+    """The row-lds tile on the geometries that stress its clamped coefficient runs: a last tile of 1 / 5 / 3 live columns, grids
+    narrower than one tile and of a single partial tile (forced onto row-lds through SPMV_AMD_ROWLDS_MIN_GRID), and a run length
+    per XCD that does not divide the tile count (SPMV_AMD_ROWLDS_GROUP=3). Random coefficients: bit-exact against the oracle."""
     if min_grid:
         monkeypatch.setenv("SPMV_AMD_ROWLDS_MIN_GRID", min_grid)
-    e, x = random_stencil(O, n, 100 * rows + n)
+    e, x = random_stencil(O, n, 100 + n)
     m = B.HostMatrix(e, n * n, n * n, n)
-    op = B.Operator("stencil5-csr")
-    assert op.init(m) == 0 and op.variant() == f"stencil5/row-lds-march{rows}"
     rp, ci, va = O.build_csr(e, n * n)
     want = O.spmv_stencil5(rp, ci, va, x, n)
-    got, _ = op.run_timed(x)
-    assert np.array_equal(got, want)
-    op.free()
+    for group in (None, "3"):
+        if group:
+            monkeypatch.setenv("SPMV_AMD_ROWLDS_GROUP", group)
+        op = B.Operator("stencil5-csr")
+        assert op.init(m) == 0 and op.variant() == "stencil5/row-lds"
+        got, _ = op.run_timed(x)
+        assert np.array_equal(got, want), group
+        op.free()
 
 
-@pytest.mark.parametrize("rows", [2, 4])
-def test_rowlds_march_in_the_solver_changes_no_bit(B, O, fresh_host_matrices, monkeypatch, rows):
-    """The march kernel writes the dot partials into the one-row kernel's slots: residual history and solution of the slab
-    solver (fused p.Ap partials, fused initial residual, alternating sweep direction) are bit-identical with and
-    without it -- on the whole grid and on a stand-in slab whose SpMV is split into interior + halo rows."""
-    def solve(n, as_rank=None, as_world=None):
-        B.lib().spmv_amd_reset_host_matrices()
-        if as_world is None:
-            slab, comm = B.CgSlab.stencil5(n), None
-        else:
-            comm = B.Comm.rccl(0, 1, B.Comm.unique_id())
-            slab = B.CgSlab.stencil5_as(n, as_rank, as_world, comm)
-        st = slab.solve(max_iters=9, tol=0.0) if as_world else slab.solve()
-        out = (st.iterations, slab.history().copy(), slab.gather().copy() if as_world is None else None)
-        slab.destroy()
-        if comm:
-            comm.destroy()
-        return out
-
-    monkeypatch.setenv("SPMV_AMD_SELF_NEIGHBOUR", "1")
-    monkeypatch.setenv("SPMV_AMD_FORCE_COLLECTIVES", "1")
-    for args in ((641,), (1024, 1, 4), (642, 0, 2)):
-        monkeypatch.setenv("SPMV_AMD_ROWLDS_ROWS", "1")
-        base = solve(*args)
-        monkeypatch.setenv("SPMV_AMD_ROWLDS_ROWS", str(rows))
-        got = solve(*args)
-        assert got[0] == base[0] and np.array_equal(got[1], base[1]), args
-        if base[2] is not None:
-            assert np.array_equal(got[2], base[2]), args
-
-
-@pytest.mark.parametrize("variant", [None, "stream", "adaptive", "row-scalar", "subwave32", "wavefront"])
+@pytest.mark.parametrize("variant", [None, "stream", "adaptive", "row-scalar", "wavefront"])
 def test_csr_rows_without_column_zero_never_touch_x0(B, O, fresh_host_matrices, variant):
     """Padding slots of the CSR kernels' chunked loads must not gather x[0]: with x[0] = inf a folded 0 * x[0] would be NaN.
     Long rows (> the 1024-entry strip, ending inside a partial chunk: the adaptive kernel's no-staging fold), short and empty

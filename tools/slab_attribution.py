@@ -23,7 +23,6 @@ def child(grid, solves, roles):
     from conftest import load_binding
 
     os.environ["SPMV_AMD_SELF_NEIGHBOUR"] = os.environ["SPMV_AMD_FORCE_COLLECTIVES"] = "1"
-    os.environ.setdefault("SPMV_AMD_SPMV_EVENT_STRIDE", "1")  # every in-loop launch timed, small slabs too
     json_fd = os.dup(1)
     os.dup2(2, 1)
     B = load_binding()
@@ -33,6 +32,10 @@ def child(grid, solves, roles):
     out = []
     for P, r in roles:
         slab = B.CgSlab.stencil5(grid) if P == 1 else B.CgSlab.stencil5_as(grid, r, P, comm)
+        slab.set_option("spmv_event_stride", 1)  # every in-loop launch timed, small slabs too
+        for opt in os.environ.get("SLAB_OPTIONS", "").split(","):  # e.g. SLAB_OPTIONS=reduce_one_launch=0
+            if "=" in opt:
+                slab.set_option(opt.split("=")[0], int(opt.split("=")[1]))
         for _ in range(3):
             slab.solve(max_iters=14, tol=0.0)
         B.lib().spmv_amd_device_synchronize()
