@@ -227,10 +227,10 @@ def current_device():
 
 def stream_ceiling(rows, warmup=3, reps=20, mix="stencil5"):
     """Per-launch milliseconds and bytes of the stream probe (csrc/stream_ceiling.hip) for a format's byte mix:
-    "stencil5" 48:8 B/row, "csr" 72:8 (values, column indices, row pointers, x : y), "ellpack" 68:8."""
+    "stencil5" 48:8 B/row, "csr" 72:8 (values, column indices, row pointers, x : y), "ellpack" 68:8, "read-only" 48:0."""
     require_gpu()
     ms = (C.c_float * reps)()
-    nbytes = lib().spmv_amd_stream_ceiling_mix({"stencil5": 0, "csr": 1, "ellpack": 2}[mix], int(rows), int(warmup), int(reps), ms)
+    nbytes = lib().spmv_amd_stream_ceiling_mix({"stencil5": 0, "csr": 1, "ellpack": 2, "read-only": 3}[mix], int(rows), int(warmup), int(reps), ms)
     if nbytes <= 0:
         raise RuntimeError("spmv_amd_stream_ceiling failed")
     return np.array(ms[:], dtype=np.float64), nbytes

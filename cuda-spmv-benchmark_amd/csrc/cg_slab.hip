@@ -298,10 +298,10 @@ void make_common(SpmvAmdCgSlab* s) {
         HIP_CHECK(hipMemset(s->d_alpha_ring, 0, kMaxRingSlots * sizeof(double)));
     }
     s->shape = current_launch_shape();
-    // every launch is timed on big slabs; below 100 M rows (multi-GPU slabs: an iteration under 2 ms) every 4th, since
+    // every launch is timed on big slabs; below 100 M rows (multi-GPU slabs: an iteration under 2 ms) every 7th, since
     // each event pair puts ~7 us of queue barriers next to the SpMV (rocprofv3 timeline, profiles/r02_slab_timeline.txt);
     // set_option("spmv_event_stride") changes it
-    s->spmv_event_stride = nl >= 100000000 ? 1 : 4;
+    s->spmv_event_stride = nl >= 100000000 ? 1 : 7;
     if (const char* v = getenv("SPMV_AMD_PINGPONG")) s->pingpong = v[0] == '1';
     if (const char* v = getenv("SPMV_AMD_NO_OVERLAP")) s->no_overlap = v[0] == '1';
     if (const char* v = getenv("SPMV_AMD_EARLY_HALO")) s->early_halo = v[0] != '0';
@@ -494,6 +494,10 @@ int slab_spmv(SpmvAmdCgSlab* s, bool with_dot, bool overlap, const int* skip,
         // per solve at 50 M rows with the rank as its own neighbour.) A launch that writes dot partials is split in this way
         // even when the exchange is NOT overlapped (detailed timers, SPMV_AMD_NO_OVERLAP): the sum's shape -- slices of the
         // interior partials, then [slice sums | boundary rows' partials] -- must not depend on how the halos travelled.
+        // (The wait for the halo rows in FRONT of the interior launch -- the exchange then overlaps only the direction update
+        // it was started under, and the cross-stream wait leaves the path between the SpMV and its dot product -- measured
+        // slower on every stand-in slab: +0.1-0.2 % at 20 000^2, +2.4 % on the P = 8 slab of 10 000^2,
+        // profiles/r05_ab_halo_wait_first.txt.)
         used = launch_stencil5_spmv(A, s->plan_interior, in, s->Ap, 1.0, part, skip, s->shape.reverse, s->compute, init);
         s->spmv_split_at = used;  // the boundary rows' partials follow: they enter the sum as extra values (reduce_device.hpp)
         if (s->tl_after_interior) HIP_CHECK(hipEventRecord(s->tl_after_interior, s->compute));

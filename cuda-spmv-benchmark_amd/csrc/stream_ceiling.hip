@@ -3,9 +3,10 @@
 // A measurement kernel, not an operator: per row it reads five coefficients and one x value and writes one
 // y value (48 B read : 8 B written, the algorithmic 56 B of SURVEY.md section 8d), every access an 8-byte,
 // fully coalesced, nontemporal load or store of a one-wave workgroup (the access shape section 3 of DESIGN.md
-// found fastest), no neighbour reads, no LDS transpose, no row structure. Its rate on non-zero data is the
-// ceiling bench.py reports next to the spec-sheet peak as `roofline.ceiling_measured`: the fraction of THAT is
-// what the SpMV kernel's own organisation costs; the rest is between the part and its data sheet.
+// found fastest), no neighbour reads, no LDS transpose, no row structure. Its rate on non-zero data is what bench.py
+// reports as `roofline.mix_probe_gbs` -- one yardstick among three (with a read-only pass, mix 3 below, and the rate
+// the loop's r update reaches in the same run): `roofline.best_stream_gbs_this_run` is their maximum. None of them is
+// "the ceiling": in round 4's run the r update streamed 7 % faster than this probe.
 #include <stdio.h>
 
 #include <vector>
@@ -49,6 +50,25 @@ __global__ __launch_bounds__(64) void stream_ceiling_kernel(const double* __rest
     }
     __builtin_nontemporal_store(ya, y + ra);
     __builtin_nontemporal_store(yb, y + rb);
+}
+
+// Read-only pass over the same arrays (mix 3): 48 B/row read, one 8-byte partial per wave written.
+__global__ __launch_bounds__(64) void stream_read_only_kernel(const double* __restrict__ v, const double* __restrict__ x,
+                                                              double* __restrict__ y, size_t tiles) {
+    const size_t tile = blockIdx.x;
+    if (tile >= tiles) return;
+    const int lane = threadIdx.x;
+    const double* src = v + tile * (5 * kRowsPerWave) + lane;
+    double c[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) c[k] = __builtin_nontemporal_load(src + 64 * k);
+    const size_t ra = tile * kRowsPerWave + lane;
+    double acc = __builtin_nontemporal_load(x + ra) + __builtin_nontemporal_load(x + ra + 64);
+#pragma unroll
+    for (int k = 0; k < 10; ++k) acc += c[k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+    if (lane == 0) y[tile] = acc;
 }
 
 // The byte mix of the CSR and ELLPACK formats at five entries per row, with the same ideal accesses: per row five 8-byte
@@ -102,7 +122,7 @@ __global__ __launch_bounds__(64) void ceiling_fill_index_kernel(int* __restrict_
 
 // Runs the probe on `rows` rows (rounded down to whole 128-row tiles): `warmup` untimed launches, then `reps`
 // launches each timed with HIP events on the launch stream. Returns the bytes one launch moves (56 per row) or 0.
-extern "C" double spmv_amd_stream_ceiling(size_t rows, int warmup, int reps, float* ms_each) {
+static double stream_probe(size_t rows, int warmup, int reps, float* ms_each, bool read_only) {
     using namespace spmv_amd;
     const size_t tiles = rows / kRowsPerWave;
     if (tiles == 0 || tiles > 0x7fffffffULL || reps < 1) return 0.0;
@@ -113,12 +133,17 @@ extern "C" double spmv_amd_stream_ceiling(size_t rows, int warmup, int reps, flo
     hipStream_t stream = nullptr;
     HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     hipLaunchKernelGGL(ceiling_fill_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, stream, v, x, rows);
-    for (int i = 0; i < warmup; ++i)
-        hipLaunchKernelGGL(stream_ceiling_kernel, dim3((unsigned)tiles), dim3(64), 0, stream, v, x, y, tiles);
+    auto launch = [&] {
+        if (read_only)
+            hipLaunchKernelGGL(stream_read_only_kernel, dim3((unsigned)tiles), dim3(64), 0, stream, v, x, y, tiles);
+        else
+            hipLaunchKernelGGL(stream_ceiling_kernel, dim3((unsigned)tiles), dim3(64), 0, stream, v, x, y, tiles);
+    };
+    for (int i = 0; i < warmup; ++i) launch();
     EventTimer t;
     for (int i = 0; i < reps; ++i) {
         t.begin(stream);
-        hipLaunchKernelGGL(stream_ceiling_kernel, dim3((unsigned)tiles), dim3(64), 0, stream, v, x, y, tiles);
+        launch();
         t.end(stream);
         ms_each[i] = t.elapsed_ms();
     }
@@ -128,15 +153,21 @@ extern "C" double spmv_amd_stream_ceiling(size_t rows, int warmup, int reps, flo
     device_release(v);
     device_release(x);
     device_release(y);
-    return 56.0 * (double)rows;
+    return (read_only ? 48.0 : 56.0) * (double)rows;
+}
+
+extern "C" double spmv_amd_stream_ceiling(size_t rows, int warmup, int reps, float* ms_each) {
+    return stream_probe(rows, warmup, reps, ms_each, false);
 }
 
 // The same probe for another format's byte mix: mix 1 = CSR at five entries per row (80 B/row: values, column indices,
-// row pointers, x, y), mix 2 = ELLPACK width 5 (76 B/row: values, column indices, x, y), mix 0 = the STENCIL5 mix above.
+// row pointers, x, y), mix 2 = ELLPACK width 5 (76 B/row: values, column indices, x, y), mix 0 = the STENCIL5 mix above,
+// mix 3 = the STENCIL5 arrays read only (48 B/row).
 // Returns the bytes one launch moves, or 0.
 extern "C" double spmv_amd_stream_ceiling_mix(int mix, size_t rows, int warmup, int reps, float* ms_each) {
     using namespace spmv_amd;
     if (mix == 0) return spmv_amd_stream_ceiling(rows, warmup, reps, ms_each);
+    if (mix == 3) return stream_probe(rows, warmup, reps, ms_each, true);
     if (mix != 1 && mix != 2) return 0.0;
     const size_t tiles = rows / kRowsPerWave;
     if (tiles == 0 || tiles > 0x7fffffffULL || reps < 1) return 0.0;
