@@ -17,19 +17,27 @@ configuration of reference docs/PROBLEM_SIZE_SCALING_RESULTS.md:40-47, on N row 
             p.Ap partials): algorithmic bytes of one launch (8*nnz + 8*cols + 8*rows of the slab,
             SURVEY.md 8d) / its average duration, from HIP events recorded on the solver's stream
             around every in-loop launch of the timed steps. Peak 8 TB/s (MI355X_MICROARCH.md).
-            ceiling_measured / frac_of_ceiling: the same byte mix (48 B read : 8 B written per row) streamed
-            with ideal accesses on this GPU in this run (csrc/stream_ceiling.hip), so the line carries the
-            fraction of the data-sheet peak AND of what the part sustains. traffic: fabric bytes per launch
-            from profiles/hbm_traffic.json, only while that file's hash of csrc/spmv_kernels.hip matches.
+            `frac` is of that peak and is the figure to read. Three yardsticks measured in the same run say what
+            the part sustains for streams: mix_probe_gbs (48 B read : 8 B written per row with ideal accesses,
+            csrc/stream_ceiling.hip), read_only_probe_gbs (the same arrays, read only) and the rate the loop's own
+            r update reaches (stages.update_r_us); best_stream_gbs_this_run is their maximum and
+            frac_of_best_stream the SpMV's share of it -- a yardstick, not a ceiling. traffic: fabric bytes per
+            launch from profiles/hbm_traffic.json, only while that file's hash of csrc/spmv_kernels.hip matches.
+            spmv_standalone: BASELINE's FIRST metric, the `spmv` leg below in brief (median ms, effective GB/s by
+            both of the reference's formulas, algorithmic GB/s, frac of peak); placement: what set-up placement did.
   spmv      (N = 1 only; runs AFTER the CG leg, so that the solver's slab is the first large allocation of the process)
             the reference's other headline: stencil5-csr operator on its own staging vectors (the ones run_timed's kernel
             works on), x = 1, 5 warm-ups + 10 timed launches, >2 sigma outliers dropped, median -> "effective" GB/s by both
             of the reference's byte formulas (spmv_metrics.cu:85-101 and the published 12*nnz+16*rows).
   scaling_probe  (N = 1 only; a PROJECTION, never part of `value`) the real per-rank slabs of a 2 / 4 / 8-GPU
             run of this problem (rows [r*N/P, (r+1)*N/P), 160 KB halos), edge rank and a two-neighbour rank,
-            each solved for the full iteration count on this GPU through the complete RCCL pipeline with the
-            rank as its own neighbour. The latency of an all-reduce BETWEEN devices cannot be measured on one
-            GPU: the efficiency is given for a range of latencies.
+            each in a FRESH process of its own (what a rank of a real job is: inside one process the second slab
+            inherits the first one's freed memory and measured up to 3 % off either way, profiles/r05_slab_attribution.txt),
+            solved for the full iteration count on this GPU through the complete RCCL pipeline with the rank as its
+            own neighbour. Clock: the solver's timed region (HIP events from the barrier to the end of the x flush,
+            the reference's :405-413 -> :728-731), median of 5 solves, for the slab and for the full problem alike.
+            The latency of an all-reduce BETWEEN devices cannot be measured on one GPU: the efficiency is given for a
+            range of latencies.
   cpu_baseline  (N = 1, rank 0) the serial C oracle (oracle/spmv_oracle.c, 1 core) on a bounded sample
             (10 000 x 10 000 = 1/4 of the rows): its CG, scaled by rows to the 400 M-unknown problem
             (~10 s), and `spmv` = its STENCIL5 and CSR SpMV (1 warm-up + 3 runs, median) in the reference's
@@ -41,7 +49,7 @@ configuration of reference docs/PROBLEM_SIZE_SCALING_RESULTS.md:40-47, on N row 
             the slab does the same for its coefficient stream, which must not share Ap's class (csrc/cg_slab.hip). Addresses only, same bits.
 
   parity_vs_golden  every run, every N: the residual history of the timed solves against the committed CPU-oracle
-            history of the same grid (tests/golden/known_answers.json: 3, 81, 512, 2000, 10000, 20000); above 1e-10
+            history of the same grid (tests/golden/known_answers.json: 3, 81, 512, 2000, 10000, 15000, 20000); above 1e-10
             relative, or on another iteration count, the run is UNMEASURED (exit 3), whatever it timed.
   breakdown per rank, from ONE extra solve after the timed region with HIP events at the stage boundaries of every
             iteration and around every halo exchange (no host syncs, overlap intact): interior SpMV, wait for the halo +
@@ -56,8 +64,8 @@ configuration of reference docs/PROBLEM_SIZE_SCALING_RESULTS.md:40-47, on N row 
 
 Wall time, worst case of every DEFAULT path (the driver's limit for this file is 600 s):
   N = 1   torch import + library (<= 120 s on a fresh box) + SpMV leg (~5 s) + (W + K + 1) solves of ~0.11 s + stream ceiling
-          (~0.1 s) + scaling probe in a child, ended after --probe-timeout = 150 s (~10 s when healthy) + CPU baseline
-          (~25 s of host work, no GPU) : < 330 s, ~25 s when healthy (BENCH_r03: 25.2 s).
+          (~0.2 s) + scaling probe (8 role processes one after the other under one child, the child ended after
+          --probe-timeout = 240 s; ~60 s when healthy) + CPU baseline (~25 s of host work, no GPU) : < 420 s, ~110 s when healthy.
   N > 1   the same import + rendezvous (gloo, 120 s limit for the store) + (W + K + 1) solves + nothing else: rank 0 prints
           the line as soon as the ranks have agreed on the measured leg. Every wait on a peer inside a solve ends after
           SPMV_AMD_WATCHDOG_S = 60 s with a report; gloo collectives give up after 180 s; a self-launched run is ended by
@@ -165,13 +173,14 @@ def spmv_headline(B, n, warmup=5, runs=10):
     }
 
 
-def stream_ceiling(B, rows=200_000_000, reps=20):
-    """The 48:8 read:write stream probe on the benchmark's data (csrc/stream_ceiling.hip), ~100 ms of GPU time at 4e8 rows."""
-    ms, nbytes = B.stream_ceiling(rows, warmup=3, reps=reps)
+def stream_ceiling(B, rows=200_000_000, reps=20, mix="stencil5"):
+    """The stream probes on the benchmark's data (csrc/stream_ceiling.hip), ~100 ms of GPU time each at 4e8 rows."""
+    ms, nbytes = B.stream_ceiling(rows, warmup=3, reps=reps, mix=mix)
     med, _ = reference_stats(ms)
+    what = {"stencil5": "48 B read : 8 B written per row", "read-only": "48 B read per row, one 8-byte partial per wave written"}[mix]
     return {"gbs": nbytes / (med / 1e3) / 1e9, "median_ms": med, "rows": rows, "bytes_per_launch": nbytes, "launches": reps,
-            "what": "48 B read : 8 B written per row, coalesced 8-byte nontemporal accesses, one-wave workgroups, "
-                    "coefficients [-1 -1 5 -1 -1] and x = 1 (non-zero data), no neighbour reads"}
+            "what": what + ", coalesced 8-byte nontemporal accesses, one-wave workgroups, coefficients [-1 -1 5 -1 -1] and x = 1 "
+                           "(non-zero data), no neighbour reads"}
 
 
 def cpu_model():
@@ -248,71 +257,79 @@ def cpu_baseline(sample_grid, full_rows):
     return rec
 
 
-def scaling_probe(B, torch, grid, full_ms, full_iterations, steps=5):
-    """What ONE GPU can say about strong scaling (N = 1 only; a projection). For P = 2, 4, 8 the real slab of the
-    edge rank (one neighbour) and of a middle rank (two neighbours) of this grid -- rows [r*N/P, (r+1)*N/P), same CSR
-    bytes, `grid`-double halos -- is solved for exactly `full_iterations` iterations through the complete multi-rank
-    pipeline over RCCL with the rank as its own neighbour (halo ncclSend / ncclRecv on the side stream under the
-    interior SpMV, split SpMV launches, both ncclAllReduce calls issued with one rank). The slab's neighbours being
-    its own grid rows, the system solved is a periodic strip, not the global one: only the time is used.
-    Not measured: the latency of a send/recv and of an all-reduce BETWEEN devices."""
-    out = {"method": "real per-rank slabs of the headline grid on one GPU: full RCCL pipeline with the rank as its own neighbour, "
-                     f"{full_iterations} iterations per solve (tolerance 0), {steps} timed solves after 2 warm-ups",
-           "projection": True, "measured_between_devices": False, "grid": grid, "full_problem_ms_per_solve": full_ms,
-           "allreduces_per_solve": 2 * full_iterations + 1, "slabs": []}
-    saved = {k: os.environ.get(k) for k in ("SPMV_AMD_SELF_NEIGHBOUR", "SPMV_AMD_FORCE_COLLECTIVES")}
+def probe_role(B, grid, P, r, full_iterations, mailbox, steps=5):
+    """ONE stand-in slab (rank r of P of this grid) in THIS process, which was started for it: the complete multi-rank pipeline
+    over RCCL with the rank as its own neighbour (halo ncclSend / ncclRecv on the side stream under the interior SpMV, split SpMV
+    launches, both all-reduces issued with one rank), `full_iterations` iterations per solve (tolerance 0: the slab's neighbours
+    being its own grid rows, the system solved is a periodic strip, not the global one -- only the time is used)."""
     os.environ["SPMV_AMD_SELF_NEIGHBOUR"] = os.environ["SPMV_AMD_FORCE_COLLECTIVES"] = "1"
-    try:
-        comm = B.Comm.rccl(0, 1, B.Comm.unique_id())
-    finally:
-        for k, v in saved.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+    comm = B.Comm.rccl(0, 1, B.Comm.unique_id())
     if comm is None:
-        out["error"] = "RCCL communicator could not be created"
-        return out
-
-    def run(P, r):
-        slab = B.CgSlab.stencil5_as(grid, r, P, comm)
-        for _ in range(2):
-            st = slab.solve(max_iters=full_iterations, tol=0.0)
-        torch.cuda.synchronize()
+        return {"error": "RCCL communicator could not be created"}
+    if mailbox and not comm.mailbox_enable():
+        comm.destroy()
+        return {"error": "peer mailbox could not be set up"}
+    slab = B.CgSlab.stencil5_as(grid, r, P, comm)
+    for _ in range(2):
+        st = slab.solve(max_iters=full_iterations, tol=0.0)
+    B.lib().spmv_amd_device_synchronize()
+    wall, event, spmv_ms = [], [], 0.0
+    for _ in range(steps):
         t0 = time.perf_counter()
-        spmv_ms = 0.0
-        for _ in range(steps):
-            st = slab.solve(max_iters=full_iterations, tol=0.0)
-            spmv_ms += st.time_spmv_ms
-        torch.cuda.synchronize()
-        ms = (time.perf_counter() - t0) / steps * 1e3
-        rec = {"as_rank": r, "neighbours": (1 if r > 0 else 0) + (1 if r < P - 1 else 0), "row_offset": slab.row_offset, "rows": slab.n_local,
-               "halo_doubles": grid, "iterations": st.iterations, "ms_per_solve": ms, "us_per_iteration": ms / max(st.iterations, 1) * 1e3,
-               "spmv_us_per_launch": spmv_ms / steps / max(st.iterations, 1) * 1e3}
-        try:  # where this slab's iteration goes: one more solve with stage-boundary events (no host syncs)
-            _, tl = slab.timeline_solve(max_iters=full_iterations, tol=0.0)
-            rec["stage_us"] = {k: round(v, 1) for k, v in tl.items() if k.endswith("_us")}
-        except Exception as e:
-            rec["stage_us"] = {"error": repr(e)}
-        slab.destroy()
-        return rec
+        st = slab.solve(max_iters=full_iterations, tol=0.0)
+        B.lib().spmv_amd_device_synchronize()
+        wall.append((time.perf_counter() - t0) * 1e3)
+        event.append(st.time_total_ms)
+        spmv_ms += st.time_spmv_ms
+    ms = float(np.median(event))
+    rec = {"as_rank": r, "neighbours": (1 if r > 0 else 0) + (1 if r < P - 1 else 0), "row_offset": slab.row_offset, "rows": slab.n_local,
+           "halo_doubles": grid, "iterations": st.iterations, "ms_per_solve": ms, "wall_ms_per_solve": float(np.median(wall)),
+           "us_per_iteration": ms / max(st.iterations, 1) * 1e3, "spmv_us_per_launch": spmv_ms / steps / max(st.iterations, 1) * 1e3,
+           "spmv_us_per_launch_covers": "the interior rows' launch (all but one or two grid rows of the slab), timed every 7th iteration"}
+    try:  # where this slab's iteration goes: one more solve with stage-boundary events (no host syncs)
+        _, tl = slab.timeline_solve(max_iters=full_iterations, tol=0.0)
+        rec["stage_us"] = {k: round(v, 1) for k, v in tl.items() if k.endswith("_us")}
+    except Exception as e:
+        rec["stage_us"] = {"error": repr(e)}
+    slab.destroy()
+    comm.destroy()
+    return rec
+
+
+def scaling_probe(grid, full_event_ms, full_iterations, role_timeout_s=45.0):
+    """What ONE GPU can say about strong scaling (N = 1 only; a projection). For P = 2, 4, 8 the real slab of the edge rank (one
+    neighbour) and of a middle rank (two neighbours) of this grid -- rows [r*N/P, (r+1)*N/P), same CSR bytes, `grid`-double
+    halos -- each solved in a FRESH process (probe_role). This function touches no GPU: it starts the role processes one after
+    the other. Not measured: the latency of a send/recv and of an all-reduce BETWEEN devices."""
+    out = {"method": "real per-rank slabs of the headline grid on one GPU, each in a fresh process of its own: full RCCL pipeline with the "
+                     f"rank as its own neighbour, {full_iterations} iterations per solve (tolerance 0), median of 5 solves after 2 warm-ups",
+           "clock": "the solver's timed region (HIP events: barrier -> end of the x flush), for the slabs and for the full problem",
+           "projection": True, "measured_between_devices": False, "grid": grid, "full_problem_ms_per_solve": full_event_ms,
+           "allreduces_per_solve": 2 * full_iterations + 1, "slabs": []}
+
+    def run(P, r, mailbox=False):
+        argv = [sys.executable, os.path.abspath(__file__), "--grid", str(grid), "--probe-role", str(P), str(r), str(full_iterations), "1" if mailbox else "0"]
+        return run_child_for_record(argv, dict(os.environ), role_timeout_s, f"probe role {r} of {P}")
 
     # the headline path of a multi-GPU run: two ncclAllReduce launches per iteration (with one rank: their launch cost only)
     out["allreduce_path"] = "ncclAllReduce (one rank: launch cost only)"
     for P in (2, 4, 8):
         ranks = sorted({0, min(P - 1, max(1, P // 2 - 1))})  # edge rank and (P > 2) one with two neighbours: 1 of 4, 3 of 8
         roles = [run(P, r) for r in ranks]
-        slowest = max(v["ms_per_solve"] for v in roles)
-        eff = {f"{lat}us": full_ms / (P * (slowest + out["allreduces_per_solve"] * lat / 1e3)) for lat in (0, 5, 10, 25, 50)}
-        out["slabs"].append({"gpus": P, "roles": roles, "slowest_role_ms_per_solve": slowest,
-                             "ideal_ms_per_solve": full_ms / P, "projected_efficiency_by_allreduce_latency": eff})
-    if comm.mailbox_enable():
-        # the same P = 8 slabs with the peer mailbox (world = 1: its launch cost, no peer latency): what folding the two
-        # all-reduces into the reduction kernels saves on this GPU
-        roles = [run(8, r) for r in (0, 3)]
+        entry = {"gpus": P, "roles": roles, "ideal_ms_per_solve": full_event_ms / P}
+        if all("ms_per_solve" in v for v in roles):
+            slowest = max(v["ms_per_solve"] for v in roles)
+            entry["slowest_role_ms_per_solve"] = slowest
+            entry["projected_efficiency_by_allreduce_latency"] = {
+                f"{lat}us": full_event_ms / (P * (slowest + out["allreduces_per_solve"] * lat / 1e3)) for lat in (0, 5, 10, 25, 50)}
+        out["slabs"].append(entry)
+    # the same P = 8 slabs with the peer mailbox (world = 1: its launch cost, no peer latency): what folding the two
+    # all-reduces into the reduction kernels saves on this GPU
+    roles = [run(8, r, mailbox=True) for r in (0, 3)]
+    if all("ms_per_solve" in v for v in roles):
         out["p8_with_peer_mailbox"] = {"roles": roles, "slowest_role_ms_per_solve": max(v["ms_per_solve"] for v in roles)}
-        comm.mailbox_disable()
-    comm.destroy()
+    else:
+        out["p8_with_peer_mailbox"] = {"roles": roles}
     return out
 
 
@@ -410,7 +427,7 @@ def parity_vs_golden(n, hist, iterations):
     except (OSError, ValueError) as e:
         return {"available": False, "note": f"golden fixture unreadable: {e!r}"}
     if case is None:
-        return {"available": False, "note": f"no committed golden history for grid {n} (fixtures exist for 3, 81, 512, 2000, 10000, 20000)"}
+        return {"available": False, "note": f"no committed golden history for grid {n} (fixtures exist for 3, 81, 512, 2000, 10000, 15000, 20000)"}
     g = np.asarray(case["cg"]["history"], dtype=np.float64)
     h = np.asarray(hist, dtype=np.float64)
     k = min(len(g), len(h))
@@ -547,6 +564,7 @@ def measure_leg(c, allreduce_kind):
             print(f"bench.py: dot-product all-reduce: {allreduce}", file=sys.stderr)
     slab = B.CgSlab.stencil5(n, comm)
     placement = slab.placement()  # set-up work, outside the timed region (csrc/cg_slab.hip, place_coefficients)
+    tile_runs = slab.tile_runs()  # ditto: row-lds tiles per XCD and run, the rule's neighbours timed at creation
 
     def barrier():
         if multi:
@@ -562,11 +580,12 @@ def measure_leg(c, allreduce_kind):
         barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        spmv_ms, spmv_launches = 0.0, 0
+        spmv_ms, spmv_launches, event_ms = 0.0, 0, []
         for _ in range(args.steps):
             st = slab.solve()
             spmv_ms += st.time_spmv_ms
             spmv_launches += st.iterations
+            event_ms.append(st.time_total_ms)
         torch.cuda.synchronize()
         barrier()
         dt = time.perf_counter() - t0
@@ -593,8 +612,9 @@ def measure_leg(c, allreduce_kind):
                "final_residual": st.residual_norm, "history": [float(v) for v in hist], "rank_ms": rank_ms, "parity_vs_golden": parity,
                "ranks_agree_on_history": True if multi else None, "breakdown": breakdown, "variant": slab.variant(),
                "local_rows": slab.n_local, "local_nnz": slab.local_nnz, "spmv_ms": spmv_ms, "spmv_launches": spmv_launches,
+               "event_ms_per_solve": float(np.median(event_ms)),
                "rccl_ranks": comm.transport_ranks() if (comm is not None and transport == "rccl") else 0,
-               "placement": placement}
+               "placement": placement, "tile_runs": tile_runs}
     finally:
         slab.destroy()
         if comm is not None:
@@ -679,20 +699,22 @@ def main():
                     help="multi-rank runs, opt-in: after the headline line is printed, repeat the K steps with the other all-reduce path in child processes")
     ap.add_argument("--no-allreduce-ab", action="store_true", help="(accepted for older command lines; the second leg is off unless --allreduce-ab)")
     ap.add_argument("--ab-timeout", type=float, default=180.0, help="--allreduce-ab: seconds before the child leg is ended")
-    ap.add_argument("--probe-timeout", type=float, default=150.0, help="N = 1: seconds before the scaling-probe child is ended")
+    ap.add_argument("--probe-timeout", type=float, default=240.0, help="N = 1: seconds before the scaling-probe child is ended")
     ap.add_argument("--launch-timeout", type=float, default=420.0,
                     help="self-launch only: seconds before the parent ends the ranks (below the driver's 600 s limit for this file)")
     ap.add_argument("--launch-grace", type=float, default=90.0,
                     help="self-launch only: seconds the other ranks get to report after one rank has exited non-zero")
     ap.add_argument("--scaling-probe-only", nargs=2, metavar=("FULL_MS", "FULL_ITERATIONS"), default=None,
                     help="(internal) run only the scaling probe and print its JSON object")
+    ap.add_argument("--probe-role", nargs=4, metavar=("P", "R", "ITERATIONS", "MAILBOX"), default=None,
+                    help="(internal) one stand-in slab of the scaling probe in this process; prints its record")
     ap.add_argument("--leg-only", choices=["rccl", "mailbox"], default=None,
                     help="(internal) run one measurement leg with that all-reduce path and print its record")
     args = ap.parse_args()
     if args.steps < 1 or args.warmup < 0 or args.gpus < 1 or args.grid < 2:
         ap.error("--steps >= 1, --warmup >= 0, --gpus >= 1 and --grid >= 2 are required")
 
-    if args.scaling_probe_only is None and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ and args.gpus > 1:
+    if args.scaling_probe_only is None and args.probe_role is None and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(self_launch(args))
 
     # The library prints progress lines the way the reference harness does ("[stencil5-csr] Cleaning up", ...):
@@ -704,16 +726,18 @@ def main():
     def emit(obj):
         os.write(json_fd, (json.dumps(obj) + "\n").encode())
 
-    if args.scaling_probe_only is not None:
-        import torch
-
+    if args.scaling_probe_only is not None:  # starts the role processes; no torch, no GPU here
+        log_process("probe-child")
+        emit(scaling_probe(args.grid, float(args.scaling_probe_only[0]), int(args.scaling_probe_only[1])))
+        return
+    if args.probe_role is not None:
         B = load_binding()
         B.lib()
         B.require_gpu()
-        torch.cuda.set_device(0)
         B.lib().spmv_amd_set_device(0)
-        log_process("probe-child")
-        emit(scaling_probe(B, torch, args.grid, float(args.scaling_probe_only[0]), int(args.scaling_probe_only[1])))
+        log_process("probe-role")
+        P, r, its, mailbox = (int(v) for v in args.probe_role)
+        emit(probe_role(B, args.grid, P, r, its, mailbox != 0))
         return
 
     c = setup_process(args)
@@ -809,13 +833,17 @@ def main():
         "avg_launch_ms": avg_spmv_ms, "launches_timed": leg["spmv_launches"], "traffic_note": traffic_note,
     }
     if rank == 0 and not args.no_ceiling and local_rows >= 1_000_000:
-        try:
-            ceil = stream_ceiling(B, rows=local_rows)  # same row count as the slab: the rate depends on it (6.2-6.4 TB/s for 2e8 / 4e8 rows)
-            roofline["ceiling_measured"] = ceil["gbs"]
-            roofline["frac_of_ceiling"] = achieved / ceil["gbs"]
-            roofline["ceiling_probe"] = ceil
-        except Exception as e:
-            roofline["ceiling_probe"] = {"error": repr(e)}
+        # yardsticks, not ceilings: what THIS run sustains for ideal streams of the slab's row count (the rate depends on it:
+        # 6.2-6.4 TB/s for 2e8 / 4e8 rows). In round 4's run the loop's r update streamed 7 % faster than the 48:8 probe.
+        for key, mix in (("mix_probe", "stencil5"), ("read_only_probe", "read-only")):
+            try:
+                probe = stream_ceiling(B, rows=local_rows, mix=mix)
+                roofline[key + "_gbs"] = probe["gbs"]
+                roofline[key] = probe
+            except Exception as e:
+                roofline[key] = {"error": repr(e)}
+        if "mix_probe_gbs" in roofline:
+            roofline["frac_of_mix_probe"] = achieved / roofline["mix_probe_gbs"]
 
     # every streaming stage of the loop against the same peak, from rank 0's stage timeline (one extra solve, HIP events; a stage
     # includes the queue gap in front of its kernel): algorithmic bytes per row of the stage / its duration
@@ -834,6 +862,26 @@ def main():
                                                       "frac": bpr * t0_["rows"] / (t0_["final_x_flush_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS}
     except Exception as e:  # evidence only
         roofline["stages"] = {"error": repr(e)}
+    rates = {"mix_probe_gbs": roofline.get("mix_probe_gbs"), "read_only_probe_gbs": roofline.get("read_only_probe_gbs"),
+             "update_r_in_the_loop_gbs": (roofline.get("stages") or {}).get("update_r_us", {}).get("gbs")}
+    rates = {k: v for k, v in rates.items() if isinstance(v, (int, float)) and v > 0}
+    if rates:
+        best = max(rates, key=rates.get)
+        roofline["best_stream_gbs_this_run"] = rates[best]
+        roofline["best_stream_is"] = best
+        roofline["frac_of_best_stream"] = achieved / rates[best]
+    if leg.get("placement") is not None:
+        roofline["placement"] = {"coefficient_stream": leg["placement"]}
+    if leg.get("tile_runs") is not None:
+        roofline["tiles_per_xcd_run"] = leg["tile_runs"]
+    if spmv is not None and "median_ms" in spmv:
+        # BASELINE.json's FIRST metric inside an object the driver keeps: SpMV effective GB/s (fp64, 20k x 20k STENCIL5), the
+        # reference's rule (src/main/main.cu:158-187: 5 warm-ups, 10 launches, > 2 sigma dropped, median) and byte formulas
+        # (src/spmv/spmv_metrics.cu:85-101; the published 12 nnz + 16 rows)
+        roofline["spmv_standalone"] = {k: spmv[k] for k in ("operator", "variant", "grid", "median_ms", "effective_gbs", "effective_gbs_published_formula",
+                                                             "algorithmic_gbs", "gflops", "vs_a100_published")} | {"frac": spmv["frac_of_hbm_peak"]}
+        if spmv.get("output_placement") is not None:
+            roofline.setdefault("placement", {})["spmv_output_vector"] = spmv["output_placement"]
 
     devices = gather(c, {"rank": rank, "device": c.device_index, "pci_bus_id": c.pci})
 
@@ -845,6 +893,8 @@ def main():
                    vs_baseline=value / A100_CG_ITERS_PER_S[world] if headline else None,
                    baseline_note="reference's published CG iters/s on the same problem at the same GPU count, A100-SXM4-80GB (BASELINE.md); no MI355X number is published",
                    config={"workload": f"CG on the {n}x{n} 5-point stencil ({rows} unknowns, {nnz} nnz), b=1, x0=0, tol 1e-6",
+                           "spmv_effective_gbs": None if spmv is None or "effective_gbs" not in spmv else
+                           {"reference_formula": spmv["effective_gbs"], "published_formula": spmv["effective_gbs_published_formula"], "median_ms": spmv["median_ms"]},
                            "grid": n, "unknowns": rows, "nnz": nnz, "partition": f"{world} row slab(s)", "transport": transport,
                            "iterations_per_solve": iterations, "converged": leg["converged"], "final_residual": leg["final_residual"],
                            "residual_history": leg["history"]},
@@ -883,7 +933,7 @@ def main():
     if rank == 0 and not args.no_scaling_probe and n >= 8192:
         # in a child process: whatever happens to it, the benchmark line is printed
         out["scaling_probe"] = run_child_for_record(
-            [sys.executable, os.path.abspath(__file__), "--grid", str(n), "--scaling-probe-only", repr(out["ms_per_step"]), str(iterations)],
+            [sys.executable, os.path.abspath(__file__), "--grid", str(n), "--scaling-probe-only", repr(leg["event_ms_per_solve"]), str(iterations)],
             dict(os.environ), args.probe_timeout, "scaling probe")
     if rank == 0 and not args.no_cpu_baseline:
         try:

@@ -96,6 +96,7 @@ struct SpmvAmdCgSlab {
     double* vec_arena = nullptr;
     // place_coefficients: {0, candidates timed, SpMV ms before, SpMV ms kept}
     std::vector<double> placement;
+    std::vector<double> tile_runs;  // tune_tile_runs: {rule, kept, SpMV ms with the rule, ms kept}; empty = did not run
     double* p_alloc = nullptr;  // [pad | prev halo | local | next halo]
     double* p = nullptr;        // local part of the CURRENT direction vector, 16-byte aligned
     // Direction ring (deferred x update). With ring_slots > 1 the direction update is written out of place into
@@ -211,6 +212,7 @@ void adopt_operator(SpmvAmdCgSlab* s, SpmvOperator* op) {
 }
 
 void place_coefficients(SpmvAmdCgSlab* s);  // below
+void tune_tile_runs(SpmvAmdCgSlab* s);
 
 void make_common(SpmvAmdCgSlab* s) {
     const size_t nl = (size_t)s->n_local;
@@ -348,6 +350,7 @@ void make_common(SpmvAmdCgSlab* s) {
         s->fuse_init_residual = s->plan_whole.variant == Stencil5Variant::RowLds && rowlds(s->plan_interior) && rowlds(s->plan_head) && rowlds(s->plan_tail);
     }
     place_coefficients(s);
+    tune_tile_runs(s);
     launch_fill(s->b, nl, 1.0, s->compute);   // default right-hand side b = 1
     launch_fill(s->x0, nl, 0.0, s->compute);  // default initial guess x0 = 0
     HIP_CHECK(hipDeviceSynchronize());
@@ -414,6 +417,30 @@ void place_coefficients(SpmvAmdCgSlab* s) {
     for (double* a : s->ring_alloc) HIP_CHECK(hipMemsetAsync(a, 0, s->slot_doubles * sizeof(double), q));
     HIP_CHECK(hipStreamSynchronize(q));
     s->placement = {0.0, (double)tried, before, s->A.values == original ? before : after};
+}
+
+// Row-lds tiles per XCD and run, by measurement on the slab's own vectors (device_runtime.hpp, tune_rowlds_xcd_run): the four
+// launch plans are then re-made with the run length kept. Their partial counts do not depend on it.
+void tune_tile_runs(SpmvAmdCgSlab* s) {
+    if (s->op != nullptr || s->ring.size() < 2) return;
+    const size_t nl = (size_t)s->n_local;
+    hipStream_t q = s->compute;
+    double* x = s->ring[1];
+    launch_fill(x, nl, 1.0, q);
+    HIP_CHECK(hipMemsetAsync(&s->d_s->converged, 0, sizeof(int), q));
+    double rec[4] = {0, 0, 0, 0};
+    const int run = tune_rowlds_xcd_run(s->A.view, s->shape, x, s->Ap, s->fused_dot ? s->partials_spmv : nullptr, q, rec);
+    HIP_CHECK(hipMemsetAsync(s->ring_alloc[1], 0, s->slot_doubles * sizeof(double), q));
+    HIP_CHECK(hipStreamSynchronize(q));
+    if (run <= 0) return;
+    s->shape.knobs.rowlds_group = run;
+    const int lo = s->has_prev ? s->halo : 0, hi = s->n_local - (s->has_next ? s->halo : 0);
+    const auto plan = [&](int a, int b) { return plan_stencil5(s->A.view, a, b > a ? b : a, Stencil5Variant::Auto, s->shape); };
+    s->plan_whole = plan(0, s->n_local);
+    s->plan_interior = plan(lo, hi);
+    s->plan_head = plan(0, lo);
+    s->plan_tail = plan(hi, s->n_local);
+    s->tile_runs.assign(rec, rec + 4);
 }
 
 bool partition_ok(const SpmvAmdComm* comm, int n, int grid, int n_local) {
@@ -1171,6 +1198,13 @@ extern "C" const char* spmv_amd_cg_slab_variant(const SpmvAmdCgSlab* s) { return
 extern "C" int spmv_amd_cg_slab_placement(const SpmvAmdCgSlab* s, double* out, int cap) {
     const int count = (int)s->placement.size();
     for (int i = 0; i < count && i < cap; ++i) out[i] = s->placement[i];
+    return count;
+}
+// Row-lds tiles per XCD and run as tuned at creation: {rule, kept, SpMV ms with the rule, ms kept}. Returns 4, or 0 if the
+// trial did not run (small slab, another kernel, SPMV_AMD_ROWLDS_GROUP set).
+extern "C" int spmv_amd_cg_slab_tile_runs(const SpmvAmdCgSlab* s, double* out, int cap) {
+    const int count = (int)s->tile_runs.size();
+    for (int i = 0; i < count && i < cap; ++i) out[i] = s->tile_runs[i];
     return count;
 }
 

@@ -33,6 +33,42 @@ LaunchShape current_launch_shape() {
     return shape;
 }
 
+int tune_rowlds_xcd_run(const SlabCsr& m, const LaunchShape& shape, const double* x, double* y, double* d_partials, hipStream_t stream,
+                        double* record) {
+    if (shape.knobs.rowlds_group > 0 || m.n_local < (16 << 20)) return 0;
+    LaunchShape trial = shape;
+    const Stencil5Plan base = plan_stencil5(m, 0, m.n_local, Stencil5Variant::Auto, trial);
+    if (base.variant != Stencil5Variant::RowLds) return 0;
+    const int rule = base.xcd_run;
+    int cand[6] = {rule, rule - 1, rule + 1, rule - 2, rule + 2, 4};
+    EventTimer timer;
+    double best_ms = 0.0, rule_ms = 0.0;
+    int best = rule;
+    for (int k = 0; k < 6; ++k) {
+        const int g = cand[k];
+        bool seen = g < 1 || g > 64;
+        for (int j = 0; j < k; ++j) seen = seen || cand[j] == g;
+        if (seen) continue;
+        trial.knobs.rowlds_group = g;
+        const Stencil5Plan p = plan_stencil5(m, 0, m.n_local, Stencil5Variant::RowLds, trial);
+        float ms[3];
+        for (int i = 0; i < 4; ++i) {
+            timer.begin(stream);
+            (void)launch_stencil5_spmv(m, p, x, y, 1.0, d_partials, nullptr, false, stream);
+            timer.end(stream);
+            const float t = timer.elapsed_ms();
+            if (i > 0) ms[i - 1] = t;
+        }
+        const double med = ms[0] < ms[1] ? (ms[1] < ms[2] ? ms[1] : (ms[0] < ms[2] ? ms[2] : ms[0])) : (ms[0] < ms[2] ? ms[0] : (ms[1] < ms[2] ? ms[2] : ms[1]));
+        if (g == rule) rule_ms = med;
+        if (best_ms == 0.0 || med < best_ms) best_ms = med, best = g;
+    }
+    HIP_CHECK(hipGetLastError());
+    if (best_ms > 0.995 * rule_ms) best = rule, best_ms = rule_ms;  // within noise: keep the rule
+    if (record) record[0] = rule, record[1] = best, record[2] = rule_ms, record[3] = best_ms;
+    return best;
+}
+
 // values | col_idx | row_ptr in ONE allocation, values first: the CSR kernels read values[e] and col_idx[e] in lock step,
 // and lock-step streams in different 32 GiB classes of the address space run ~6 % slower (device_runtime.hpp).
 // separate_values (solver slabs whose coefficient stream may be re-placed, cg_slab.hip): `values` is an allocation of its

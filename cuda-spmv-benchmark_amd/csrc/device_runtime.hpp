@@ -118,6 +118,14 @@ inline T* device_alloc_best_of(size_t count, size_t min_count, Cost&& cost_ms, i
     return cand[best];
 }
 
+// Row-lds tile -> XCD run length by measurement (round 5; spmv_kernels.hip, rowlds_xcd_run_rule has the why): times the whole
+// slab's SpMV on (x, y) for the rule's neighbours and for 4, and returns the fastest run length -- 0 where tuning does not
+// apply (not a row-lds slab, fewer than 16 Mi rows, SPMV_AMD_ROWLDS_GROUP forces a value). Set-up work: the mapping of
+// workgroups to tiles is a performance choice only, results and partial slots do not depend on it.
+// record (optional, 4 doubles): {rule, kept, ms with the rule, ms kept}.
+int tune_rowlds_xcd_run(const SlabCsr& m, const LaunchShape& shape, const double* x, double* y, double* d_partials, hipStream_t stream,
+                        double* record = nullptr);
+
 // Pair of events for on-stream timing of one region.
 struct EventTimer {
     hipEvent_t start = nullptr, stop = nullptr;

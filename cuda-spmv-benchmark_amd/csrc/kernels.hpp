@@ -82,6 +82,7 @@ struct Stencil5Plan {
 };
 Stencil5Plan plan_stencil5(const SlabCsr& m, int first_row, int last_row, Stencil5Variant variant,
                            const LaunchShape& shape);
+int rowlds_xcd_run_rule(int n);  // the untuned run length of row-lds tiles per XCD for an n x n grid
 // The first SpMV of a CG solve fused with the initial residual (row-lds plans only): instead of storing y = A x the
 // launch writes r = b - A x and p = r and one partial of r.r per wave into d_dot_partials.
 struct ResidualOut {

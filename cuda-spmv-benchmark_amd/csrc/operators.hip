@@ -39,6 +39,8 @@ struct CsrBackedOperator {
     CsrVariant csr_variant = CsrVariant::Auto;
     const char* variant_name = "uninitialised";
 
+    int tuned_run = 0;         // stencil5-csr: row-lds tiles per XCD and run kept by the set-up trial (0 = not tried yet, -1 = does not apply)
+    double tuning[4] = {0, 0, 0, 0};  // {rule, kept, ms with the rule, ms kept}
     int y_candidates = 1;      // output placement: candidates timed for dY, and what the choice was worth (device_runtime.hpp)
     double y_gain = 1.0;
     void alloc_vectors() {
@@ -99,6 +101,7 @@ struct CsrBackedOperator {
         device_release(dX);
         device_release(dY);
         ready = false;
+        tuned_run = 0;
         variant_name = "uninitialised";
     }
 };
@@ -112,10 +115,23 @@ void stencil_pick_variant() {
     g_stencil.shape = current_launch_shape();
     g_stencil.plan = plan_stencil5(g_stencil.A.view, 0, g_stencil.rows, g_stencil.stencil_variant, g_stencil.shape);
     g_stencil.variant_name = g_stencil.plan.name;
-    if (g_stencil.dY == nullptr)  // once per init: the class a good output vector lies in does not depend on the variant
+    if (g_stencil.dY == nullptr) {  // once per init: the class a good output vector lies in does not depend on the variant
         g_stencil.place_output([](const double* x, double* y) {
             (void)launch_stencil5_spmv(g_stencil.A.view, g_stencil.plan, x, y, 1.0, nullptr, nullptr, false, kDefaultStream);
         });
+        g_stencil.tuned_run = 0;
+    }
+    // row-lds tiles per XCD and run: the rule's neighbours timed once per init on the operator's own vectors (device_runtime.hpp)
+    if (g_stencil.stencil_variant == Stencil5Variant::Auto || g_stencil.stencil_variant == Stencil5Variant::RowLds) {
+        if (g_stencil.tuned_run == 0 && g_stencil.shape.knobs.rowlds_group == 0) {
+            const int run = tune_rowlds_xcd_run(g_stencil.A.view, g_stencil.shape, g_stencil.dX, g_stencil.dY, nullptr, kDefaultStream, g_stencil.tuning);
+            g_stencil.tuned_run = run > 0 ? run : -1;
+        }
+        if (g_stencil.tuned_run > 0 && g_stencil.shape.knobs.rowlds_group == 0) {
+            g_stencil.shape.knobs.rowlds_group = g_stencil.tuned_run;
+            g_stencil.plan = plan_stencil5(g_stencil.A.view, 0, g_stencil.rows, g_stencil.stencil_variant, g_stencil.shape);
+        }
+    }
 }
 
 int stencil_init(MatrixData* mat) {
@@ -125,6 +141,9 @@ int stencil_init(MatrixData* mat) {
     stencil_pick_variant();
     printf("[stencil5-csr] %d rows, %d nnz, grid %dx%d, variant %s\n", csr_mat.nb_rows,
            csr_mat.nb_nonzeros, mat->grid_size, mat->grid_size, g_stencil.variant_name);
+    if (g_stencil.tuned_run > 0)
+        printf("[stencil5-csr] tiles per XCD and run: %d kept (rule %d: %.4f ms, kept %.4f ms)\n", g_stencil.tuned_run, (int)g_stencil.tuning[0],
+               g_stencil.tuning[2], g_stencil.tuning[3]);
     return 0;
 }
 

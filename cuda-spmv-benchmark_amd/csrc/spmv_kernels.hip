@@ -801,6 +801,19 @@ void launch_verify_stencil5_csr(const SlabCsr& m, int* d_mismatch, hipStream_t s
                        m, d_mismatch);
 }
 
+// Consecutive row-lds tiles one XCD takes of every run of 8 * run tiles. A run a little longer than one grid row lets an XCD
+// find the x lines of the rows above / below in its own L2 (it fetched them one grid row earlier); one that exceeds the grid
+// row by a whole XCD share hands every column to the NEXT XCD row after row and re-uses nothing. Measured per grid with
+// everything else held still (profiles/r05_size_sweep.txt): optimum at 0.92-1.07 grid rows, and spiky -- 12 500^2: 13 tiles
+// 1.386 ms, 14 tiles (round 2's "one grid row + ~1100 columns") 1.476 ms. The rule below is the starting point; operators
+// and solver slabs of >= 16 Mi rows time its neighbours at set-up and keep the fastest (tune_rowlds_xcd_run).
+int rowlds_xcd_run_rule(int n) {
+    if (n < 8000) return 4;  // small grids keep short runs (4096^2: 0.150 vs 0.165 ms)
+    const int tiles = (n + kLdsTileCols - 1) / kLdsTileCols;
+    const int run = (int)(1.05 * tiles / 8.0 + 0.5);
+    return run < 1 ? 1 : (run > 64 ? 64 : run);
+}
+
 Stencil5Plan plan_stencil5(const SlabCsr& m, int first_row, int last_row, Stencil5Variant variant,
                            const LaunchShape& shape) {
     Stencil5Plan p;
@@ -826,8 +839,7 @@ Stencil5Plan plan_stencil5(const SlabCsr& m, int first_row, int last_row, Stenci
             p.name = "stencil5/row-direct";
         } else {
             p.row_blocks = (n + kLdsTileCols - 1) / kLdsTileCols;  // column tiles (= workgroups) per grid row
-            // consecutive tiles per XCD: one grid row + ~1100 columns per run of 8 * xcd_run tiles (xcd_run_group)
-            p.xcd_run = knobs.rowlds_group > 0 ? knobs.rowlds_group : xcd_run_group(n, kLdsTileCols, 4);
+            p.xcd_run = knobs.rowlds_group > 0 ? knobs.rowlds_group : rowlds_xcd_run_rule(n);
             if (p.xcd_run < 1 || p.xcd_run > 64) p.xcd_run = 4;
             p.name = "stencil5/row-lds";
         }

@@ -352,6 +352,9 @@ void spmv_amd_cg_slab_set_timeline(SpmvAmdCgSlab* s, int on);
  * allocations one region apart: {0, candidates timed, SpMV ms before, SpMV ms kept}. Returns 4, or 0 if it did not run.
  * Addresses only: results never change; a candidate that does not fit ends the trial, never the process. */
 int spmv_amd_cg_slab_placement(const SpmvAmdCgSlab* s, double* out, int cap);
+/* Row-lds tiles per XCD and run, timed at creation on slabs of >= 16 Mi rows (csrc/device_runtime.hpp, tune_rowlds_xcd_run):
+ * {rule, kept, SpMV ms with the rule, ms kept}. Returns 4, or 0 if the trial did not run. Workgroup -> tile mapping only. */
+int spmv_amd_cg_slab_tile_runs(const SpmvAmdCgSlab* s, double* out, int cap);
 /* The timed in-loop SpMV launches of the last solve, one by one (ms, iteration order). Returns their number. */
 int spmv_amd_cg_slab_spmv_launch_ms(const SpmvAmdCgSlab* s, float* out, int cap);
 /* Loop options of an existing slab (A/B runs on the same allocations; results are bit-identical under every option):

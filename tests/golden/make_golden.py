@@ -11,7 +11,7 @@
                          the values recorded in SURVEY.md section 8c (computed there by an
                          independent numpy/scipy restatement), which the oracle must reproduce.
 
-Run from the repo root:  python tests/golden/make_golden.py [--with-10k] [--with-20k] [--out=<json>]
+Run from the repo root:  python tests/golden/make_golden.py [--with-10k] [--with-15k] [--with-20k] [--out=<json>]
 """
 import hashlib
 import json
@@ -79,6 +79,8 @@ def main():
         cases[f"{n}:{c}"] = case(n, c, -1.0)
     if "--with-10k" in sys.argv:
         cases["10000:5.0"] = case(10000, 5.0, -1.0)
+    if "--with-15k" in sys.argv:  # BASELINE config 5's grid; the reference publishes CG there too (docs/PROBLEM_SIZE_SCALING_RESULTS.md:31-38); ~25 GB of host memory
+        cases["15000:5.0"] = case(15000, 5.0, -1.0)
     if "--with-20k" in sys.argv:  # needs ~45 GB of host memory and about a minute: run on the GPU box's host
         cases["20000:5.0"] = case(20000, 5.0, -1.0)
     info["cases"] = cases

@@ -264,6 +264,8 @@ def test_placement_at_set_up_changes_addresses_only(B, O, fresh_host_matrices, m
         slab = B.CgSlab.stencil5(n)
         rec = slab.placement()
         assert (rec is None) if cand == "1" else (rec["kind"] == "coefficient candidates" and rec["candidates"] == 3 and rec["spmv_ms_kept"] <= rec["spmv_ms_before"] * 1.001)
+        runs = slab.tile_runs()  # row-lds tiles per XCD and run: the rule's neighbours timed at creation, the fastest kept
+        assert runs is not None and runs["rule"] == 4 and 1 <= runs["kept"] <= 6 and runs["spmv_ms_kept"] <= runs["spmv_ms_rule"]
         st = slab.solve()
         each = slab.spmv_launch_ms()
         assert 0 < len(each) <= st.iterations and np.all(each > 0)

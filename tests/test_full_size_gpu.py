@@ -111,6 +111,20 @@ def test_cg_10k_matches_committed_golden_history(B, golden):
     slab.destroy()
 
 
+def test_cg_15k_matches_committed_golden_history(B, golden):
+    """BASELINE config 5's grid (a grid of n != 0 mod 16 columns: the row-lds tiles of most grid rows start off a 128-byte line);
+    the reference publishes CG there too (docs/PROBLEM_SIZE_SCALING_RESULTS.md:31-38). History from tests/golden/make_golden.py --with-15k."""
+    g = golden["cases"].get("15000:5.0")
+    if g is None:
+        pytest.skip("15k golden not generated")
+    slab = B.CgSlab.stencil5(15000)
+    st = slab.solve()
+    assert st.iterations == g["cg"]["iterations"] == 14 and st.converged == 1
+    assert hist_err(slab.history(), g["cg"]["history"]) < 1e-10
+    assert slab.tile_runs() is not None  # the run-length trial ran on this slab (2.25e8 rows)
+    slab.destroy()
+
+
 def test_cg_20k_published_iteration_count_and_invariants(B):
     """400 M unknowns: 14 iterations on every GPU count (README.md:62); ||r0|| = sqrt(n^2) exactly;
     residuals decrease monotonically for this SPD system; the solve is bit-reproducible."""

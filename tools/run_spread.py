@@ -30,7 +30,7 @@ for k in range(runs):
                 print("      " + l[:260])
         st = line["roofline"].get("stages", {})
         print(f"   {name:24s} {line['value']:.2f} it/s  {line['ms_per_step']:.3f} ms/solve  in-loop SpMV {line['roofline']['avg_launch_ms']:.4f} ms "
-              f"(frac {line['roofline']['frac']:.3f}, of ceiling {line['roofline'].get('frac_of_ceiling', 0):.3f})  standalone SpMV {line['spmv']['median_ms']:.4f} ms  "
+              f"(frac {line['roofline']['frac']:.3f}, of best stream {line['roofline'].get('frac_of_best_stream', 0):.3f})  standalone SpMV {line['spmv']['median_ms']:.4f} ms  "
               f"r update {st.get('update_r_us', {}).get('us', 0):.1f} us  direction update {st.get('direction_update_us', {}).get('us', 0):.1f} us  "
               f"flush {st.get('final_x_flush_us', {}).get('us', 0):.0f} us  initial residual {line['breakdown']['per_rank'][0].get('initial_residual_us', 0):.0f} us  "
               f"placement {line.get('placement')} / spmv {line['spmv'].get('output_placement')}", flush=True)
