@@ -90,6 +90,7 @@ import hashlib
 import importlib.util
 import json
 import os
+import re
 import socket
 import subprocess
 import sys
@@ -573,7 +574,7 @@ def measure_leg(c, allreduce_kind):
     try:
         for _ in range(args.warmup):
             st = slab.solve()
-        if args.leg_only and os.environ.get("SPMV_AMD_BENCH_TEST_KILL_LEG_CHILD") == "1":  # test hook: the extra leg dies mid-run
+        if args.leg_only and args.leg_role == "ab" and os.environ.get("SPMV_AMD_BENCH_TEST_KILL_LEG_CHILD") == "1":  # test hook: the extra leg dies mid-run
             import signal
 
             os.kill(os.getpid(), signal.SIGKILL)
@@ -619,6 +620,16 @@ def measure_leg(c, allreduce_kind):
         slab.destroy()
         if comm is not None:
             comm.destroy()
+    leg["devices"] = gather(c, {"rank": rank, "device": c.device_index, "pci_bus_id": c.pci})
+    # yardsticks, not ceilings: what THIS run sustains for ideal streams of the slab's row count (the rate depends on it:
+    # 6.2-6.4 TB/s for 2e8 / 4e8 rows). In round 4's run the loop's r update streamed 7 % faster than the 48:8 probe.
+    leg["probes"] = {}
+    if rank == 0 and not args.no_ceiling and leg["local_rows"] >= 1_000_000:
+        for key, mix in (("mix_probe", "stencil5"), ("read_only_probe", "read-only")):
+            try:
+                leg["probes"][key] = stream_ceiling(B, rows=leg["local_rows"], mix=mix)
+            except Exception as e:
+                leg["probes"][key] = {"error": repr(e)}
     return leg
 
 
@@ -656,17 +667,23 @@ def run_child_for_record(argv, env, timeout_s, what):
     return rec
 
 
-def other_allreduce_leg(c, kind, timeout_s):
-    """--allreduce-ab: the same K steps with the OTHER all-reduce path, in child processes (one per rank, fresh rendezvous on a
-    new port), started only after the headline line is on stdout: whatever happens there -- a failed set-up, a watchdog exit,
-    a GPU fault in an unproven path, a kill from outside -- the headline stands. Returns rank 0's record of the child leg
-    (or the reason there is none)."""
+WATCHDOG_LINE = re.compile(r"\[spmv_amd watchdog\] rank \d+: (no progress for [0-9.]+ s in stage '[^']*'(?: \(CG iteration \d+\))?)")
+
+
+def run_leg_children(c, kind, role, extra_env, timeout_s):
+    """One measurement leg in CHILD processes, one per rank, on a fresh rendezvous port: every rank process of a multi-rank run
+    (a supervisor: it never touches the GPU) starts its own child and waits for it. Whatever happens to a child -- an
+    UNMEASURED exit, a watchdog exit of a wedged RCCL call, a kill from outside, the time limit -- comes back as a record:
+    {"rec": the JSON object of the child's last `{` line or None, "rc": exit status, "watchdog": the library watchdog's own
+    sentence if the child ended through it, else None}. The child's stderr is passed on."""
     port = [free_port() if c.rank == 0 else None]
     if c.multi:
         c.dist.broadcast_object_list(port, src=0)
     env = dict(os.environ, RANK=str(c.rank), LOCAL_RANK=str(c.local_rank), WORLD_SIZE=str(c.world), MASTER_ADDR="127.0.0.1",
-               MASTER_PORT=str(port[0]))
+               MASTER_PORT=str(port[0]), **extra_env)
     env.pop("SPMV_AMD_BENCH_TEST_CRASH_RANK", None)
+    if c.world > 1:
+        env.setdefault("NCCL_DEBUG", "WARN")  # RCCL's own words on stderr when a communicator misbehaves
     # Under torch.distributed.run the ranks carry TORCHELASTIC_* variables; TORCHELASTIC_USE_AGENT_STORE makes env://
     # rendezvous CONNECT to the launcher's store at MASTER_PORT instead of creating one. The children rendezvous among
     # themselves on a fresh port, so they must not see any of that.
@@ -674,14 +691,180 @@ def other_allreduce_leg(c, kind, timeout_s):
                                                                         "GROUP_WORLD_SIZE", "TORCH_NCCL_ASYNC_ERROR_HANDLING")]:
         env.pop(k)
     argv = [sys.executable, os.path.abspath(__file__), "--gpus", str(c.world), "--steps", str(c.args.steps), "--warmup", str(c.args.warmup),
-            "--grid", str(c.args.grid), "--leg-only", kind]
-    rec = run_child_for_record(argv, env, timeout_s, "child leg")
+            "--grid", str(c.args.grid), "--leg-only", kind, "--leg-role", role] + (["--no-ceiling"] if c.args.no_ceiling else [])
+    rec, rc, err = None, None, ""
+    try:
+        child = subprocess.run(argv, env=env, capture_output=True, text=True, timeout=timeout_s)
+        rc, err = child.returncode, child.stderr
+        lines = [l for l in child.stdout.splitlines() if l.startswith("{")]
+        if lines:
+            try:
+                rec = json.loads(lines[-1])
+            except ValueError:
+                rec = None
+    except subprocess.TimeoutExpired as e:
+        rc, err = -9, (e.stderr.decode(errors="replace") if isinstance(e.stderr, bytes) else (e.stderr or ""))
+        rec = {"error": f"{role} leg did not finish within {timeout_s:.0f} s and was ended"}
+    sys.stderr.write(err)
+    sys.stderr.flush()
+    m = WATCHDOG_LINE.search(err)
+    if rc != 0 and (rec is None or "error" not in rec):
+        how = f"killed by signal {-rc}" if rc < 0 else f"exited with {rc}"
+        rec = dict(rec or {}, error=f"{role} leg child {how}" + (f": {m.group(1)}" if m else ""))
+    return {"rec": rec, "rc": rc, "watchdog": m.group(1) if m else None}
+
+
+def supervise_headline(c, kind, timeout_s):
+    """The headline leg of a multi-rank run, in child processes. Returns (leg or None, reason or None, extras).
+    If a rank of the first attempt ended through the library's watchdog -- the overlapped pipeline drives two RCCL communicators
+    from two streams, the one construction of this solver no run between devices has exercised yet -- the
+    ranks are started ONCE more, as fresh processes on a fresh rendezvous, with SPMV_AMD_NO_OVERLAP=1 (halo exchange on the
+    compute stream: the reference's own, non-overlapped shape, cg_solver_mgpu_partitioned.cu:173-231). A line measured that way
+    says so: "degraded": "no-overlap after <the watchdog's sentence>", with the first attempt's outcome per rank beside it."""
+    first = run_leg_children(c, kind, "headline", {}, timeout_s)
+    outcomes = gather(c, {"rank": c.rank, "rc": first["rc"], "watchdog": first["watchdog"], "error": (first["rec"] or {}).get("error")})
+    if all(o["rc"] == 0 for o in outcomes):
+        return (first["rec"] or {}).get("leg"), None, {}
+    reasons = "; ".join(f"rank {o['rank']}: {o['error']}" for o in outcomes if o["rc"] != 0)
+    sentences = [o["watchdog"] for o in outcomes if o["watchdog"]]
+    if not sentences or os.environ.get("SPMV_AMD_NO_OVERLAP") == "1":
+        return None, reasons, {}
+    if c.rank == 0:
+        print(f"bench.py: the overlapped leg ended through the watchdog ({sentences[0]}); starting fresh ranks once with SPMV_AMD_NO_OVERLAP=1", file=sys.stderr)
+    second = run_leg_children(c, kind, "headline", {"SPMV_AMD_NO_OVERLAP": "1"}, timeout_s)
+    outcomes2 = gather(c, {"rank": c.rank, "rc": second["rc"], "watchdog": second["watchdog"], "error": (second["rec"] or {}).get("error")})
+    extras = {"degraded": f"no-overlap after {sentences[0]}", "first_leg_failure": {"per_rank": outcomes}}
+    if all(o["rc"] == 0 for o in outcomes2):
+        return (second["rec"] or {}).get("leg"), None, extras
+    return None, "after the no-overlap retry: " + "; ".join(f"rank {o['rank']}: {o['error']}" for o in outcomes2 if o["rc"] != 0) + f" (first attempt: {reasons})", extras
+
+
+def other_allreduce_leg(c, kind, timeout_s):
+    """--allreduce-ab: the same K steps with the OTHER all-reduce path, in child processes (one per rank, fresh rendezvous on a
+    new port), started only after the headline line is on stdout: whatever happens there -- a failed set-up, a watchdog exit,
+    a GPU fault in an unproven path, a kill from outside -- the headline stands. Returns rank 0's record of the child leg
+    (or the reason there is none)."""
+    out = run_leg_children(c, kind, "ab", {}, timeout_s)
+    rec = out["rec"] or {"error": "child leg printed no record"}
+    if "leg" in rec:
+        leg = rec["leg"]
+        rec = {k: leg[k] for k in ("allreduce", "ms_per_step", "iterations", "rank_ms", "parity_vs_golden", "ranks_agree_on_history", "rccl_ranks")} | {
+            "breakdown": breakdown_summary(leg["breakdown"])}
     if c.multi:
         try:
             c.dist.barrier()
         except Exception as e:  # a rank lost in the extra leg must not take the (already printed) headline's exit status with it
             rec = dict(rec, barrier_after_leg=repr(e))
     return rec
+
+
+def build_line(args, base, leg, spmv, extras, world, n, rows, nnz):
+    """The benchmark line from a finished leg (rank 0 only; touches neither the GPU nor another rank)."""
+    # template argument: <kMode = 1 (SpMV + p.Ap partials)>
+    kernel_symbol = {"stencil5/row-lds": "stencil5_rowlds_kernel<1>", "stencil5/row-direct": "stencil5_rowdirect_kernel<true>"}.get(leg["variant"], leg["variant"])
+    transport, allreduce, degraded, dt, iterations = leg["transport"], leg["allreduce"], extras.get("degraded") or leg["degraded"], leg["dt"], leg["iterations"]
+
+    # dominant kernel: STENCIL5 SpMV of this rank's slab, average over the launches of the timed steps
+    local_rows, local_nnz = leg["local_rows"], leg["local_nnz"] if leg["local_nnz"] > 0 else None
+    if local_nnz is None:  # nnz of the slab does not fit the int the info call returns (single rank, 20k)
+        local_nnz = nnz // world
+    alg_bytes = 8 * local_nnz + 8 * local_rows + 8 * local_rows
+    avg_spmv_ms = leg["spmv_ms"] / max(leg["spmv_launches"], 1)
+    achieved = alg_bytes / (avg_spmv_ms / 1e3) / 1e9 if avg_spmv_ms > 0 else 0.0
+    # fabric bytes per launch from the committed PMC passes -- only if they were taken on THIS kernel source
+    traffic, traffic_note = None, None
+    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    try:
+        rec = json.load(open(tpath))
+        source_hash = hashlib.sha256(open(KERNEL_SOURCE, "rb").read()).hexdigest()
+        if rec.get("grid") != n or rec.get("n_gpus") != world or rec.get("kernel") != kernel_symbol:
+            traffic_note = "profiles/hbm_traffic.json holds another configuration or kernel: traffic not reported"
+        elif rec.get("kernel_source_sha256") != source_hash:
+            traffic_note = "profiles/hbm_traffic.json is stale (csrc/spmv_kernels.hip changed since the PMC passes): traffic not reported"
+        else:
+            traffic = rec.get("bytes_per_launch")
+            traffic_note = ("L2-to-fabric bytes per launch from separate rocprofv3 --pmc passes (profiles/hbm_traffic.json, taken on this "
+                            "kernel source); Infinity-Cache hits included")
+    except (OSError, ValueError):
+        traffic_note = "no profiles/hbm_traffic.json"
+    roofline = {
+        "bound": "hbm", "kernel": kernel_symbol + " (SpMV + p.Ap partials)", "achieved": achieved, "peak": HBM_PEAK_GBS,
+        "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
+        "avg_launch_ms": avg_spmv_ms, "launches_timed": leg["spmv_launches"], "traffic_note": traffic_note,
+    }
+    for key, probe in (leg.get("probes") or {}).items():  # the stream yardsticks, measured by the process that owned the GPU
+        roofline[key] = probe
+        if "gbs" in probe:
+            roofline[key + "_gbs"] = probe["gbs"]
+    if "mix_probe_gbs" in roofline:
+        roofline["frac_of_mix_probe"] = achieved / roofline["mix_probe_gbs"]
+
+    # every streaming stage of the loop against the same peak, from rank 0's stage timeline (one extra solve, HIP events; a stage
+    # includes the queue gap in front of its kernel): algorithmic bytes per row of the stage / its duration
+    try:
+        t0_ = leg["breakdown"][0]
+        stage_bytes = {"spmv_interior_us": ("SpMV + p.Ap partials (interior rows)", 56.0), "update_r_us": ("r -= alpha Ap + r.r partials", 24.0),
+                       "direction_update_us": ("p' = r + beta p (out of place)", 24.0)}
+        roofline["stages"] = {k: {"what": what, "bytes_per_row": bpr, "us": t0_[k], "gbs": bpr * t0_["rows"] / (t0_[k] * 1e-6) / 1e9,
+                                  "frac": bpr * t0_["rows"] / (t0_[k] * 1e-6) / 1e9 / HBM_PEAK_GBS}
+                              for k, (what, bpr) in stage_bytes.items() if t0_.get(k, 0) > 0}
+        its = max(int(t0_["iterations"]), 1)
+        if t0_.get("final_x_flush_us", 0) > 0:
+            bpr = 8.0 * its + 16.0  # one read of every direction of the window + x in + x out
+            roofline["stages"]["final_x_flush_us"] = {"what": f"x = x0 + sum of {its} alpha_k p_k (deferred x update)", "bytes_per_row": bpr, "us": t0_["final_x_flush_us"],
+                                                      "gbs": bpr * t0_["rows"] / (t0_["final_x_flush_us"] * 1e-6) / 1e9,
+                                                      "frac": bpr * t0_["rows"] / (t0_["final_x_flush_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS}
+    except Exception as e:  # evidence only
+        roofline["stages"] = {"error": repr(e)}
+    rates = {"mix_probe_gbs": roofline.get("mix_probe_gbs"), "read_only_probe_gbs": roofline.get("read_only_probe_gbs"),
+             "update_r_in_the_loop_gbs": (roofline.get("stages") or {}).get("update_r_us", {}).get("gbs")}
+    rates = {k: v for k, v in rates.items() if isinstance(v, (int, float)) and v > 0}
+    if rates:
+        best = max(rates, key=rates.get)
+        roofline["best_stream_gbs_this_run"] = rates[best]
+        roofline["best_stream_is"] = best
+        roofline["frac_of_best_stream"] = achieved / rates[best]
+    if leg.get("placement") is not None:
+        roofline["placement"] = {"coefficient_stream": leg["placement"]}
+    if leg.get("tile_runs") is not None:
+        roofline["tiles_per_xcd_run"] = leg["tile_runs"]
+    if spmv is not None and "median_ms" in spmv:
+        # BASELINE.json's FIRST metric inside an object the driver keeps: SpMV effective GB/s (fp64, 20k x 20k STENCIL5), the
+        # reference's rule (src/main/main.cu:158-187: 5 warm-ups, 10 launches, > 2 sigma dropped, median) and byte formulas
+        # (src/spmv/spmv_metrics.cu:85-101; the published 12 nnz + 16 rows)
+        roofline["spmv_standalone"] = {k: spmv[k] for k in ("operator", "variant", "grid", "median_ms", "effective_gbs", "effective_gbs_published_formula",
+                                                             "algorithmic_gbs", "gflops", "vs_a100_published")} | {"frac": spmv["frac_of_hbm_peak"]}
+        if spmv.get("output_placement") is not None:
+            roofline.setdefault("placement", {})["spmv_output_vector"] = spmv["output_placement"]
+
+    devices = leg.get("devices")
+    if True:
+        value = args.steps * iterations / dt
+        headline = world in A100_CG_ITERS_PER_S and n == 20000 and degraded is None
+        out = dict(base, value=value, ms_per_step=dt / args.steps * 1e3,
+                   vs_baseline=value / A100_CG_ITERS_PER_S[world] if headline else None,
+                   baseline_note="reference's published CG iters/s on the same problem at the same GPU count, A100-SXM4-80GB (BASELINE.md); no MI355X number is published",
+                   config={"workload": f"CG on the {n}x{n} 5-point stencil ({rows} unknowns, {nnz} nnz), b=1, x0=0, tol 1e-6",
+                           "spmv_effective_gbs": None if spmv is None or "effective_gbs" not in spmv else
+                           {"reference_formula": spmv["effective_gbs"], "published_formula": spmv["effective_gbs_published_formula"], "median_ms": spmv["median_ms"]},
+                           "grid": n, "unknowns": rows, "nnz": nnz, "partition": f"{world} row slab(s)", "transport": transport,
+                           "iterations_per_solve": iterations, "converged": leg["converged"], "final_residual": leg["final_residual"],
+                           "residual_history": leg["history"]},
+                   transport=transport, allreduce=allreduce, ranks_agree_on_history=leg["ranks_agree_on_history"], parity_vs_golden=leg["parity_vs_golden"],
+                   rccl_ranks=leg["rccl_ranks"], devices=devices, rank_ms_per_step=leg["rank_ms"], breakdown=breakdown_summary(leg["breakdown"]),
+                   launched_by="bench.py (self-launched ranks)" if os.environ.get("SPMV_AMD_BENCH_SELF_LAUNCHED") == "1" else
+                   ("external launcher (RANK/WORLD_SIZE in the environment)" if "RANK" in os.environ else "single process"),
+                   roofline=roofline)
+        if leg.get("placement") is not None:
+            out["placement"] = leg["placement"]
+        if degraded:
+            out["degraded"] = degraded
+        if extras.get("first_leg_failure"):
+            out["first_leg_failure"] = extras["first_leg_failure"]
+        if spmv is not None:
+            out["spmv"] = spmv
+
+    return out
 
 
 def main():
@@ -710,6 +893,9 @@ def main():
                     help="(internal) one stand-in slab of the scaling probe in this process; prints its record")
     ap.add_argument("--leg-only", choices=["rccl", "mailbox"], default=None,
                     help="(internal) run one measurement leg with that all-reduce path and print its record")
+    ap.add_argument("--leg-role", choices=["headline", "ab"], default="ab", help="(internal) which leg of the parent this child is")
+    ap.add_argument("--leg-timeout", type=float, default=170.0,
+                    help="multi-rank runs: seconds before an attempt at the headline leg (child processes) is ended; two attempts at most")
     args = ap.parse_args()
     if args.steps < 1 or args.warmup < 0 or args.gpus < 1 or args.grid < 2:
         ap.error("--steps >= 1, --warmup >= 0, --gpus >= 1 and --grid >= 2 are required")
@@ -767,30 +953,45 @@ def main():
                           config={"workload": f"CG on the {n}x{n} 5-point stencil, b=1, x0=0, tol 1e-6", "grid": n, "partition": f"{world} row slab(s)"}))
         leave(EXIT_UNMEASURED)
 
-    try:
-        pick_device(c)
-    except Unmeasured as e:
-        give_up(str(e))
-
-    if args.leg_only:  # child of other_allreduce_leg(): one leg, one record, nothing else
+    # north_star's path (RCCL send/recv halos + ncclAllReduce) is the headline; SPMV_AMD_BENCH_ALLREDUCE=mailbox swaps the legs
+    headline_kind = "mailbox" if os.environ.get("SPMV_AMD_BENCH_ALLREDUCE", "rccl") == "mailbox" else "rccl"
+    extras = {}
+    if args.leg_only:  # a supervisor's child: the process that owns the GPU. One leg, one record, nothing else
         try:
+            pick_device(c)
             leg = measure_leg(c, args.leg_only)
         except Unmeasured as e:
             give_up(str(e))
         if rank == 0:
-            emit({k: leg[k] for k in ("allreduce", "ms_per_step", "iterations", "rank_ms", "parity_vs_golden", "ranks_agree_on_history", "rccl_ranks")}
-                 | {"breakdown": breakdown_summary(leg["breakdown"])})
+            emit({"leg": leg})
         leave(0)
-
-    # headline leg FIRST: the slab is then the first large allocation of the process and gets the device's free memory in one
-    # piece (what a solver run by itself gets; behind another leg's allocations and frees the same solve measured 0.5 % slower,
-    # profiles/r04_class_pool_clean_process.txt against r04_class_pool_1gib_chunks.txt). north_star's path (RCCL send/recv halos + ncclAllReduce); SPMV_AMD_BENCH_ALLREDUCE=mailbox swaps the legs
-    headline_kind = "mailbox" if os.environ.get("SPMV_AMD_BENCH_ALLREDUCE", "rccl") == "mailbox" else "rccl"
-    try:
-        leg = measure_leg(c, headline_kind)
-    except Unmeasured as e:
-        give_up(str(e))
-    transport, allreduce, degraded, dt, iterations = leg["transport"], leg["allreduce"], leg["degraded"], leg["dt"], leg["iterations"]
+    elif multi:
+        # A rank process of a multi-rank run is a SUPERVISOR: rendezvous (gloo) and bookkeeping here, everything that touches
+        # the GPU in a child process -- so that a leg whose ranks end through the library's watchdog can be followed, once, by
+        # fresh ranks with the halo exchange on the compute stream (supervise_headline), never by a re-exec and never silently.
+        leg, reason, extras = supervise_headline(c, headline_kind, args.leg_timeout)
+        if leg is None and rank == 0 and reason is None:
+            reason = "the leg's rank 0 printed no record"
+        verdict = [reason if rank == 0 else None]
+        dist.broadcast_object_list(verdict, src=0)
+        if verdict[0] is not None:
+            if rank == 0 and extras:
+                print(f"bench.py: {json.dumps(extras)}", file=sys.stderr)
+            give_up(verdict[0])
+        shared = [{k: leg[k] for k in ("transport",)} if rank == 0 else None]
+        dist.broadcast_object_list(shared, src=0)
+        if rank != 0:
+            leg = shared[0]
+    else:
+        # single process: the headline leg FIRST, so that the slab is the first large allocation of the process and gets the
+        # device's free memory in one piece (what a solver run by itself gets; behind another leg's allocations and frees the
+        # same solve measured 0.5 % slower, profiles/r04_class_pool_clean_process.txt against r04_class_pool_1gib_chunks.txt)
+        try:
+            pick_device(c)
+            leg = measure_leg(c, headline_kind)
+        except Unmeasured as e:
+            give_up(str(e))
+    transport = leg["transport"]
 
     spmv = None
     if world == 1 and not multi and not args.no_spmv:
@@ -799,116 +1000,8 @@ def main():
         except Exception as e:  # the CG measurement above stands whatever happens to this leg
             spmv = {"error": repr(e)}
 
-    # template arguments: <kMode = 1 (SpMV + p.Ap partials), kWeLds = W/E neighbours from LDS (the default)>
-    rowlds = "stencil5_rowlds_kernel<1, true>" if os.environ.get("SPMV_AMD_ROWLDS_WE_LDS", "1") != "0" else "stencil5_rowlds_kernel<1, false>"
-    kernel_symbol = {"stencil5/row-lds": rowlds, "stencil5/row-planes": rowlds.replace("rowlds", "planes"),
-                     "stencil5/row-direct": "stencil5_rowdirect_kernel<1, true>"}.get(leg["variant"], leg["variant"])
-
-    # dominant kernel: STENCIL5 SpMV of this rank's slab, average over the launches of the timed steps
-    local_rows, local_nnz = leg["local_rows"], leg["local_nnz"] if leg["local_nnz"] > 0 else None
-    if local_nnz is None:  # nnz of the slab does not fit the int the info call returns (single rank, 20k)
-        local_nnz = nnz // world
-    alg_bytes = 8 * local_nnz + 8 * local_rows + 8 * local_rows
-    avg_spmv_ms = leg["spmv_ms"] / max(leg["spmv_launches"], 1)
-    achieved = alg_bytes / (avg_spmv_ms / 1e3) / 1e9 if avg_spmv_ms > 0 else 0.0
-    # fabric bytes per launch from the committed PMC passes -- only if they were taken on THIS kernel source
-    traffic, traffic_note = None, None
-    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    try:
-        rec = json.load(open(tpath))
-        source_hash = hashlib.sha256(open(KERNEL_SOURCE, "rb").read()).hexdigest()
-        if rec.get("grid") != n or rec.get("n_gpus") != world or rec.get("kernel") != kernel_symbol:
-            traffic_note = "profiles/hbm_traffic.json holds another configuration or kernel: traffic not reported"
-        elif rec.get("kernel_source_sha256") != source_hash:
-            traffic_note = "profiles/hbm_traffic.json is stale (csrc/spmv_kernels.hip changed since the PMC passes): traffic not reported"
-        else:
-            traffic = rec.get("bytes_per_launch")
-            traffic_note = ("L2-to-fabric bytes per launch from separate rocprofv3 --pmc passes (profiles/hbm_traffic.json, taken on this "
-                            "kernel source); Infinity-Cache hits included")
-    except (OSError, ValueError):
-        traffic_note = "no profiles/hbm_traffic.json"
-    roofline = {
-        "bound": "hbm", "kernel": kernel_symbol + " (SpMV + p.Ap partials)", "achieved": achieved, "peak": HBM_PEAK_GBS,
-        "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
-        "avg_launch_ms": avg_spmv_ms, "launches_timed": leg["spmv_launches"], "traffic_note": traffic_note,
-    }
-    if rank == 0 and not args.no_ceiling and local_rows >= 1_000_000:
-        # yardsticks, not ceilings: what THIS run sustains for ideal streams of the slab's row count (the rate depends on it:
-        # 6.2-6.4 TB/s for 2e8 / 4e8 rows). In round 4's run the loop's r update streamed 7 % faster than the 48:8 probe.
-        for key, mix in (("mix_probe", "stencil5"), ("read_only_probe", "read-only")):
-            try:
-                probe = stream_ceiling(B, rows=local_rows, mix=mix)
-                roofline[key + "_gbs"] = probe["gbs"]
-                roofline[key] = probe
-            except Exception as e:
-                roofline[key] = {"error": repr(e)}
-        if "mix_probe_gbs" in roofline:
-            roofline["frac_of_mix_probe"] = achieved / roofline["mix_probe_gbs"]
-
-    # every streaming stage of the loop against the same peak, from rank 0's stage timeline (one extra solve, HIP events; a stage
-    # includes the queue gap in front of its kernel): algorithmic bytes per row of the stage / its duration
-    try:
-        t0_ = leg["breakdown"][0]
-        stage_bytes = {"spmv_interior_us": ("SpMV + p.Ap partials (interior rows)", 56.0), "update_r_us": ("r -= alpha Ap + r.r partials", 24.0),
-                       "direction_update_us": ("p' = r + beta p (out of place)", 24.0)}
-        roofline["stages"] = {k: {"what": what, "bytes_per_row": bpr, "us": t0_[k], "gbs": bpr * t0_["rows"] / (t0_[k] * 1e-6) / 1e9,
-                                  "frac": bpr * t0_["rows"] / (t0_[k] * 1e-6) / 1e9 / HBM_PEAK_GBS}
-                              for k, (what, bpr) in stage_bytes.items() if t0_.get(k, 0) > 0}
-        its = max(int(t0_["iterations"]), 1)
-        if t0_.get("final_x_flush_us", 0) > 0:
-            bpr = 8.0 * its + 16.0  # one read of every direction of the window + x in + x out
-            roofline["stages"]["final_x_flush_us"] = {"what": f"x = x0 + sum of {its} alpha_k p_k (deferred x update)", "bytes_per_row": bpr, "us": t0_["final_x_flush_us"],
-                                                      "gbs": bpr * t0_["rows"] / (t0_["final_x_flush_us"] * 1e-6) / 1e9,
-                                                      "frac": bpr * t0_["rows"] / (t0_["final_x_flush_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS}
-    except Exception as e:  # evidence only
-        roofline["stages"] = {"error": repr(e)}
-    rates = {"mix_probe_gbs": roofline.get("mix_probe_gbs"), "read_only_probe_gbs": roofline.get("read_only_probe_gbs"),
-             "update_r_in_the_loop_gbs": (roofline.get("stages") or {}).get("update_r_us", {}).get("gbs")}
-    rates = {k: v for k, v in rates.items() if isinstance(v, (int, float)) and v > 0}
-    if rates:
-        best = max(rates, key=rates.get)
-        roofline["best_stream_gbs_this_run"] = rates[best]
-        roofline["best_stream_is"] = best
-        roofline["frac_of_best_stream"] = achieved / rates[best]
-    if leg.get("placement") is not None:
-        roofline["placement"] = {"coefficient_stream": leg["placement"]}
-    if leg.get("tile_runs") is not None:
-        roofline["tiles_per_xcd_run"] = leg["tile_runs"]
-    if spmv is not None and "median_ms" in spmv:
-        # BASELINE.json's FIRST metric inside an object the driver keeps: SpMV effective GB/s (fp64, 20k x 20k STENCIL5), the
-        # reference's rule (src/main/main.cu:158-187: 5 warm-ups, 10 launches, > 2 sigma dropped, median) and byte formulas
-        # (src/spmv/spmv_metrics.cu:85-101; the published 12 nnz + 16 rows)
-        roofline["spmv_standalone"] = {k: spmv[k] for k in ("operator", "variant", "grid", "median_ms", "effective_gbs", "effective_gbs_published_formula",
-                                                             "algorithmic_gbs", "gflops", "vs_a100_published")} | {"frac": spmv["frac_of_hbm_peak"]}
-        if spmv.get("output_placement") is not None:
-            roofline.setdefault("placement", {})["spmv_output_vector"] = spmv["output_placement"]
-
-    devices = gather(c, {"rank": rank, "device": c.device_index, "pci_bus_id": c.pci})
-
-    out = None
-    if rank == 0:
-        value = args.steps * iterations / dt
-        headline = world in A100_CG_ITERS_PER_S and n == 20000 and degraded is None
-        out = dict(base, value=value, ms_per_step=dt / args.steps * 1e3,
-                   vs_baseline=value / A100_CG_ITERS_PER_S[world] if headline else None,
-                   baseline_note="reference's published CG iters/s on the same problem at the same GPU count, A100-SXM4-80GB (BASELINE.md); no MI355X number is published",
-                   config={"workload": f"CG on the {n}x{n} 5-point stencil ({rows} unknowns, {nnz} nnz), b=1, x0=0, tol 1e-6",
-                           "spmv_effective_gbs": None if spmv is None or "effective_gbs" not in spmv else
-                           {"reference_formula": spmv["effective_gbs"], "published_formula": spmv["effective_gbs_published_formula"], "median_ms": spmv["median_ms"]},
-                           "grid": n, "unknowns": rows, "nnz": nnz, "partition": f"{world} row slab(s)", "transport": transport,
-                           "iterations_per_solve": iterations, "converged": leg["converged"], "final_residual": leg["final_residual"],
-                           "residual_history": leg["history"]},
-                   transport=transport, allreduce=allreduce, ranks_agree_on_history=leg["ranks_agree_on_history"], parity_vs_golden=leg["parity_vs_golden"],
-                   rccl_ranks=leg["rccl_ranks"], devices=devices, rank_ms_per_step=leg["rank_ms"], breakdown=breakdown_summary(leg["breakdown"]),
-                   launched_by="bench.py (self-launched ranks)" if os.environ.get("SPMV_AMD_BENCH_SELF_LAUNCHED") == "1" else
-                   ("external launcher (RANK/WORLD_SIZE in the environment)" if "RANK" in os.environ else "single process"),
-                   roofline=roofline)
-        if leg.get("placement") is not None:
-            out["placement"] = leg["placement"]
-        if degraded:
-            out["degraded"] = degraded
-        if spmv is not None:
-            out["spmv"] = spmv
+    out = build_line(args, base, leg, spmv, extras, world, n, rows, nnz) if rank == 0 else None
+    iterations = leg["iterations"] if rank == 0 else None
 
     if multi:
         # A multi-rank run has nothing left to measure: the line goes out NOW, while every rank process is still alive and

@@ -165,7 +165,8 @@ struct SpmvAmdCgSlab {
     // switches the alternation off).
     bool pingpong = true;
     bool roctx_always = false;  // SPMV_AMD_ROCTX=1: roctx ranges even without detailed timers
-    bool no_overlap = false;  // SPMV_AMD_NO_OVERLAP=1: halo exchange on the compute stream, for A/B runs of the overlap
+    bool no_overlap = false;  // SPMV_AMD_NO_OVERLAP=1: halo exchange on the compute stream (the reference's shape; bench.py's fallback)
+    bool test_wedge_overlapped_exchange = false;  // SPMV_AMD_TEST_WEDGE_OVERLAPPED_EXCHANGE=1, see exchange_halo
     bool early_halo = true;   // SPMV_AMD_EARLY_HALO=0: halo exchange only after the whole direction update (round 2's order)
     // Late bulk (round 4): the direction update of iteration k is enqueued before the host knows whether k converged, and on
     // the converging iteration that launch only reads a flag -- 3.1 M one-wave workgroups at 4e8 rows, 0.65 ms of pure
@@ -306,6 +307,7 @@ void make_common(SpmvAmdCgSlab* s) {
     s->spmv_event_stride = nl >= 100000000 ? 1 : 7;
     if (const char* v = getenv("SPMV_AMD_PINGPONG")) s->pingpong = v[0] == '1';
     if (const char* v = getenv("SPMV_AMD_NO_OVERLAP")) s->no_overlap = v[0] == '1';
+    if (const char* v = getenv("SPMV_AMD_TEST_WEDGE_OVERLAPPED_EXCHANGE")) s->test_wedge_overlapped_exchange = v[0] == '1';
     if (const char* v = getenv("SPMV_AMD_EARLY_HALO")) s->early_halo = v[0] != '0';
     if (const char* v = getenv("SPMV_AMD_ROCTX")) s->roctx_always = v[0] == '1';
     s->late_bulk = nl >= 100000000;
@@ -608,6 +610,10 @@ void exchange_halo(SpmvAmdCgSlab* s, double* v, hipStream_t stream) {
     // a staged transport blocks in here on its host exchange, RCCL may block while it connects peers
     WatchdogScope guard("halo exchange (send/recv of the first and last grid row)", s->comm->rank, s->enqueued_iteration,
                         report_slab_state, s);
+    // SPMV_AMD_TEST_WEDGE_OVERLAPPED_EXCHANGE=1 (test hook): an exchange issued on the SIDE stream never returns -- the host
+    // thread stays in here, as it would behind an RCCL call that blocks -- so that the watchdog ends the process and a
+    // supervisor can be shown to restart the ranks without the overlap (tests/test_distributed.py). Nothing is wedged on the GPU.
+    while (s->test_wedge_overlapped_exchange && stream == s->side && s->side != nullptr) std::this_thread::sleep_for(std::chrono::milliseconds(200));
     s->comm->halo_exchange(s->has_prev ? v : nullptr, s->has_next ? v + (s->n_local - s->halo) : nullptr,
                            s->has_prev ? v - s->halo : nullptr, s->has_next ? v + s->n_local : nullptr, s->halo, stream);
 }

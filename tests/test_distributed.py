@@ -242,8 +242,9 @@ FORCED_MULTI_ENV = dict(SPMV_AMD_BENCH_FORCE_DIST="1", SPMV_AMD_FORCE_COLLECTIVE
 def test_bench_multi_rank_default_run_is_lean(tmp_path):
     """One GPU, the complete multi-rank pipeline (SPMV_AMD_BENCH_FORCE_DIST + SPMV_AMD_SELF_NEIGHBOUR: RCCL send / recv of the
     halo rows on the side stream, split SpMV launches, ncclAllReduce of both dot products) on the 2000 x 2000 grid, for which a
-    golden history is committed, WITHOUT any option: exactly one process touched the GPU (the rank; no child leg, no probe),
-    ONE line, with parity_vs_golden and the stage breakdown and no allreduce_ab."""
+    golden history is committed, WITHOUT any option: exactly one process touched the GPU (the rank's leg child: the rank process
+    itself is a supervisor that only rendezvouses; no second leg, no probe), ONE line, with parity_vs_golden and the stage
+    breakdown and no allreduce_ab, degraded or first_leg_failure."""
     log = tmp_path / "procs.jsonl"
     env = dict(os.environ, SPMV_AMD_BENCH_PROCESS_LOG=str(log), **FORCED_MULTI_ENV)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--grid", "2000",
@@ -253,8 +254,36 @@ def test_bench_multi_rank_default_run_is_lean(tmp_path):
     assert len(lines) == 1
     check_multi_rank_line(lines[0], 1)
     assert lines[0]["breakdown"]["per_rank"][0]["halo_exchange_on_side_stream_us"] > 0
-    assert lines[0]["rccl_ranks"] == 1 and "scaling_probe" not in lines[0]
-    assert [p["role"] for p in read_process_log(log)] == ["rank"]
+    assert lines[0]["rccl_ranks"] == 1 and "scaling_probe" not in lines[0] and "degraded" not in lines[0] and "first_leg_failure" not in lines[0]
+    assert [p["role"] for p in read_process_log(log)] == ["rank", "leg-child"]
+    assert "mix_probe_gbs" in lines[0]["roofline"] and lines[0]["devices"][0]["rank"] == 0  # measured by the leg child, carried by its record
+
+
+@pytest.mark.gpu
+def test_bench_restarts_fresh_ranks_without_overlap_after_a_watchdog_exit(tmp_path):
+    """VERDICT r04 item 5. The overlapped pipeline (halo exchange on a side stream, two RCCL communicators driven from two
+    streams) has never run between devices; if its ranks end through the library's watchdog, bench.py must not lose the run: the
+    rank processes are supervisors, the leg runs in their children, and after a watchdog exit FRESH children are started once
+    with SPMV_AMD_NO_OVERLAP=1. Here the side-stream exchange is wedged on the host (SPMV_AMD_TEST_WEDGE_OVERLAPPED_EXCHANGE; the
+    GPU is not involved) and the watchdog limit is 5 s: one line, measured, parity-checked, marked degraded with the
+    watchdog's own sentence and the first attempt's outcome; 2N = 2 processes touched the GPU over the run's life."""
+    log = tmp_path / "procs.jsonl"
+    env = dict(os.environ, SPMV_AMD_BENCH_PROCESS_LOG=str(log), SPMV_AMD_TEST_WEDGE_OVERLAPPED_EXCHANGE="1", SPMV_AMD_WATCHDOG_S="5", **FORCED_MULTI_ENV)
+    t0 = time.monotonic()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--grid", "2000",
+                          "--no-cpu-baseline", "--no-spmv"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and time.monotonic() - t0 < 300, out.stdout + out.stderr
+    lines = _json_lines(out.stdout)
+    assert len(lines) == 1
+    line = lines[0]
+    check_multi_rank_line(line, 1)
+    assert line["degraded"].startswith("no-overlap after no progress for ") and "halo exchange" in line["degraded"], line["degraded"]
+    first = line["first_leg_failure"]["per_rank"]
+    assert len(first) == 1 and first[0]["rc"] == 1 and "halo exchange" in first[0]["watchdog"]
+    assert line["vs_baseline"] is None
+    assert line["breakdown"]["per_rank"][0]["halo_exchange_on_side_stream_us"] == 0  # the exchange ran on the compute stream
+    assert [p["role"] for p in read_process_log(log)] == ["rank", "leg-child", "leg-child"]
+    assert "[spmv_amd watchdog]" in out.stderr and "starting fresh ranks once with SPMV_AMD_NO_OVERLAP=1" in out.stderr
 
 
 @pytest.mark.gpu
@@ -286,7 +315,7 @@ def test_bench_headline_survives_a_second_leg_that_is_killed(tmp_path):
     assert len(lines) == 2 and lines[0]["value"] is not None and lines[0]["parity_vs_golden"]["ok"] and "allreduce_ab" not in lines[0]
     ab = lines[1]["allreduce_ab"]
     assert lines[1]["value"] == lines[0]["value"] and ab["mailbox"] is None and "signal 9" in ab["other_leg"]["error"], ab
-    assert sorted(p["role"] for p in read_process_log(log)) == ["leg-child", "rank"]
+    assert sorted(p["role"] for p in read_process_log(log)) == ["leg-child", "leg-child", "rank"]  # headline leg, killed extra leg, supervisor
 
 
 @pytest.mark.gpu
@@ -339,7 +368,8 @@ def test_slab_solver_over_rccl_between_devices(world, n, mode):
 @pytest.mark.parametrize("world", [2, 4])
 def test_bench_over_rccl_between_devices(world, tmp_path):
     """`python bench.py --gpus N` as the driver runs it, on N devices, at the 2000 x 2000 grid (golden history committed):
-    rccl_ranks == N, parity_vs_golden green, breakdown for every rank, exactly N rank processes."""
+    rccl_ranks == N, parity_vs_golden green, breakdown for every rank, exactly N processes on the GPUs (the ranks' leg children;
+    the rank processes themselves are supervisors that never touch a GPU)."""
     need_gpus(world)
     log = tmp_path / "procs.jsonl"
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", SPMV_AMD_BENCH_PROCESS_LOG=str(log))
@@ -351,7 +381,8 @@ def test_bench_over_rccl_between_devices(world, tmp_path):
     assert len(lines) == 1 and lines[0]["rccl_ranks"] == world
     check_multi_rank_line(lines[0], world)
     assert len({d["pci_bus_id"] for d in lines[0]["devices"]}) == world  # distinct devices
-    assert sorted(p["role"] for p in read_process_log(log)) == ["launcher"] + ["rank"] * world  # N processes on the GPUs, no more
+    assert sorted(p["role"] for p in read_process_log(log)) == ["launcher"] + ["leg-child"] * world + ["rank"] * world  # N processes on the GPUs, no more
+    assert "degraded" not in lines[0]
 
 
 def test_bench_self_launches_its_ranks_and_fails_loudly_without_gpus():
@@ -370,15 +401,17 @@ def test_bench_self_launches_its_ranks_and_fails_loudly_without_gpus():
 
 
 def test_bench_default_multi_gpu_command_starts_exactly_n_rank_processes(tmp_path):
-    """`python bench.py --gpus 2` with every default: the processes of the run are the launcher (no torch, no GPU) and two
-    ranks -- no second leg, no probe, nothing else that could touch a GPU (no GPU here: the ranks then report UNMEASURED)."""
+    """`python bench.py --gpus 2` with every default: the processes of the run are the launcher (no torch, no GPU), two rank
+    processes (supervisors: gloo rendezvous, no GPU) and ONE leg child each -- no second leg, no probe, nothing else that could
+    touch a GPU (no GPU here: the leg children report UNMEASURED, and that is no watchdog exit, so nothing is restarted)."""
     log = tmp_path / "procs.jsonl"
     env = dict(os.environ, HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="", SPMV_AMD_BENCH_PROCESS_LOG=str(log))
     env.pop("RANK", None), env.pop("WORLD_SIZE", None)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 3, out.stdout + out.stderr
     procs = read_process_log(log)
-    assert sorted(p["role"] for p in procs) == ["launcher", "rank", "rank"] and sorted(p["rank"] for p in procs if p["role"] == "rank") == [0, 1]
+    assert sorted(p["role"] for p in procs) == ["launcher", "leg-child", "leg-child", "rank", "rank"]
+    assert sorted(p["rank"] for p in procs if p["role"] == "rank") == [0, 1] == sorted(p["rank"] for p in procs if p["role"] == "leg-child")
 
 
 def load_bench_module():
@@ -416,8 +449,9 @@ def test_bench_default_timeouts_fit_the_drivers_limit():
     (with the reason) is what the driver reads."""
     import re
     defaults = {m.group(1): float(m.group(2)) for m in re.finditer(r'"--([a-z-]+-timeout)", type=float, default=([0-9.]+)', open(os.path.join(ROOT, "bench.py")).read())}
-    assert set(defaults) == {"ab-timeout", "probe-timeout", "launch-timeout"}
+    assert set(defaults) == {"ab-timeout", "probe-timeout", "launch-timeout", "leg-timeout"}
     assert defaults["launch-timeout"] < 600 and defaults["ab-timeout"] < defaults["launch-timeout"] and defaults["probe-timeout"] + 180 < 600
+    assert 2 * defaults["leg-timeout"] + 60 < defaults["launch-timeout"]  # two attempts at the headline leg (overlapped, then not) fit
 
 
 def test_bench_self_launch_reports_a_rank_that_died():
