@@ -152,7 +152,7 @@ __global__ __launch_bounds__(kBlock) void reduce_one_launch_kernel(const double*
                        (int)gridDim.x, stage, tail, s, &s_last);
 }
 
-// Two launches (SPMV_AMD_REDUCE_ONE_LAUNCH=0, the form of rounds 2-4): stage one ...
+// Two launches (ReduceScratch::one_launch = false, the form of rounds 2-4; A/B aid): stage one ...
 __global__ __launch_bounds__(kBlock) void reduce_slices_kernel(const double* __restrict__ partials, int count, int slice,
                                                                double* __restrict__ sums, const int* __restrict__ skip_flag) {
     __shared__ double s[kBlock];

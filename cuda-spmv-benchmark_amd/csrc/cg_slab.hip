@@ -27,7 +27,7 @@
 //    computed by the same code whichever launch it falls in, so overlap cannot change results;
 //  * (round 3) the direction update runs on the slab's first / last grid row FIRST and the exchange starts behind that
 //    launch: the RCCL send / recv kernel, which otherwise competes for CUs with a SpMV that fills the chip and ends after
-//    it, is over long before the interior rows are (early halo; SPMV_AMD_EARLY_HALO=0 = the old order, same bits);
+//    it, is over long before the interior rows are (early halo; set_option("early_halo", 0) = the old order, same bits);
 //  * every wait on another rank is bounded (watchdog.hpp): a wedged peer becomes a report and a non-zero exit;
 //  * (round 4) WHERE the vectors lie is part of the design: on MI355X kernels that walk several vectors in lock step lose 6.5 %
 //    when the vectors lie in different classes of 32 GiB address regions, and only hipMalloc decides the class. r, Ap and the
@@ -113,7 +113,7 @@ struct SpmvAmdCgSlab {
     double* partials_spmv = nullptr;  // dot partials of the SpMV launches (interior, head, tail back to back)
     double* partials_blas = nullptr;
     double* reduce_stage = nullptr;  // scratch of this slab's reductions (kernels.hpp, ReduceScratch)
-    // One launch per dot product (round 5, reduce_device.hpp); SPMV_AMD_REDUCE_ONE_LAUNCH=0 / set_option("reduce_one_launch", 0):
+    // One launch per dot product (round 5, reduce_device.hpp); set_option("reduce_one_launch", 0):
     // the two launches of rounds 2-4, same sums bit for bit (A/B aid). With it the boundary rows of a split SpMV ride in the
     // launch that reduces the SpMV's partials (launch_stencil5_edges_and_reduce).
     bool reduce_one_launch = true;
@@ -152,7 +152,7 @@ struct SpmvAmdCgSlab {
     std::vector<double> history;
     // event pairs around every spmv_event_stride-th in-loop SpMV (recorded without any host sync,
     // resolved after the loop): time_spmv_ms with timers off is the live average of those launches
-    // times the iteration count. Stride 1 = every launch; SPMV_AMD_SPMV_EVENT_STRIDE=4 / 0 (none)
+    // times the iteration count. Stride 1 = every launch; set_option("spmv_event_stride", 4 / 0 (none))
     // changed a 16 ms solve at 50 M rows by < 0.5 %, so every launch is timed.
     std::vector<hipEvent_t> spmv_ev;
     int spmv_event_stride = 1;
@@ -161,13 +161,13 @@ struct SpmvAmdCgSlab {
     // the 256 MiB Infinity Cache. Results and partial slots are independent of the direction. Measured on
     // MI355X, whole solve: 50 M rows (the per-GPU slab of an 8-GPU run) 15.90 -> 15.60 ms, SpMV launches
     // 0.520 -> 0.496 ms; 100 M rows -0.5 %, 200 M rows -0.8 %, 400 M rows unchanged. Making the producers'
-    // stores / consumers' loads plain instead of nontemporal did not raise the hit share (SPMV_AMD_PINGPONG=0
+    // stores / consumers' loads plain instead of nontemporal did not raise the hit share (set_option("pingpong", 0)
     // switches the alternation off).
     bool pingpong = true;
     bool roctx_always = false;  // SPMV_AMD_ROCTX=1: roctx ranges even without detailed timers
     bool no_overlap = false;  // SPMV_AMD_NO_OVERLAP=1: halo exchange on the compute stream (the reference's shape; bench.py's fallback)
     bool test_wedge_overlapped_exchange = false;  // SPMV_AMD_TEST_WEDGE_OVERLAPPED_EXCHANGE=1, see exchange_halo
-    bool early_halo = true;   // SPMV_AMD_EARLY_HALO=0: halo exchange only after the whole direction update (round 2's order)
+    bool early_halo = true;   // set_option("early_halo", 0): halo exchange only after the whole direction update (round 2's order)
     // Late bulk (round 4): the direction update of iteration k is enqueued before the host knows whether k converged, and on
     // the converging iteration that launch only reads a flag -- 3.1 M one-wave workgroups at 4e8 rows, 0.65 ms of pure
     // dispatch per solve. On large slabs the host enqueues a LEAD piece of lead_rows rows (long enough to cover one host
@@ -175,7 +175,7 @@ struct SpmvAmdCgSlab {
     // convergence before its p update too (cg_solver_mgpu_partitioned.cu:652-676). Same kernel over disjoint row ranges:
     // same bits. Measured at 4e8 rows on one slab, settings alternated between solves: 108.04 -> 107.34 ms per solve, -0.65 %
     // (profiles/r04_ab_late_bulk.txt). Small slabs (a whole update is ~0.2 ms at 5e7 rows) keep the single launch;
-    // SPMV_AMD_LATE_BULK=0/1 forces. Ring mode only.
+    // set_option("late_bulk", 0 / 1) forces. Ring mode only.
     bool late_bulk = false;
     size_t lead_rows = (size_t)1 << 24;
     int poll_sequence = 0;
@@ -305,14 +305,10 @@ void make_common(SpmvAmdCgSlab* s) {
     // each event pair puts ~7 us of queue barriers next to the SpMV (rocprofv3 timeline, profiles/r02_slab_timeline.txt);
     // set_option("spmv_event_stride") changes it
     s->spmv_event_stride = nl >= 100000000 ? 1 : 7;
-    if (const char* v = getenv("SPMV_AMD_PINGPONG")) s->pingpong = v[0] == '1';
     if (const char* v = getenv("SPMV_AMD_NO_OVERLAP")) s->no_overlap = v[0] == '1';
     if (const char* v = getenv("SPMV_AMD_TEST_WEDGE_OVERLAPPED_EXCHANGE")) s->test_wedge_overlapped_exchange = v[0] == '1';
-    if (const char* v = getenv("SPMV_AMD_EARLY_HALO")) s->early_halo = v[0] != '0';
     if (const char* v = getenv("SPMV_AMD_ROCTX")) s->roctx_always = v[0] == '1';
     s->late_bulk = nl >= 100000000;
-    if (const char* v = getenv("SPMV_AMD_LATE_BULK")) s->late_bulk = v[0] == '1';
-    if (const char* v = getenv("SPMV_AMD_REDUCE_ONE_LAUNCH")) s->reduce_one_launch = v[0] != '0';
     s->partials_blas = device_alloc<double>(dot_scratch_doubles(nl));
     HIP_CHECK(hipMemset(s->partials_blas, 0, dot_scratch_doubles(nl) * sizeof(double)));
     s->reduce_stage = reduce_scratch_alloc();

@@ -177,7 +177,7 @@ void launch_check_convergence(const double* d_rr_new, double b_norm, double tol,
 // doubles, zero before the first use (every reduction leaves it ready for the next).
 struct ReduceScratch {
     double* base = nullptr;  // null: a single workgroup sums everything (short lists only)
-    bool one_launch = true;  // false: slices and final sum as two launches, the form of rounds 2-4 (SPMV_AMD_REDUCE_ONE_LAUNCH=0)
+    bool one_launch = true;  // false: slices and final sum as two launches, the form of rounds 2-4 (the slab option reduce_one_launch = 0)
 };
 int reduce_scratch_doubles();
 double* reduce_scratch_alloc();  // uncached device memory where the runtime offers it, zeroed; hipFree releases it

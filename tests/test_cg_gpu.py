@@ -120,16 +120,16 @@ def test_direction_ring_is_bit_identical_to_in_place_updates(B, O, fresh_host_ma
 
 @pytest.mark.parametrize("n", [130, 640])
 def test_sweep_direction_alternation_changes_nothing(B, O, fresh_host_matrices, monkeypatch, n):
-    """SPMV_AMD_PINGPONG: consecutive kernels walk the vectors in opposite directions. Tiles, arithmetic and
+    """Loop option "pingpong": consecutive kernels walk the vectors in opposite directions. Tiles, arithmetic and
     partial slots are the same either way, so x and the history are bit-identical with and without it."""
     rng = np.random.default_rng(7 * n)
     e = O.stencil5_coo(n)
     b, x0 = rng.standard_normal(n * n), 0.1 * rng.standard_normal(n * n)
     out = {}
     for mode in ("0", "1"):
-        monkeypatch.setenv("SPMV_AMD_PINGPONG", mode)
         B.lib().spmv_amd_reset_host_matrices()
         slab = B.CgSlab.from_matrix(B.HostMatrix(e, n * n, n * n, n))
+        slab.set_option("pingpong", int(mode))
         slab.set_vectors(b, x0)
         st = slab.solve()
         out[mode] = (st.iterations, slab.history().copy(), slab.gather().copy())
@@ -238,6 +238,42 @@ def test_a_failing_run_device_is_a_status_not_the_end_of_the_callers_process(B, 
     B.lib().spmv_amd_cg_release_workspace()  # idempotent
     x2, hist2, _ = B.cg_solve(Foreign, m, np.ones(n * n), np.zeros(n * n), device=device)
     assert np.array_equal(hist2, hist) and np.array_equal(x2, x)
+    real.free()
+
+
+def test_release_asked_for_from_inside_run_device_is_deferred_not_a_deadlock(B, O, fresh_host_matrices):
+    """cg_solve_device holds the workspace lock for the whole solve, callbacks into a foreign run_device included.
+    A caller's run_device that calls spmv_amd_cg_release_workspace() -- a documented way to give the memory back -- must neither
+    hang on that (non-recursive) lock nor pull the vectors from under the running loop: the release is noted, the solve finishes
+    with the right numbers, and the workspace is gone afterwards (the next solve builds a fresh one and agrees bit for bit)."""
+    n = 120
+    m = B.HostMatrix(O.stencil5_coo(n), n * n, n * n, n)
+    real = B.Operator("cusparse-csr")
+    assert real.init(m) == 0
+    calls = []
+
+    def run_device(d_x, d_y):
+        calls.append(1)
+        if len(calls) == 2 and release[0]:
+            B.lib().spmv_amd_cg_release_workspace()  # from inside the solve, on the solving thread
+        return real.op.contents.run_device(d_x, d_y)
+
+    keep = (B.INIT_FN(lambda mat: 0), B.RUN_TIMED_FN(lambda x, y, ms: 1), B.RUN_DEVICE_FN(run_device), B.FREE_FN(lambda: None))
+    table = B.SpmvOperator(b"callers-own", *keep)
+
+    class Foreign:
+        op = C.pointer(table)
+
+    release = [True]
+    rp, ci, va = O.stencil5_csr(n)
+    x, hist, st = B.cg_solve(Foreign, m, np.ones(n * n), np.zeros(n * n), device=True)
+    xo, ho, ro = O.cg(rp, ci, va, n, np.ones(n * n), np.zeros(n * n), device_form=True)
+    assert st.iterations == ro.iterations and st.converged == 1 and hist_err(hist, ho) < TOL
+    assert np.max(np.abs(x - xo)) <= TOL * np.max(np.abs(xo))
+    release[0] = False
+    x2, hist2, _ = B.cg_solve(Foreign, m, np.ones(n * n), np.zeros(n * n), device=True)
+    assert np.array_equal(hist2, hist) and np.array_equal(x2, x)
+    B.lib().spmv_amd_cg_release_workspace()
     real.free()
 
 
@@ -588,7 +624,7 @@ def test_symmetric_matrix_market_file_through_the_operators_and_cg(B, O, fresh_h
 @pytest.mark.parametrize("ring", ["16", "1"])
 def test_early_halo_exchange_changes_no_bit(B, monkeypatch, ring):
     """Round 3: the slab's first / last grid row get their direction update first and the halo exchange starts behind them,
-    under the rest of the direction update (SPMV_AMD_EARLY_HALO=0 restores round 2's order). Same kernels on disjoint row
+    under the rest of the direction update (loop option early_halo = 0 restores round 2's order). Same kernels on disjoint row
     ranges: the residual history of a stand-in slab (two neighbours, RCCL send / recv to itself) is bit-identical, with the
     direction ring and with the in-place x / p update."""
     monkeypatch.setenv("SPMV_AMD_SELF_NEIGHBOUR", "1")
@@ -596,9 +632,9 @@ def test_early_halo_exchange_changes_no_bit(B, monkeypatch, ring):
     monkeypatch.setenv("SPMV_AMD_P_RING", ring)
     out = {}
     for early in ("0", "1"):
-        monkeypatch.setenv("SPMV_AMD_EARLY_HALO", early)
         comm = B.Comm.rccl(0, 1, B.Comm.unique_id())
         slab = B.CgSlab.stencil5_as(1024, 1, 4, comm)
+        slab.set_option("early_halo", int(early))
         st = slab.solve(max_iters=11, tol=0.0)
         out[early] = (st.iterations, slab.history().copy())
         st_t, tl = slab.timeline_solve(max_iters=11, tol=0.0)
@@ -606,6 +642,29 @@ def test_early_halo_exchange_changes_no_bit(B, monkeypatch, ring):
         slab.destroy()
         comm.destroy()
     assert out["0"][0] == out["1"][0] == 11 and np.array_equal(out["0"][1], out["1"][1])
+
+
+def test_long_row_matrices_take_the_wavefront_kernel_and_the_unfused_loop(B, O, fresh_host_matrices):
+    """a CSR matrix whose MEAN row length exceeds 192 (here a band of half-width 160: ~312 entries per row) is
+    sent to the one-row-per-wavefront kernel by the auto rule. That kernel's row sum is a tree (not the sequential sum: <= 1e-12
+    instead of bit-exact) and it writes no dot partials, so cg_solve_device runs the unfused loop on it (run_device + a dot pass,
+    +16 B/row per iteration). Both must still match the oracle."""
+    e, r, c, _ = M.banded(3000, 160, diagonal=12.0)
+    m = B.HostMatrix(e, r, c, -1)
+    op = B.Operator("cusparse-csr")
+    assert op.init(m) == 0 and op.variant() == "csr/wavefront"
+    rp, ci, va = O.build_csr(e, r)
+    x = np.random.default_rng(11).standard_normal(c)
+    want = O.spmv_csr(rp, ci, va, x)
+    got, _ = op.run_timed(x)
+    scale = np.maximum(np.abs(want), O.spmv_csr(rp, ci, np.abs(va), np.abs(x)))
+    assert np.max(np.abs(got - want) / scale) <= 1e-12
+    b = np.random.default_rng(12).standard_normal(r)
+    xs, hist, st = B.cg_solve(op, m, b, np.zeros(r), device=True)
+    xo, ho, ro = O.cg(rp, ci, va, -1, b, np.zeros(r), device_form=True)
+    assert st.iterations == ro.iterations and st.converged == 1 and hist_err(hist, ho) < TOL
+    assert np.max(np.abs(xs - xo)) <= TOL * np.max(np.abs(xo))
+    op.free()
 
 
 @pytest.mark.parametrize("mode", ["cusparse-csr", "ellpack"])

@@ -34,7 +34,7 @@ if os.environ.get("SPMV_AMD_COMPARE_CEILINGS", "1") != "0":
     for mix in sorted({MIX[m] for m in modes}):
         ms, nbytes = B.stream_ceiling(rows, warmup=3, reps=10, mix=mix)
         ceilings[mix] = nbytes / float(np.median(ms)) / 1e6
-        print(f"stream ceiling, {mix:8s} byte mix: {float(np.median(ms)):8.3f} ms  {ceilings[mix]:8.1f} GB/s ({ceilings[mix] / 8000.0:.3f} of 8 TB/s)")
+        print(f"stream probe, {mix:8s} byte mix: {float(np.median(ms)):8.3f} ms  {ceilings[mix]:8.1f} GB/s ({ceilings[mix] / 8000.0:.3f} of 8 TB/s)")
 out = []
 for mode in modes:
     op = B.Operator(mode)
@@ -49,12 +49,12 @@ for mode in modes:
            "effective_gbs_reference_formula": effective / med / 1e6, "algorithmic_bytes": algorithmic[mode],
            "algorithmic_gbs": algorithmic[mode] / med / 1e6, "frac_of_8TBs": algorithmic[mode] / med / 1e6 / 8000.0}
     if MIX[mode] in ceilings:
-        rec["ceiling_gbs"] = ceilings[MIX[mode]]
-        rec["frac_of_ceiling"] = rec["algorithmic_gbs"] / ceilings[MIX[mode]]
+        rec["mix_probe_gbs"] = ceilings[MIX[mode]]
+        rec["frac_of_mix_probe"] = rec["algorithmic_gbs"] / ceilings[MIX[mode]]
     out.append(rec)
     print(f"{mode:18s} {rec['variant']:22s} {med:8.3f} ms  eff {rec['effective_gbs_reference_formula']:8.1f} GB/s  "
           f"alg {rec['algorithmic_gbs']:8.1f} GB/s ({rec['frac_of_8TBs']:.3f} of 8 TB/s"
-          + (f", {rec['frac_of_ceiling']:.3f} of the measured {MIX[mode]}-mix ceiling)" if "frac_of_ceiling" in rec else ")"))
+          + (f", {rec['frac_of_mix_probe']:.3f} of the {MIX[mode]}-mix stream probe of this run)" if "frac_of_mix_probe" in rec else ")"))
     if placed:
         print(f"{'':18s} output placement: {placed[0]} candidates timed at init, first / kept = {placed[1]:.3f}")
     op.free()

@@ -76,7 +76,7 @@ for name in cases:
     B.lib().spmv_amd_reset_host_matrices()
     op = B.Operator("cusparse-csr")
     ref_y = None
-    variants = [None, "stream", "adaptive", "row-scalar", "subwave4", "subwave8", "subwave16", "subwave32", "wavefront"]
+    variants = [None, "stream", "adaptive", "row-scalar", "wavefront"]
     first = True
     for var in variants:
         op.select_variant(var)

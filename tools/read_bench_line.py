@@ -31,8 +31,14 @@ def digest(d, name):
           + f"; ranks agree on history: {d.get('ranks_agree_on_history')}")
     r = d.get("roofline", {})
     print(f"   dominant kernel {r.get('kernel')}: {r.get('avg_launch_ms', 0):.4f} ms = {r.get('achieved', 0) / 1e3:.2f} TB/s = {r.get('frac', 0):.3f} of {r.get('peak', 0) / 1e3:.0f} TB/s"
-          + (f" = {r['frac_of_ceiling']:.3f} of the ceiling measured in this run ({r['ceiling_measured'] / 1e3:.2f} TB/s)" if r.get("frac_of_ceiling") else "")
+          + (f"; {r['frac_of_best_stream']:.3f} of the best stream rate of this run ({r['best_stream_gbs_this_run'] / 1e3:.2f} TB/s, {r.get('best_stream_is')})" if r.get("frac_of_best_stream") else "")
           + (f"; fabric traffic {r['traffic'] / 1e9:.2f} GB per launch = {r['traffic'] / r['algorithmic_bytes_per_launch']:.3f} x algorithmic" if r.get("traffic") else "; traffic: n/a"))
+    s = r.get("spmv_standalone")
+    if s:
+        print(f"   SpMV alone (BASELINE metric 1, reference rule): {s['median_ms']:.4f} ms = {s['effective_gbs']:.0f} GB/s effective ({s['effective_gbs_published_formula']:.0f} by the "
+              f"published formula = x{s['vs_a100_published']:.2f} the A100), {s['algorithmic_gbs']:.0f} GB/s algorithmic = {s['frac']:.3f} of peak")
+    if d.get("degraded"):
+        print(f"   DEGRADED: {d['degraded']}")
     for k, v in (r.get("stages") or {}).items():
         if isinstance(v, dict) and "frac" in v:
             print(f"      stage {k:24s} {v['us']:9.1f} us  {v['gbs'] / 1e3:5.2f} TB/s = {v['frac']:.3f}   {v['what']}")
@@ -51,6 +57,9 @@ def digest(d, name):
     if sp and "slabs" in sp:
         print(f"   strong-scaling PROJECTION from one GPU ({sp.get('allreduce_path')}):")
         for s in sp["slabs"]:
+            if "projected_efficiency_by_allreduce_latency" not in s:
+                print(f"      P = {s['gpus']}: a role failed: " + "; ".join(str(r_.get("error")) for r_ in s["roles"]))
+                continue
             eff = s["projected_efficiency_by_allreduce_latency"]
             print(f"      P = {s['gpus']}: slowest slab {s['slowest_role_ms_per_solve']:.3f} ms (ideal {s['ideal_ms_per_solve']:.3f}); efficiency at 0 / 10 / 25 / 50 us per all-reduce: "
                   f"{eff['0us']:.3f} / {eff['10us']:.3f} / {eff['25us']:.3f} / {eff['50us']:.3f}")
