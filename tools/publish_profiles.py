@@ -53,7 +53,7 @@ kernel = bench["roofline"]["kernel"].split(" (")[0]
 if "<true" in kernel:  # line written before the kernel's template head changed from <bool kDot, .> to <int kMode, .>
     kernel = kernel.replace("<true, ", "<1, ")
 # the in-loop instantiation (kDot = true): its PMC rows are the SpMV launches of the CG loop
-pmc = next(v for k, v in summary["pmc_avg_per_launch"].items() if kernel.split("<")[0] in k and kernel.split("<")[1].rstrip(">") in k)
+pmc = next(v for k, v in summary["pmc_avg_per_launch"].items() if kernel in k)
 source = os.path.join(ROOT, "cuda-spmv-benchmark_amd", "csrc", "spmv_kernels.hip")
 fetch = pmc["FETCH_SIZE"] * 1024 * 2
 write = pmc["WRITE_SIZE"] * 1024
