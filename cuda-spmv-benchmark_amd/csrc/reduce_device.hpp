@@ -8,7 +8,7 @@
 // for bit, whether the rows ran in a launch of their own or inside the reducing launch (spmv_kernels.hip). Rounds 2-4 issued these as two launches (reduce_slices_kernel, reduce_partials_kernel): 13-17 us per
 // dot product on the P = 8 slab of the headline grid and 29 us at 4e8 rows, two of them per iteration -- half of the fixed cost
 // that keeps a 1/P slab from costing T1/P (profiles/r05_slab_attribution.txt). Two changes:
-//  * the slice loop issues eight independent loads before it adds them (same order of additions): the two-launch kernel walked
+//  * the slice loop issues sixteen independent loads before it adds them (same order of additions): the two-launch kernel walked
 //    its 6-48 partials per thread as a chain of dependent load -> add steps, ~0.6 us each;
 //  * the workgroup that finishes LAST does the second stage in the same launch. Hand-over without cache maintenance: a slice
 //    sum is published with an agent-scope relaxed atomic store (sc1: written through to the memory side, past the XCD-private
@@ -121,18 +121,20 @@ __device__ __forceinline__ void block_tree(double acc, double* __restrict__ s) {
     }
 }
 
-// Thread t's share of partials[lo, hi): elements lo + t, lo + t + 256, ... added in ascending order, eight loads in flight.
+// Thread t's share of partials[lo, hi): elements lo + t, lo + t + 256, ... added in ascending order, sixteen loads in flight
+// (4e8 rows: 48 partials per thread; eight in flight took 12.3 us per reduction, profiles/r05_bench_kernel_stats.csv).
 __device__ __forceinline__ double strided_sum(const double* __restrict__ partials, int lo, int hi) {
+    constexpr int kInFlight = 16;
     double acc = 0.0;
-    for (int base = lo + (int)threadIdx.x; base < hi; base += 8 * kReduceBlock) {
-        double v[8];
+    for (int base = lo + (int)threadIdx.x; base < hi; base += kInFlight * kReduceBlock) {
+        double v[kInFlight];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < kInFlight; ++u) {
             const int i = base + u * kReduceBlock;
             v[u] = i < hi ? partials[i] : 0.0;
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
+        for (int u = 0; u < kInFlight; ++u)
             if (base + u * kReduceBlock < hi) acc += v[u];
     }
     return acc;
