@@ -720,9 +720,11 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
     // residual history: one slot per iteration, capped at 2^20 entries (later iterations go unrecorded)
     const int want_hist = config->max_iters < (1 << 20) ? config->max_iters + 1 : (1 << 20);
     if (s->hist_cap < want_hist) {
-        device_release(s->d_hist);
+        // host-coherent pinned memory, written by the scalar kernels one 8-byte store per iteration: the host reads the history
+        // (and with it the final residual) where it lies, no copy command at the end of a solve
+        if (s->d_hist) HIP_CHECK(hipHostFree(s->d_hist));
         s->hist_cap = want_hist;
-        s->d_hist = device_alloc<double>((size_t)s->hist_cap);
+        HIP_CHECK(hipHostMalloc((void**)&s->d_hist, (size_t)s->hist_cap * sizeof(double), hipHostMallocCoherent | hipHostMallocMapped));
     }
     CgScalars init;
     memset(&init, 0, sizeof init);
@@ -1084,8 +1086,22 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
     }
     HIP_CHECK(hipGetLastError());
 
+    // The outcome, from what the scalar kernels left in host-coherent memory (the stop event above has been waited for):
+    // iteration count and flag from the last status record, ||r|| of the last counted iteration from the history -- which is
+    // fin.residual when converged and sqrt(fin.rr_old) when not (the step moves rr_new into rr_old exactly then). Only a solve
+    // longer than the history (2^20 iterations) has to fetch the device scalars.
     CgScalars fin;
-    HIP_CHECK(hipMemcpy(&fin, s->d_s, sizeof fin, hipMemcpyDeviceToHost));
+    memset(&fin, 0, sizeof fin);
+    if (enqueued > 0 && !s->op_failed) {
+        fin.iterations = s->h_poll->iterations;
+        fin.converged = s->h_poll->converged;
+    }
+    if (fin.iterations < s->hist_cap && !s->op_failed) {
+        fin.residual = s->d_hist[fin.iterations];
+        fin.rr_old = fin.residual * fin.residual;
+    } else {
+        HIP_CHECK(hipMemcpy(&fin, s->d_s, sizeof fin, hipMemcpyDeviceToHost));
+    }
     if (timeline) {
         // averages over the counted iterations; order = kTimelineNames
         auto us = [&](hipEvent_t a, hipEvent_t b) {
@@ -1140,7 +1156,7 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
     stats->iterations = fin.iterations;
     stats->converged = fin.converged;
     // not converged: the reference reports sqrt(rs_old) of the last completed iteration (:720-725)
-    stats->residual_norm = fin.converged ? fin.residual : sqrt(fin.rr_old);
+    stats->residual_norm = (fin.converged || fin.iterations < s->hist_cap) ? fin.residual : sqrt(fin.rr_old);
     stats->time_total_ms = total_ms;
     if (!fin.converged && comm->rank == 0 && s->label == nullptr) printf("\nMax iterations reached without convergence\n");
     if (detail && stats->iterations > 0) {
@@ -1149,8 +1165,7 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
         stats->time_axpby_update_p_ms /= stats->iterations;
     }
     const int count = fin.iterations + 1 < s->hist_cap ? fin.iterations + 1 : s->hist_cap;
-    s->history.assign((size_t)count, 0.0);
-    download(s->history.data(), s->d_hist, (size_t)count);
+    s->history.assign(s->d_hist, s->d_hist + count);
     last_cg_history() = s->history;
     return s->op_failed ? 1 : 0;
 }
@@ -1273,7 +1288,7 @@ extern "C" void spmv_amd_cg_slab_destroy(SpmvAmdCgSlab* s) {
     device_release(s->partials_blas);
     device_release(s->reduce_stage);
     device_release(s->d_s);
-    device_release(s->d_hist);
+    if (s->d_hist) (void)hipHostFree(s->d_hist);
     if (s->h_poll) (void)hipHostFree(s->h_poll);
     for (hipEvent_t e : s->spmv_ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : s->tl_compute) (void)hipEventDestroy(e);
