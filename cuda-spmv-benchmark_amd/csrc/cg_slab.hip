@@ -123,7 +123,16 @@ struct SpmvAmdCgSlab {
     int hist_cap = 0;
     // pinned, host-coherent. progress = 4 * sequence + k, written by the last block of the local reductions of the
     // iteration that will publish `sequence`: k = 1 local p.Ap summed, k = 2 local r.r summed (watchdog report only)
-    struct Poll { int sequence; int converged; int iterations; int progress; }* h_poll = nullptr;
+    // halo_late: set by a boundary wave that gave up waiting for the halo's arrival flag (kernels.hpp, HaloArrival)
+    struct Poll { int sequence; int converged; int iterations; int progress; int halo_late; }* h_poll = nullptr;
+    // Device-side arrival flag of the halo exchange (round 5): behind every exchange on the SIDE stream a one-thread launch
+    // raises *d_halo_flag to that exchange's sequence number, and the boundary waves of the launch that needs the halo rows
+    // wait for it themselves -- no cross-stream event wait (a barrier packet, ~10 us in front of the launch it guards:
+    // profiles/r05_ab_reduce_one_launch.txt, 17 us idle against 7) on the path between a SpMV and its dot product.
+    // set_option("halo_flag", 0): the event wait of rounds 1-4. Same launches, same bits.
+    unsigned* d_halo_flag = nullptr;
+    unsigned halo_sequence = 0;
+    bool halo_flag = true;
     // non-null while a solve runs on a communicator with a working peer mailbox: the last stage of every dot
     // product then completes the sum across the ranks itself (no all-reduce launch)
     const PeerMailbox* reduce_mailbox = nullptr;
@@ -312,6 +321,8 @@ void make_common(SpmvAmdCgSlab* s) {
     s->partials_blas = device_alloc<double>(dot_scratch_doubles(nl));
     HIP_CHECK(hipMemset(s->partials_blas, 0, dot_scratch_doubles(nl) * sizeof(double)));
     s->reduce_stage = reduce_scratch_alloc();
+    s->d_halo_flag = device_alloc<unsigned>(1);
+    HIP_CHECK(hipMemset(s->d_halo_flag, 0, sizeof(unsigned)));
     s->d_s = device_alloc<CgScalars>(1);
     HIP_CHECK(hipMemset(s->d_s, 0, sizeof(CgScalars)));
     HIP_CHECK(hipHostMalloc((void**)&s->h_poll, sizeof(*s->h_poll), hipHostMallocCoherent | hipHostMallocMapped));
@@ -532,11 +543,20 @@ int slab_spmv(SpmvAmdCgSlab* s, bool with_dot, bool overlap, const int* skip,
         const bool fused_tail = with_dot && part != nullptr && init == nullptr && s->reduce_one_launch && lo % A.grid_size == 0 &&
                                 (s->n_local - hi) % A.grid_size == 0 && lo <= A.grid_size && s->n_local - hi <= A.grid_size;
         if (fused_tail && spmv_done) HIP_CHECK(hipEventRecord(spmv_done, s->compute));
-        if (overlap) HIP_CHECK(hipStreamWaitEvent(s->compute, s->ev_halo_done, 0));
+        HaloArrival arrival;
+        if (fused_tail && overlap && s->halo_flag) {
+            // the boundary waves wait for the exchange's arrival flag themselves; bounded well inside the host's watchdog
+            const double limit_s = watchdog_limit_seconds() > 0.0 && watchdog_limit_seconds() < 40.0 ? 0.5 * watchdog_limit_seconds() : 20.0;
+            arrival = HaloArrival{s->d_halo_flag, s->halo_sequence, (long long)(limit_s * 1e8), &s->h_poll->halo_late};
+        } else if (overlap) {
+            HIP_CHECK(hipStreamWaitEvent(s->compute, s->ev_halo_done, 0));
+        }
         if (fused_tail && launch_stencil5_edges_and_reduce(A, s->plan_interior, lo > 0, hi < s->n_local, in, s->Ap, 1.0, part, &s->d_s->pAp, skip,
-                                                           s->scratch(), s->spmv_progress, s->spmv_progress_value, s->reduce_mailbox, s->compute)) {
+                                                           s->scratch(), s->spmv_progress, s->spmv_progress_value, s->reduce_mailbox, s->compute,
+                                                           arrival)) {
             return used;
         }
+        if (arrival.flag != nullptr) HIP_CHECK(hipStreamWaitEvent(s->compute, s->ev_halo_done, 0));  // the fused launch did not apply
         if (fused_tail) spmv_done = nullptr;  // already recorded
         used += slab_boundary_spmv(s, in, part, skip, s->compute, init);
     }
@@ -798,6 +818,7 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
             HIP_CHECK(hipEventRecord(s->ev_p_ready, s->compute));
             HIP_CHECK(hipStreamWaitEvent(s->side, s->ev_p_ready, 0));
             exchange_halo(s, s->x0, s->side);
+            launch_halo_arrived(s->d_halo_flag, ++s->halo_sequence, s->side);
             HIP_CHECK(hipEventRecord(s->ev_halo_done, s->side));
             x0_halo_on_side = true;
         }
@@ -847,6 +868,7 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
         HIP_CHECK(hipStreamWaitEvent(s->side, s->ev_p_ready, 0));
         if (timeline) HIP_CHECK(hipEventRecord(tl_event(s->tl_side, 2 * (size_t)tl_exchanges), s->side));
         exchange_p_halo(s, s->side);
+        launch_halo_arrived(s->d_halo_flag, ++s->halo_sequence, s->side);
         if (timeline) HIP_CHECK(hipEventRecord(tl_event(s->tl_side, 2 * (size_t)tl_exchanges + 1), s->side));
         if (timeline) ++tl_exchanges;
         HIP_CHECK(hipEventRecord(s->ev_halo_done, s->side));
@@ -1053,6 +1075,14 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
         }
         if (!status_known) wait_for_status(s);
         mailbox_check(comm);
+        if (__atomic_load_n(&s->h_poll->halo_late, __ATOMIC_ACQUIRE) != 0) {
+            // worded like the host watchdog's report: bench.py's supervisors read that sentence and restart the ranks once without the overlap
+            fprintf(stderr, "\n[spmv_amd watchdog] rank %d: no progress for %.1f s in stage 'halo arrival flag (in-kernel wait of the boundary rows)' "
+                            "(CG iteration %d)\n", comm->rank, watchdog_limit_seconds() > 0.0 && watchdog_limit_seconds() < 40.0 ? 0.5 * watchdog_limit_seconds() : 20.0,
+                    enqueued - 1);
+            report_slab_state(s, stderr);
+            exit(EXIT_FAILURE);
+        }
         if (s->h_poll->converged) done = true;
         if (config->verbose >= 2 && comm->rank == 0) {
             CgScalars now;
@@ -1245,6 +1275,7 @@ extern "C" int spmv_amd_cg_slab_set_option(SpmvAmdCgSlab* s, const char* name, l
     else if (strcmp(name, "pingpong") == 0) s->pingpong = value != 0;
     else if (strcmp(name, "reduce_one_launch") == 0) s->reduce_one_launch = value != 0;
     else if (strcmp(name, "no_overlap") == 0) s->no_overlap = value != 0;
+    else if (strcmp(name, "halo_flag") == 0) s->halo_flag = value != 0;
     else if (strcmp(name, "spmv_event_stride") == 0) s->spmv_event_stride = (int)value;
     else return -1;
     return 0;
@@ -1287,6 +1318,7 @@ extern "C" void spmv_amd_cg_slab_destroy(SpmvAmdCgSlab* s) {
     device_release(s->partials_spmv);
     device_release(s->partials_blas);
     device_release(s->reduce_stage);
+    device_release(s->d_halo_flag);
     device_release(s->d_s);
     if (s->d_hist) (void)hipHostFree(s->d_hist);
     if (s->h_poll) (void)hipHostFree(s->h_poll);

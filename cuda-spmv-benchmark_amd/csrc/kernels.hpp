@@ -182,6 +182,18 @@ struct ReduceScratch {
 int reduce_scratch_doubles();
 double* reduce_scratch_alloc();  // uncached device memory where the runtime offers it, zeroed; hipFree releases it
 
+// Device-side arrival flag of a halo exchange (round 5): instead of a cross-stream event wait in front of the launch that reads
+// the halo rows, the side stream raises *flag to the exchange's sequence number behind the receive (launch_halo_arrived) and the
+// boundary waves of launch_stencil5_edges_and_reduce wait for it themselves -- bounded by timeout_ticks of the 100 MHz wall
+// clock; a wave that gives up sets *late (host-coherent pinned memory), which ends the run on the host. flag == nullptr: none.
+struct HaloArrival {
+    const unsigned* flag = nullptr;
+    unsigned expected = 0;
+    long long timeout_ticks = 0;
+    int* late = nullptr;
+};
+void launch_halo_arrived(unsigned* d_flag, unsigned sequence, hipStream_t stream);
+
 // The first and / or last grid row of a solver slab (the rows that wait for the halos) AND the reduction of the SpMV's p.Ap
 // partials -- the interior launch's d_interior_partials plus these rows' own -- into *d_out, in ONE launch (spmv_kernels.hip).
 // `interior` = the plan of the launch over the other rows. Returns false, having launched nothing, where the fused form does
@@ -190,7 +202,7 @@ double* reduce_scratch_alloc();  // uncached device memory where the runtime off
 bool launch_stencil5_edges_and_reduce(const SlabCsr& m, const Stencil5Plan& interior, bool first_gridrow, bool last_gridrow, const double* x,
                                       double* y, double alpha, const double* d_interior_partials, double* d_out, const int* d_skip_flag,
                                       const ReduceScratch& scratch, int* host_progress, int progress_value, const PeerMailbox* mailbox,
-                                      hipStream_t stream);
+                                      hipStream_t stream, const HaloArrival& halo = HaloArrival{});
 
 // ---- fused CG steps of the slab solver (all skip their work when s->converged) ----
 // r = b - Ap ; p = r ; partials of r.r

@@ -167,7 +167,10 @@ constexpr int kLdsTileCols = 128;
 // 640 doubles, `xrow`: 130). Returns false if the launch was enqueued past convergence (`skip`: the flag's value,
 // REQUESTED by the caller before this call and tested here only after the tile's loads have been issued -- a wave does not
 // sit on a scalar-load round trip before its first vector load; such a launch only reads). *dot: the tile's partial.
-template <int kMode>
+// kFreshHalo (boundary tiles evaluated behind a device-side arrival flag instead of a kernel boundary, see
+// stencil5_rowlds_edges_reduce_kernel): the north / south values -- the halo rows another GPU's data was received into -- are
+// read with agent-scope loads, which this XCD's L2 cannot serve from a line it cached before the rows arrived.
+template <int kMode, bool kFreshHalo = false>
 __device__ __forceinline__ bool rowlds_tile(const SlabCsr& m, const double* __restrict__ x, double* __restrict__ y, double alpha,
                                             int li, int gi, int j0, int lane, int skip, double* __restrict__ strip,
                                             double* __restrict__ xrow, const ResidualOut& res, double* dot) {
@@ -203,7 +206,13 @@ __device__ __forceinline__ bool rowlds_tile(const SlabCsr& m, const double* __re
             xc[h] = xw[h] = xe[h] = xn[h] = xs[h] = bv[h] = 0.0;
             if (j < n) {
                 const double* __restrict__ xl = x + ((long long)li * n + j);
-                xc[h] = xl[0], xn[h] = xl[-n], xs[h] = xl[n];
+                xc[h] = xl[0];
+                if (kFreshHalo) {
+                    xn[h] = published(reinterpret_cast<const unsigned long long*>(xl - n));
+                    xs[h] = published(reinterpret_cast<const unsigned long long*>(xl + n));
+                } else {
+                    xn[h] = xl[-n], xs[h] = xl[n];
+                }
                 if (kInit) bv[h] = __builtin_nontemporal_load(res.b + ((long long)li * n + j));
                 // only the tile's two outer neighbours come from memory; the rest from the LDS copy below
                 if (h == 0 && lane == 0 && j > 0) xw[0] = xl[-1];
@@ -329,7 +338,7 @@ __global__ __launch_bounds__(64) void stencil5_rowlds_kernel(
 __global__ __launch_bounds__(kReduceBlock) void stencil5_rowlds_edges_reduce_kernel(
     SlabCsr m, const double* __restrict__ x, double* __restrict__ y, double alpha, int li_first, int li_step, int gfirst,
     int col_tiles, int edge_tiles, int edge_blocks, const double* __restrict__ interior_partials, int interior_count, int slice,
-    int slice_blocks, ReduceStage stage, ReduceTail tail) {
+    int slice_blocks, ReduceStage stage, ReduceTail tail, HaloArrival halo) {
     __shared__ double strip[kWavesPerBlock][5 * kLdsTileCols];
     __shared__ double xrow[kWavesPerBlock][kLdsTileCols + 2];
     __shared__ double s[kReduceBlock];
@@ -344,9 +353,28 @@ __global__ __launch_bounds__(kReduceBlock) void stencil5_rowlds_edges_reduce_ker
             const int li = li_first + row_group * li_step;
             double dot = 0.0;
             const ResidualOut none{nullptr, nullptr, nullptr};
-            if (rowlds_tile<1>(m, x, y, alpha, li, gfirst + li, (tile - row_group * col_tiles) * kLdsTileCols, lane, skip, strip[wave],
-                               xrow[wave], none, &dot) && lane == 0)
-                publish(stage.extra + tile, dot);
+            bool live;
+            if (halo.flag != nullptr) {
+                // No kernel boundary orders this launch behind the halo exchange: the side stream raises `flag` to the
+                // exchange's sequence number once the received rows are in memory, and every boundary wave waits for it here
+                // (bounded: a neighbour that never sends must not leave waves spinning; the host reads *late and ends the run).
+                if (skip == 0 && lane == 0) {
+                    const long long t0 = wall_clock64();
+                    while ((int)(__hip_atomic_load(halo.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - halo.expected) < 0) {
+                        if (wall_clock64() - t0 > halo.timeout_ticks) {
+                            __hip_atomic_store(halo.late, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(4);
+                    }
+                }
+                live = rowlds_tile<1, true>(m, x, y, alpha, li, gfirst + li, (tile - row_group * col_tiles) * kLdsTileCols, lane, skip, strip[wave],
+                                            xrow[wave], none, &dot);
+            } else {
+                live = rowlds_tile<1>(m, x, y, alpha, li, gfirst + li, (tile - row_group * col_tiles) * kLdsTileCols, lane, skip, strip[wave],
+                                      xrow[wave], none, &dot);
+            }
+            if (live && lane == 0) publish(stage.extra + tile, dot);
         }
         if (skip != 0) {  // the same value in every workgroup of the launch
             reduce_skipped(tail, blockIdx.x == 0);
@@ -933,10 +961,20 @@ int launch_stencil5_spmv_first_and_last_gridrow(const SlabCsr& m, const Stencil5
     return d_dot_partials ? tiles : 0;
 }
 
+namespace {
+__global__ void halo_arrived_kernel(unsigned* flag, unsigned sequence) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) __hip_atomic_store(flag, sequence, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+}  // namespace
+
+void launch_halo_arrived(unsigned* d_flag, unsigned sequence, hipStream_t stream) {
+    hipLaunchKernelGGL(halo_arrived_kernel, dim3(1), dim3(64), 0, stream, d_flag, sequence);
+}
+
 bool launch_stencil5_edges_and_reduce(const SlabCsr& m, const Stencil5Plan& interior, bool first_gridrow, bool last_gridrow, const double* x,
                                       double* y, double alpha, const double* d_interior_partials, double* d_out, const int* d_skip_flag,
                                       const ReduceScratch& scratch, int* host_progress, int progress_value, const PeerMailbox* mailbox,
-                                      hipStream_t stream) {
+                                      hipStream_t stream, const HaloArrival& halo) {
     const int n = m.grid_size;
     if (interior.variant != Stencil5Variant::RowLds || scratch.base == nullptr || !scratch.one_launch || (!first_gridrow && !last_gridrow) ||
         interior.partials <= 0 || n <= 0 || m.n_local % n != 0)
@@ -951,7 +989,7 @@ bool launch_stencil5_edges_and_reduce(const SlabCsr& m, const Stencil5Plan& inte
     const ReduceTail tail{d_out, d_skip_flag, host_progress, progress_value, mailbox, StepArgs{nullptr, 0.0, nullptr, nullptr, 0, nullptr, 0}};
     hipLaunchKernelGGL(stencil5_rowlds_edges_reduce_kernel, dim3((unsigned)(edge_blocks + slice_blocks)), dim3(kReduceBlock), 0, stream, m, x, y,
                        alpha, first_gridrow ? 0 : local_gridrows - 1, local_gridrows - 1, m.row_offset / n, col_tiles, edge_tiles, edge_blocks,
-                       d_interior_partials, interior.partials, slice, slice_blocks, reduce_stage_of(scratch.base), tail);
+                       d_interior_partials, interior.partials, slice, slice_blocks, reduce_stage_of(scratch.base), tail, halo);
     return true;
 }
 

@@ -368,7 +368,8 @@ def test_loop_options_leave_every_bit_alone(B, monkeypatch, n, P, r):
     forced on with a lead of 50 000 rows so that small grids take the path in both sweep directions. Round 5: every dot product
     reduced by ONE launch (the workgroup that finishes last sums the slice sums) and, on slabs with neighbours, the boundary
     rows of the split SpMV evaluated inside that launch -- against the two-launch reductions and the separate boundary-row
-    launch of rounds 2-4 (reduce_one_launch = 0); halo exchange on the compute stream (no_overlap). History and solution must be
+    launch of rounds 2-4 (reduce_one_launch = 0); halo exchange on the compute stream (no_overlap); the boundary waves waiting for
+    the halo's device-side arrival flag (halo_flag, default) against the cross-stream event wait. History and solution must be
     bit-identical under every combination, with the direction ring and with the in-place x / p update, on a plain slab (even
     and odd row counts) and on stand-in slabs of a larger job (one and two neighbours)."""
     comm = None
@@ -390,9 +391,10 @@ def test_loop_options_leave_every_bit_alone(B, monkeypatch, n, P, r):
         h0, x0 = slab.history().copy(), slab.gather() if P == 1 else None
         for opts in ({"late_bulk": 1, "lead_rows": 50000}, {"late_bulk": 1, "lead_rows": 512}, {"late_bulk": 0, "reduce_one_launch": 1},
                      {"late_bulk": 1, "lead_rows": 50000, "reduce_one_launch": 1}, {"reduce_one_launch": 1, "no_overlap": 1},
-                     {"reduce_one_launch": 0, "no_overlap": 1}):
+                     {"reduce_one_launch": 0, "no_overlap": 1}, {"reduce_one_launch": 1, "halo_flag": 0}, {"reduce_one_launch": 1, "halo_flag": 1, "late_bulk": 1, "lead_rows": 512}):
             for k in ("late_bulk", "reduce_one_launch", "no_overlap"):
                 slab.set_option(k, opts.get(k, 0))
+            slab.set_option("halo_flag", opts.get("halo_flag", 1))
             slab.set_option("lead_rows", opts.get("lead_rows", 1 << 24))
             st = slab.solve(**kw)
             assert (st.iterations, st.converged) == (st0.iterations, st0.converged) and np.array_equal(slab.history(), h0), (ring, opts)
