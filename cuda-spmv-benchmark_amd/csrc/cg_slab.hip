@@ -133,6 +133,10 @@ struct SpmvAmdCgSlab {
     unsigned* d_halo_flag = nullptr;
     unsigned halo_sequence = 0;
     bool halo_flag = true;
+    // Measurement hook, set_option("stop_at", k): iteration k counts as the converging one whatever its residual (kernels.hpp,
+    // CgScalars::stop_at). A stand-in slab's periodic system never converges; with max_iters alone it would run one direction
+    // update + halo exchange more than the rank of a real job, whose 14th iteration converges. Timing only.
+    int stop_at = 0;
     // non-null while a solve runs on a communicator with a working peer mailbox: the last stage of every dot
     // product then completes the sum across the ranks itself (no all-reduce launch)
     const PeerMailbox* reduce_mailbox = nullptr;
@@ -749,6 +753,7 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
     CgScalars init;
     memset(&init, 0, sizeof init);
     init.max_history = s->hist_cap;
+    init.stop_at = s->stop_at;
     HIP_CHECK(hipMemcpyAsync(s->d_s, &init, sizeof init, hipMemcpyHostToDevice, s->compute));
     // Every solve starts from the stored x0 (the reference benchmark wrapper restores x on the host
     // before each run). x is not overwritten with x0 first: the initial SpMV reads x0 and the first
@@ -1276,6 +1281,7 @@ extern "C" int spmv_amd_cg_slab_set_option(SpmvAmdCgSlab* s, const char* name, l
     else if (strcmp(name, "reduce_one_launch") == 0) s->reduce_one_launch = value != 0;
     else if (strcmp(name, "no_overlap") == 0) s->no_overlap = value != 0;
     else if (strcmp(name, "halo_flag") == 0) s->halo_flag = value != 0;
+    else if (strcmp(name, "stop_at") == 0) s->stop_at = value > 0 ? (int)value : 0;
     else if (strcmp(name, "spmv_event_stride") == 0) s->spmv_event_stride = (int)value;
     else return -1;
     return 0;

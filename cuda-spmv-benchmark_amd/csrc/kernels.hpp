@@ -146,7 +146,8 @@ struct CgScalars {
     int converged;
     int iterations;
     int max_history;
-    int pad;
+    int stop_at;  // measurement hook (set_option "stop_at"): the scalar step of this iteration declares convergence whatever the
+                  // residual, so that a stand-in slab (whose periodic system never converges) does a converging solve's work: 0 = off
 };
 
 void launch_fill(double* d, size_t n, double value, hipStream_t stream);

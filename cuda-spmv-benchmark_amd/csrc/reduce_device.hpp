@@ -43,7 +43,7 @@ __device__ __forceinline__ void cg_scalars_step(CgScalars* s, double tol, double
         s->iterations += 1;
         if (alpha_ring != nullptr) alpha_ring[(s->iterations - 1) % ring_slots] = s->alpha;
         if (history != nullptr && s->iterations < s->max_history) history[s->iterations] = res;
-        if (res / s->b_norm < tol) {
+        if (res / s->b_norm < tol || (s->stop_at > 0 && s->iterations == s->stop_at)) {
             s->converged = 1;
         } else {
             s->beta = s->rr_new / s->rr_old;

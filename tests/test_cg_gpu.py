@@ -623,6 +623,29 @@ def test_symmetric_matrix_market_file_through_the_operators_and_cg(B, O, fresh_h
     slab.destroy()
 
 
+def test_stop_at_makes_a_stand_in_slab_do_a_converging_solves_work(B, monkeypatch):
+    """Timing aid of the scaling probe (set_option "stop_at"): a stand-in slab's periodic system never converges, so with max_iters
+    alone it runs one direction update + halo exchange more than the rank of a real job, whose last iteration converges. With
+    stop_at = k the k-th iteration counts as the converging one: k iterations, converged, k - 1 direction updates, and the same
+    residuals up to there as the free-running solve."""
+    monkeypatch.setenv("SPMV_AMD_SELF_NEIGHBOUR", "1")
+    monkeypatch.setenv("SPMV_AMD_FORCE_COLLECTIVES", "1")
+    comm = B.Comm.rccl(0, 1, B.Comm.unique_id())
+    slab = B.CgSlab.stencil5_as(1024, 1, 4, comm)
+    free = slab.solve(max_iters=9, tol=0.0)
+    h_free = slab.history().copy()
+    assert free.iterations == 9 and free.converged == 0
+    slab.set_option("stop_at", 9)
+    st = slab.solve(max_iters=9, tol=0.0)
+    assert st.iterations == 9 and st.converged == 1 and np.array_equal(slab.history(), h_free)
+    _, tl = slab.timeline_solve(max_iters=9, tol=0.0)
+    assert tl["iterations"] == 9 and tl["direction_updates"] == 8
+    slab.set_option("stop_at", 0)
+    assert slab.solve(max_iters=9, tol=0.0).converged == 0
+    slab.destroy()
+    comm.destroy()
+
+
 @pytest.mark.parametrize("ring", ["16", "1"])
 def test_early_halo_exchange_changes_no_bit(B, monkeypatch, ring):
     """Round 3: the slab's first / last grid row get their direction update first and the halo exchange starts behind them,
