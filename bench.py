@@ -34,7 +34,9 @@ configuration of reference docs/PROBLEM_SIZE_SCALING_RESULTS.md:40-47, on N row 
             each in a FRESH process of its own (what a rank of a real job is: inside one process the second slab
             inherits the first one's freed memory and measured up to 3 % off either way, profiles/r05_slab_attribution.txt),
             solved for the full iteration count on this GPU through the complete RCCL pipeline with the rank as its
-            own neighbour. Clock: the solver's timed region (HIP events from the barrier to the end of the x flush,
+            own neighbour, the last iteration counting as the converging one as in the real solve (rounds 2-4 let the
+            stand-in run a 14th direction update + halo exchange no real rank runs: +1.3 % per slab solve).
+            Clock: the solver's timed region (HIP events from the barrier to the end of the x flush,
             the reference's :405-413 -> :728-731), median of 5 solves, for the slab and for the full problem alike.
             The latency of an all-reduce BETWEEN devices cannot be measured on one GPU: the efficiency is given for a
             range of latencies.
