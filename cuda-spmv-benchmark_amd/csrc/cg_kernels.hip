@@ -334,6 +334,18 @@ __global__ void cg_scalars_step_kernel(CgScalars* s, double tol, double* history
     cg_scalars_step(s, tol, history, host_record, sequence, alpha_ring, ring_slots);
 }
 
+// The scalar step as a launch of its own (behind an ncclAllReduce) that ALSO updates the direction on the rows the neighbours
+// wait for: workgroup 0's first thread takes the step and hands beta on, every workgroup then takes a share (reduce_device.hpp,
+// EdgeUpdate). One launch instead of two on the RCCL path.
+__global__ __launch_bounds__(kBlock) void cg_step_and_edges_kernel(StepArgs step, ReduceStage stage, EdgeUpdate edges) {
+    __shared__ int s_flag;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        cg_scalars_step(step.scalars, step.tol, step.history, step.host_record, step.sequence, step.alpha_ring, step.ring_slots);
+        publish_step(stage, step.scalars, step.sequence);
+    }
+    edge_update_after_step(edges, stage, step.sequence, (int)blockIdx.x, (int)gridDim.x, &s_flag);
+}
+
 // Direction update written out of place (deferred x update, cg_slab.hip): p_out = 1.0*r + beta*p_in.
 __global__ __launch_bounds__(kStream) void cg_update_p_ring_kernel(size_t n, const CgScalars* __restrict__ s,
                                                                    const double* __restrict__ r,
@@ -540,7 +552,18 @@ void launch_reduce_partials_and_step(const double* partials, int count, double* 
                 StepArgs{s, tol, history, host_record, sequence, alpha_ring, ring_slots});
 }
 
-int reduce_scratch_doubles() { return kReduceStageBlocks + kReduceExtraMax + 1; }
+bool launch_cg_scalars_step_and_edges(CgScalars* s, double tol, double* history, int* host_record, int sequence, hipStream_t stream,
+                                      double* alpha_ring, int ring_slots, const ReduceScratch& scratch, const EdgeRows& e) {
+    if (scratch.base == nullptr || e.count_a + e.count_b == 0) return false;
+    const size_t pairs = (e.count_a + e.count_b) >> 1;
+    const unsigned blocks = (unsigned)((pairs + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(cg_step_and_edges_kernel, dim3(blocks < 1 ? 1 : (blocks > 256 ? 256 : blocks)), dim3(kBlock), 0, stream,
+                       StepArgs{s, tol, history, host_record, sequence, alpha_ring, ring_slots}, reduce_stage_of(scratch.base),
+                       EdgeUpdate{e.r, e.p_in, e.p_out, e.count_a, e.second, e.count_b, e.fma_form ? 1 : 0, e.timeout_ticks, e.late});
+    return true;
+}
+
+int reduce_scratch_doubles() { return kReduceStageBlocks + kReduceExtraMax + 3; }  // sums | extras | ticket | beta | step_ready
 
 double* reduce_scratch_alloc() {
     // uncached device memory where the runtime offers it: the slice sums and the ticket are handed between workgroups on

@@ -133,6 +133,7 @@ struct SpmvAmdCgSlab {
     unsigned* d_halo_flag = nullptr;
     unsigned halo_sequence = 0;
     bool halo_flag = true;
+    bool edges_in_step = true;  // set_option("edges_in_step", 0): RCCL path, the early direction update of the edge rows as a launch of its own (rounds 3-4)
     // Measurement hook, set_option("stop_at", k): iteration k counts as the converging one whatever its residual (kernels.hpp,
     // CgScalars::stop_at). A stand-in slab's periodic system never converges; with max_iters alone it would run one direction
     // update + halo exchange more than the rank of a real job, whose 14th iteration converges. Timing only.
@@ -943,34 +944,6 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
         // the scalar step publishes {sequence, converged, iterations} straight into host-coherent pinned
         // memory: no copy command sits between it and the p update on the stream. Without an all-reduce
         // between the sum and the step, the step runs in the tail of the reduction's launch.
-        ++s->poll_sequence;
-        trace.push("Dot_Product");
-        if (separate) {
-            timed(&stats->time_reductions_ms, &stats->time_dot_rs_new_ms, [&] {
-                launch_reduce_partials(s->partials_blas, cg_partial_count(nl), &s->d_s->rr_new, skip, s->compute, s->scratch(),
-                                       &s->h_poll->progress, 4 * s->poll_sequence + 2);
-            });
-            s->enqueued_stage = "all-reduce of r.r";
-            {
-                TraceScope r(trace, "AllReduce");
-                timed(&stats->time_allreduce_ms, nullptr, [&] { allreduce_scalar(s, &s->d_s->rr_new, "all-reduce of r.r"); });
-            }
-            launch_cg_scalars_step(s->d_s, config->tolerance, s->d_hist, &s->h_poll->sequence, s->poll_sequence,
-                                   s->compute, s->d_alpha_ring, slots);
-        } else {
-            timed(&stats->time_reductions_ms, &stats->time_dot_rs_new_ms, [&] {
-                // single rank, or mailbox: sum (completed across the ranks in place) and scalar step in one launch
-                launch_reduce_partials_and_step(s->partials_blas, cg_partial_count(nl), &s->d_s->rr_new, skip, s->compute,
-                                                s->scratch(), s->d_s, config->tolerance, s->d_hist,
-                                                &s->h_poll->sequence, s->poll_sequence, s->d_alpha_ring, slots, mailbox,
-                                                &s->h_poll->progress, 4 * s->poll_sequence + 2);
-            });
-        }
-        trace.pop();
-        mark(enqueued, 5);
-        ++enqueued;
-        trace.push("BLAS_AXPBY");
-
         // p <- r + beta p, its halo exchange, and (when overlapping) nothing else before the host
         // looks at the status: the GPU works on these while the host waits for the record.
         // Early halo (round 3): the rows the neighbours need -- the slab's first / last grid row -- are updated by two
@@ -989,6 +962,50 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
         const size_t tail_rows = nl - tail_start;
         const bool early_halo = multi && !detail && !s->no_overlap && s->early_halo && (nl % 2) == 0 && nl >= 4 * (size_t)s->halo + 4 * kAlign &&
                                 head_rows < tail_start;
+        // Round 5, RCCL path: that early update rides in the scalar step's launch (which follows the ncclAllReduce), behind the
+        // step: one launch fewer per iteration (kernels.hpp, EdgeRows). Ring mode, and not in the iteration whose new direction
+        // re-uses a slot the pending x flush still has to read.
+        const int next_iteration = enqueued + 1;
+        const bool edges_in_step = separate && early_halo && s->edges_in_step && slots > 1 && next_iteration - window_start < slots;
+        bool edges_done = false;
+        EdgeRows edge_rows{};
+        if (edges_in_step) {
+            const double limit_s = watchdog_limit_seconds() > 0.0 && watchdog_limit_seconds() < 40.0 ? 0.5 * watchdog_limit_seconds() : 20.0;
+            edge_rows = EdgeRows{r_cur, s->p, s->ring[(size_t)(next_iteration % slots)], head_rows, tail_start, tail_rows, s->device_form,
+                                 (long long)(limit_s * 1e8), &s->h_poll->halo_late};
+        }
+        ++s->poll_sequence;
+        trace.push("Dot_Product");
+        if (separate) {
+            timed(&stats->time_reductions_ms, &stats->time_dot_rs_new_ms, [&] {
+                launch_reduce_partials(s->partials_blas, cg_partial_count(nl), &s->d_s->rr_new, skip, s->compute, s->scratch(),
+                                       &s->h_poll->progress, 4 * s->poll_sequence + 2);
+            });
+            s->enqueued_stage = "all-reduce of r.r";
+            {
+                TraceScope r(trace, "AllReduce");
+                timed(&stats->time_allreduce_ms, nullptr, [&] { allreduce_scalar(s, &s->d_s->rr_new, "all-reduce of r.r"); });
+            }
+            if (edges_in_step)
+                edges_done = launch_cg_scalars_step_and_edges(s->d_s, config->tolerance, s->d_hist, &s->h_poll->sequence, s->poll_sequence, s->compute,
+                                                              s->d_alpha_ring, slots, s->scratch(), edge_rows);
+            if (!edges_done)
+                launch_cg_scalars_step(s->d_s, config->tolerance, s->d_hist, &s->h_poll->sequence, s->poll_sequence,
+                                       s->compute, s->d_alpha_ring, slots);
+        } else {
+            timed(&stats->time_reductions_ms, &stats->time_dot_rs_new_ms, [&] {
+                // single rank, or mailbox: sum (completed across the ranks in place) and scalar step in one launch
+                launch_reduce_partials_and_step(s->partials_blas, cg_partial_count(nl), &s->d_s->rr_new, skip, s->compute,
+                                                s->scratch(), s->d_s, config->tolerance, s->d_hist,
+                                                &s->h_poll->sequence, s->poll_sequence, s->d_alpha_ring, slots, mailbox,
+                                                &s->h_poll->progress, 4 * s->poll_sequence + 2);
+            });
+        }
+        trace.pop();
+        mark(enqueued, 5);
+        ++enqueued;
+        trace.push("BLAS_AXPBY");
+
         // The bulk of the update over rows [lo, hi), lo on a 4 KiB boundary. Late bulk: the piece the sweep walks first, then
         // the status record, then -- unless the iteration converged -- the rest; the lead piece keeps the GPU busy while
         // the host reads the record and launches.
@@ -1053,7 +1070,9 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
             };
             timed(&stats->time_blas1_ms, &stats->time_axpby_update_p_ms, [&] {
                 if (early_halo) {
-                    if (head_rows > 0 && tail_rows > 0)  // a rank with two neighbours: both grid rows in one launch
+                    if (edges_done)
+                        ;  // those rows were updated behind the scalar step, inside its launch
+                    else if (head_rows > 0 && tail_rows > 0)  // a rank with two neighbours: both grid rows in one launch
                         launch_cg_update_p_ring_two_ranges(head_rows, tail_start, tail_rows, s->d_s, r_cur, p_in, p_next, enqueued, s->compute, s->device_form);
                     else
                         ring_update(0, head_rows, false), ring_update(tail_start, tail_rows, false);
@@ -1080,10 +1099,12 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
         }
         if (!status_known) wait_for_status(s);
         mailbox_check(comm);
-        if (__atomic_load_n(&s->h_poll->halo_late, __ATOMIC_ACQUIRE) != 0) {
+        if (const int gave_up = __atomic_load_n(&s->h_poll->halo_late, __ATOMIC_ACQUIRE)) {
             // worded like the host watchdog's report: bench.py's supervisors read that sentence and restart the ranks once without the overlap
-            fprintf(stderr, "\n[spmv_amd watchdog] rank %d: no progress for %.1f s in stage 'halo arrival flag (in-kernel wait of the boundary rows)' "
-                            "(CG iteration %d)\n", comm->rank, watchdog_limit_seconds() > 0.0 && watchdog_limit_seconds() < 40.0 ? 0.5 * watchdog_limit_seconds() : 20.0,
+            fprintf(stderr, "\n[spmv_amd watchdog] rank %d: no progress for %.1f s in stage '%s' (CG iteration %d)\n", comm->rank,
+                    watchdog_limit_seconds() > 0.0 && watchdog_limit_seconds() < 40.0 ? 0.5 * watchdog_limit_seconds() : 20.0,
+                    gave_up == 2 ? "scalar step's hand-over (in-kernel wait of the edge rows' direction update)"
+                                 : "halo arrival flag (in-kernel wait of the boundary rows)",
                     enqueued - 1);
             report_slab_state(s, stderr);
             exit(EXIT_FAILURE);
@@ -1281,6 +1302,7 @@ extern "C" int spmv_amd_cg_slab_set_option(SpmvAmdCgSlab* s, const char* name, l
     else if (strcmp(name, "reduce_one_launch") == 0) s->reduce_one_launch = value != 0;
     else if (strcmp(name, "no_overlap") == 0) s->no_overlap = value != 0;
     else if (strcmp(name, "halo_flag") == 0) s->halo_flag = value != 0;
+    else if (strcmp(name, "edges_in_step") == 0) s->edges_in_step = value != 0;
     else if (strcmp(name, "stop_at") == 0) s->stop_at = value > 0 ? (int)value : 0;
     else if (strcmp(name, "spmv_event_stride") == 0) s->spmv_event_stride = (int)value;
     else return -1;

@@ -249,6 +249,18 @@ void launch_reduce_partials(const double* partials, int count, double* d_out,
                             const int* d_skip_flag, hipStream_t stream, const ReduceScratch& scratch = ReduceScratch{},
                             int* host_progress = nullptr, int progress_value = 0,
                             const PeerMailbox* mailbox = nullptr, const double* extra = nullptr, int extra_count = 0);
+// The direction update of the rows a slab's neighbours wait for -- p_out = r + beta p_in on rows [0, count_a) and
+// [second, second + count_b), all even -- to be run BEHIND the scalar step inside the step's launch on the RCCL path
+// (reduce_device.hpp, EdgeUpdate): one launch fewer per iteration than launch_cg_update_p_ring_two_ranges.
+struct EdgeRows {
+    const double* r;
+    const double* p_in;
+    double* p_out;
+    size_t count_a, second, count_b;
+    bool fma_form;
+    long long timeout_ticks;  // bound of the in-launch wait for the step (100 MHz wall clock)
+    int* late;                // host-coherent int, set to 2 by a workgroup that gave up
+};
 // The same reduction followed by launch_cg_scalars_step() in the same launch
 // (only valid when no all-reduce has to happen between the sum and the step).
 void launch_reduce_partials_and_step(const double* partials, int count, double* d_out, const int* d_skip_flag,
@@ -256,6 +268,10 @@ void launch_reduce_partials_and_step(const double* partials, int count, double* 
                                      int* host_record, int sequence, double* alpha_ring = nullptr, int ring_slots = 0,
                                      const PeerMailbox* mailbox = nullptr, int* host_progress = nullptr,
                                      int progress_value = 0);
+// launch_cg_scalars_step() + the EdgeRows update in one launch (the RCCL path, where the step follows an ncclAllReduce).
+// Returns false, having launched nothing, without a scratch.
+bool launch_cg_scalars_step_and_edges(CgScalars* s, double tol, double* history, int* host_record, int sequence, hipStream_t stream,
+                                      double* alpha_ring, int ring_slots, const ReduceScratch& scratch, const EdgeRows& edge_rows);
 // After the (all-reduced) r.r is known: b_norm (first call), residual, history, convergence
 // flag, beta, rr_old <- rr_new, iteration counter.
 void launch_cg_scalars_init(CgScalars* s, double* history, hipStream_t stream);

@@ -70,6 +70,25 @@ struct StepArgs {
     int ring_slots;
 };
 
+// The direction update of the rows a slab's neighbours wait for (its first / last grid row, rounded outwards to 4 KiB), run
+// BEHIND the scalar step inside the step's own launch on the RCCL path (round 5, cg_step_and_edges_kernel): p_out = r + beta p_in
+// on rows [0, count_a) and [second, second + count_b). Every workgroup of the launch takes a share once the step's workgroup
+// has published beta and the convergence verdict through the scratch (agent-scope stores / loads, the hand-over below) -- a
+// wait among workgroups of ONE launch, all of them resident (<= 256 of 256 threads), bounded by timeout_ticks of the 100 MHz
+// wall clock. One launch fewer per iteration than the separate update of rounds 3-4: -0.2 % per solve on the 20 000^2 P = 8
+// slab, -0.6 % on the 10 000^2 one (profiles/r05_ab_edges_in_step.txt). Inside the one-launch r.r reduction (no all-reduce
+// call between sum and step: single rank, mailbox) the same merge measured +0.0 / +0.1 % -- the hand-over costs what the
+// launch saved -- and is not built.
+struct EdgeUpdate {
+    const double* r = nullptr;
+    const double* p_in = nullptr;
+    double* p_out = nullptr;
+    size_t count_a = 0, second = 0, count_b = 0;  // all even
+    int fma_form = 0;
+    long long timeout_ticks = 0;
+    int* late = nullptr;  // host-coherent: set by a workgroup that gave up waiting
+};
+
 // What happens to the finished sum.
 //  * mailbox (may be null): the sum is completed ACROSS THE RANKS by the finishing workgroup's first wave (comm.hpp);
 //  * step.scalars (may be null): the CG scalar step runs on the finished sum in the same launch;
@@ -91,12 +110,15 @@ struct ReduceStage {
     unsigned long long* sums;   // kReduceStageBlocks doubles, as bits
     unsigned long long* extra;  // kReduceExtraMax doubles, as bits
     unsigned* ticket;
+    unsigned long long* beta;   // EdgeUpdate: beta of the step just taken, as bits
+    unsigned* step_ready;       // EdgeUpdate: 2 * sequence + converged, raised behind beta
 };
 
 // scratch layout (kernels.hpp, ReduceScratch): [kReduceStageBlocks sums | kReduceExtraMax extras | ticket]
 __host__ __device__ inline ReduceStage reduce_stage_of(double* base) {
     unsigned long long* b = reinterpret_cast<unsigned long long*>(base);
-    return ReduceStage{b, b + kReduceStageBlocks, reinterpret_cast<unsigned*>(b + kReduceStageBlocks + kReduceExtraMax)};
+    return ReduceStage{b, b + kReduceStageBlocks, reinterpret_cast<unsigned*>(b + kReduceStageBlocks + kReduceExtraMax),
+                       b + kReduceStageBlocks + kReduceExtraMax + 1, reinterpret_cast<unsigned*>(b + kReduceStageBlocks + kReduceExtraMax + 2)};
 }
 // Slice workgroups of a reduction over `count` partials: one up to 1024 partials, else ceil(count / slice) with
 // slice = ceil(count / kReduceStageBlocks).
@@ -175,6 +197,44 @@ __device__ __forceinline__ void publish(unsigned long long* slot, double value) 
 }
 __device__ __forceinline__ double published(const unsigned long long* slot) {
     return __longlong_as_double((long long)__hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+
+// The step's workgroup (thread 0, right behind cg_scalars_step) hands beta and the verdict to the other workgroups.
+__device__ __forceinline__ void publish_step(const ReduceStage& stage, const CgScalars* s, int sequence) {
+    publish(stage.beta, s->beta);
+    __hip_atomic_store(stage.step_ready, 2u * (unsigned)sequence + (s->converged ? 1u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Called by ALL threads of EVERY workgroup of the launch (block `block` of `blocks`): waits for publish_step of `sequence`,
+// then updates this workgroup's share of the edge rows. s_flag: one int of LDS.
+__device__ __forceinline__ void edge_update_after_step(const EdgeUpdate& e, const ReduceStage& stage, int sequence, int block, int blocks,
+                                                       int* __restrict__ s_flag) {
+    if (threadIdx.x == 0) {
+        const long long t0 = wall_clock64();
+        unsigned seen;
+        while (((seen = __hip_atomic_load(stage.step_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 1) != (unsigned)sequence) {
+            if (wall_clock64() - t0 > e.timeout_ticks) {
+                __hip_atomic_store(e.late, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                seen = 1u;  // treated as converged: nothing is written
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        *s_flag = (int)(seen & 1u);
+    }
+    __syncthreads();
+    if (*s_flag != 0) return;  // the iteration converged (or the wait gave up): no direction is needed
+    const double beta = published(stage.beta);
+    typedef double edge_d2 __attribute__((ext_vector_type(2)));
+    const size_t pairs_a = e.count_a >> 1, pairs = (e.count_a + e.count_b) >> 1, shift = (e.second - e.count_a) >> 1;
+    for (size_t i = (size_t)block * kReduceBlock + threadIdx.x; i < pairs; i += (size_t)blocks * kReduceBlock) {
+        const size_t at = i < pairs_a ? i : i + shift;
+        const edge_d2 rv = reinterpret_cast<const edge_d2*>(e.r)[at];
+        edge_d2 pv = reinterpret_cast<const edge_d2*>(e.p_in)[at];
+        pv.x = e.fma_form ? fma(beta, pv.x, rv.x) : fma(1.0, rv.x, beta * pv.x);  // cg_kernels.hip, direction()
+        pv.y = e.fma_form ? fma(beta, pv.y, rv.y) : fma(1.0, rv.y, beta * pv.y);
+        reinterpret_cast<edge_d2*>(e.p_out)[at] = pv;
+    }
 }
 
 // Called by ALL threads of a workgroup once everything it contributes has been published (by any of its threads, each

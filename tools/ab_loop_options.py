@@ -3,8 +3,8 @@
 with spmv_amd_cg_slab_set_option -- so that placement (worth up to +-1.3 % between two slabs of one process,
 profiles/r03_placement.txt) cannot enter. Solves run to the tolerance (14 iterations on the 20000 grid), alternating A B B A.
 
-   python tools/ab_loop_options.py <option> [grid=20000] [as_world=1 as_rank=0] [rounds=8]
-   options: late_bulk, early_halo, pingpong, reduce_one_launch, no_overlap
+   python tools/ab_loop_options.py <option> [grid=20000] [as_world=1 as_rank=0] [rounds=8] [collectives=1]
+   options: late_bulk, early_halo, pingpong, reduce_one_launch, no_overlap, halo_flag, edges_in_step
 A slab of a larger job (as_world > 1) is a stand-in slab on a self-neighbour RCCL rank (see tools/ab_early_halo_rigorous.py)."""
 import os
 import sys
@@ -20,10 +20,12 @@ n = int(sys.argv[2]) if len(sys.argv) > 2 else 20000
 P = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 r = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 rounds = int(sys.argv[5]) if len(sys.argv) > 5 else 8
+collectives = sys.argv[6] if len(sys.argv) > 6 else "1"  # "0": no ncclAllReduce call between the sums and the step (the shape of the mailbox path)
 
 comm = None
 if P > 1:
-    os.environ["SPMV_AMD_SELF_NEIGHBOUR"] = os.environ["SPMV_AMD_FORCE_COLLECTIVES"] = "1"
+    os.environ["SPMV_AMD_SELF_NEIGHBOUR"] = "1"
+    os.environ["SPMV_AMD_FORCE_COLLECTIVES"] = collectives
 B = load_binding()
 B.lib()
 B.require_gpu()
