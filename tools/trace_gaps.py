@@ -60,3 +60,13 @@ for g, nxt in gaps:
 print("idle time in front of each kernel kind:")
 for k, (ns, cnt) in sorted(by_next.items(), key=lambda kv: -kv[1][0]):
     print(f"  {ns / 1e3:10.1f} us  {cnt:4d} x {ns / cnt / 1e3:8.2f} us  before {k[:90]}")
+# one iteration, launch by launch: from the interior SpMV launch of a middle iteration to the next one
+spmv = [i for i, e in enumerate(solve) if "stencil5_rowlds_kernel<1" in e[2] or "stencil5_row_" in e[2]]
+if len(spmv) >= 3:
+    a, b = spmv[len(spmv) // 2], spmv[len(spmv) // 2 + 1]
+    print(f"one iteration, launch by launch (start offset, duration, idle before; us) -- {(solve[b][0] - solve[a][0]) / 1e3:.1f} us:")
+    prev_end = solve[a - 1][1] if a > 0 else solve[a][0]
+    for s, e, name in solve[a:b]:
+        short = name.replace("(anonymous namespace)::", "").replace("spmv_amd::", "").replace("void ", "").split("(")[0]
+        print(f"  +{(s - solve[a][0]) / 1e3:8.1f}  {(e - s) / 1e3:8.1f}  {(s - prev_end) / 1e3:6.1f}  {short[:90]}")
+        prev_end = max(prev_end, e)
