@@ -572,6 +572,7 @@ def measure_leg(c, allreduce_kind):
     slab = B.CgSlab.stencil5(n, comm)
     placement = slab.placement()  # set-up work, outside the timed region (csrc/cg_slab.hip, place_coefficients)
     tile_runs = slab.tile_runs()  # ditto: row-lds tiles per XCD and run, the rule's neighbours timed at creation
+    setup_ms = slab.setup_ms()    # wall ms of creation's phases; none of it inside the timed region
 
     def barrier():
         if multi:
@@ -621,7 +622,7 @@ def measure_leg(c, allreduce_kind):
                "local_rows": slab.n_local, "local_nnz": slab.local_nnz, "spmv_ms": spmv_ms, "spmv_launches": spmv_launches,
                "event_ms_per_solve": float(np.median(event_ms)),
                "rccl_ranks": comm.transport_ranks() if (comm is not None and transport == "rccl") else 0,
-               "placement": placement, "tile_runs": tile_runs}
+               "placement": placement, "tile_runs": tile_runs, "setup_ms": setup_ms}
     finally:
         slab.destroy()
         if comm is not None:
@@ -834,6 +835,9 @@ def build_line(args, base, leg, spmv, extras, world, n, rows, nnz):
         roofline["placement"] = {"coefficient_stream": leg["placement"]}
     if leg.get("tile_runs") is not None:
         roofline["tiles_per_xcd_run"] = leg["tile_runs"]
+    if leg.get("setup_ms") is not None:
+        # what creating the slab cost on the wall (rank 0): set-up, as the reference's build + upload before its timed region
+        roofline["setup_ms_outside_timed_region"] = {k: round(v, 1) for k, v in leg["setup_ms"].items()}
     if spmv is not None and "median_ms" in spmv:
         # BASELINE.json's FIRST metric inside an object the driver keeps: SpMV effective GB/s (fp64, 20k x 20k STENCIL5), the
         # reference's rule (src/main/main.cu:158-187: 5 warm-ups, 10 launches, > 2 sigma dropped, median) and byte formulas

@@ -93,7 +93,7 @@ DECLARED_SYMBOLS = [
     "spmv_amd_comm_mailbox_disable", "spmv_amd_comm_mailbox_ready",
     "spmv_amd_cg_slab_create", "spmv_amd_cg_slab_create_stencil5", "spmv_amd_cg_slab_create_stencil5_as", "spmv_amd_cg_slab_set_vectors", "spmv_amd_cg_slab_solve",
     "spmv_amd_cg_slab_gather", "spmv_amd_cg_slab_history", "spmv_amd_cg_slab_spmv", "spmv_amd_cg_slab_info",
-    "spmv_amd_cg_slab_time_spmv", "spmv_amd_cg_slab_set_timeline", "spmv_amd_cg_slab_set_option", "spmv_amd_operator_placement", "spmv_amd_cg_slab_placement", "spmv_amd_cg_slab_tile_runs", "spmv_amd_cg_slab_spmv_launch_ms",  "spmv_amd_cg_release_workspace", "spmv_amd_cg_slab_timeline_names", "spmv_amd_cg_slab_timeline", "spmv_amd_cg_slab_variant", "spmv_amd_cg_slab_destroy", "spmv_amd_version", "spmv_amd_write_stencil5_values",
+    "spmv_amd_cg_slab_time_spmv", "spmv_amd_cg_slab_set_timeline", "spmv_amd_cg_slab_set_option", "spmv_amd_operator_placement", "spmv_amd_cg_slab_placement", "spmv_amd_cg_slab_tile_runs", "spmv_amd_cg_slab_setup_ms", "spmv_amd_cg_slab_spmv_launch_ms",  "spmv_amd_cg_release_workspace", "spmv_amd_cg_slab_timeline_names", "spmv_amd_cg_slab_timeline", "spmv_amd_cg_slab_variant", "spmv_amd_cg_slab_destroy", "spmv_amd_version", "spmv_amd_write_stencil5_values",
     "spmv_amd_blas1_axpy", "spmv_amd_blas1_axpby", "spmv_amd_blas1_axpy_dev", "spmv_amd_blas1_update_p_dev", "spmv_amd_blas1_dot",
     "spmv_amd_cg_fused_step",
 ]
@@ -624,9 +624,14 @@ class CgSlab:
         lib().spmv_amd_cg_slab_placement.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         if lib().spmv_amd_cg_slab_placement(self.h, v, 4) != 4:
             return None
-        if v[0] == 1.0:
-            return {"kind": "class pool", "chunks_created": int(v[1]), "chunks_in_vectors": int(v[2]), "coefficients_in_pool": bool(v[3])}
         return {"kind": "coefficient candidates", "candidates": int(v[1]), "spmv_ms_before": float(v[2]), "spmv_ms_kept": float(v[3])}
+
+    def setup_ms(self):
+        """Wall ms of creation's set-up phases (outside every timed region)."""
+        v = (C.c_double * 5)()
+        lib().spmv_amd_cg_slab_setup_ms.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        lib().spmv_amd_cg_slab_setup_ms(self.h, v, 5)
+        return dict(zip(("matrix_to_hbm", "streams_and_vectors", "verify_and_plans", "coefficient_placement", "tile_runs"), (float(x) for x in v)))
 
     def tile_runs(self):
         """Row-lds tiles per XCD and run as tuned at creation, or None if the trial did not run."""

@@ -97,6 +97,13 @@ struct SpmvAmdCgSlab {
     // place_coefficients: {0, candidates timed, SpMV ms before, SpMV ms kept}
     std::vector<double> placement;
     std::vector<double> tile_runs;  // tune_tile_runs: {rule, kept, SpMV ms with the rule, ms kept}; empty = did not run
+    // wall ms of the set-up phases of creation, each closed by a device synchronisation (spmv_amd_cg_slab_setup_ms):
+    // matrix to HBM (upload or generation), streams + vectors, verification + launch plans, coefficient placement, tile runs
+    double setup_ms[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    // false for the slab a one-shot entry point creates, solves on once and destroys (cg_solve_mgpu_partitioned): the two timed
+    // trials of creation cost 0.05-5 s (the placement trial allocates and frees two spacers of up to 28 GiB) and can win
+    // back 2 % of ONE solve at most; a slab the caller keeps (spmv_amd_cg_slab_create*) runs them
+    bool setup_trials = true;
     double* p_alloc = nullptr;  // [pad | prev halo | local | next halo]
     double* p = nullptr;        // local part of the CURRENT direction vector, 16-byte aligned
     // Direction ring (deferred x update). With ring_slots > 1 the direction update is written out of place into
@@ -229,8 +236,18 @@ void adopt_operator(SpmvAmdCgSlab* s, SpmvOperator* op) {
 void place_coefficients(SpmvAmdCgSlab* s);  // below
 void tune_tile_runs(SpmvAmdCgSlab* s);
 
+// Set-up phase clock: wall time since `from`, after everything enqueued so far has finished.
+double setup_phase_ms(std::chrono::steady_clock::time_point& from) {
+    HIP_CHECK(hipDeviceSynchronize());
+    const auto now = std::chrono::steady_clock::now();
+    const double ms = std::chrono::duration<double, std::milli>(now - from).count();
+    from = now;
+    return ms;
+}
+
 void make_common(SpmvAmdCgSlab* s) {
     const size_t nl = (size_t)s->n_local;
+    auto phase = std::chrono::steady_clock::now();
     // A self-neighbour rank that owns the WHOLE grid (part_world == 1) keeps halos on both sides: the rows that would
     // read them are the first and last grid row of the global grid, which have no north / south entry, so the
     // full pipeline runs and the solve must still reproduce the plain one (tests/test_distributed.py).
@@ -339,6 +356,7 @@ void make_common(SpmvAmdCgSlab* s) {
         HIP_CHECK(hipDeviceSynchronize());
         return;
     }
+    s->setup_ms[1] = setup_phase_ms(phase);
     s->A.verify_stencil(s->compute);
     {
         // dot partials: one slot per launched wave; the launch geometry is a fixed function of the
@@ -363,11 +381,13 @@ void make_common(SpmvAmdCgSlab* s) {
         const auto rowlds = [&](const Stencil5Plan& p) { return p.last_row <= p.first_row || p.variant == Stencil5Variant::RowLds; };
         s->fuse_init_residual = s->plan_whole.variant == Stencil5Variant::RowLds && rowlds(s->plan_interior) && rowlds(s->plan_head) && rowlds(s->plan_tail);
     }
-    place_coefficients(s);
-    tune_tile_runs(s);
+    s->setup_ms[2] = setup_phase_ms(phase);
+    if (s->setup_trials) place_coefficients(s);
+    s->setup_ms[3] = setup_phase_ms(phase);
+    if (s->setup_trials) tune_tile_runs(s);
     launch_fill(s->b, nl, 1.0, s->compute);   // default right-hand side b = 1
     launch_fill(s->x0, nl, 0.0, s->compute);  // default initial guess x0 = 0
-    HIP_CHECK(hipDeviceSynchronize());
+    s->setup_ms[4] = setup_phase_ms(phase);
 }
 
 // The coefficient stream's place (round 4). The in-loop SpMV reads the coefficients V and a direction buffer x and writes Ap; by
@@ -650,7 +670,8 @@ void exchange_p_halo(SpmvAmdCgSlab* s, hipStream_t stream) { exchange_halo(s, s-
 
 }  // namespace
 
-extern "C" SpmvAmdCgSlab* spmv_amd_cg_slab_create(MatrixData* mat, SpmvAmdComm* comm) {
+namespace {
+SpmvAmdCgSlab* create_from_matrix(MatrixData* mat, SpmvAmdComm* comm, bool setup_trials) {
     if (comm == nullptr) comm = self_comm();
     if (mat->rows != mat->cols) {
         fprintf(stderr, "[cg-slab] CG needs a square matrix\n");
@@ -669,11 +690,17 @@ extern "C" SpmvAmdCgSlab* spmv_amd_cg_slab_create(MatrixData* mat, SpmvAmdComm* 
     s->grid = mat->grid_size;
     s->row_offset = row_offset;
     s->n_local = n_local;
-    s->A.separate_values = wants_coefficient_placement((size_t)n_local);  // the copy that loses the placement trial can then be freed
+    s->setup_trials = setup_trials;
+    s->A.separate_values = setup_trials && wants_coefficient_placement((size_t)n_local);  // the copy that loses the placement trial can then be freed
+    auto phase = std::chrono::steady_clock::now();
     s->A.upload_slab(csr_mat, row_offset, n_local, mat->grid_size);
+    s->setup_ms[0] = setup_phase_ms(phase);
     make_common(s);
     return s;
 }
+}  // namespace
+
+extern "C" SpmvAmdCgSlab* spmv_amd_cg_slab_create(MatrixData* mat, SpmvAmdComm* comm) { return create_from_matrix(mat, comm, true); }
 
 namespace {
 SpmvAmdCgSlab* create_stencil5_slab(int n, int part_rank, int part_world, SpmvAmdComm* comm) {
@@ -693,8 +720,9 @@ SpmvAmdCgSlab* create_stencil5_slab(int n, int part_rank, int part_world, SpmvAm
     s->row_offset = row_offset;
     s->n_local = n_local;
     s->A.separate_values = wants_coefficient_placement((size_t)n_local);
+    auto phase = std::chrono::steady_clock::now();
     s->A.generate_stencil5(n, row_offset, n_local, 5.0, -1.0, nullptr);
-    HIP_CHECK(hipStreamSynchronize(nullptr));
+    s->setup_ms[0] = setup_phase_ms(phase);
     make_common(s);
     return s;
 }
@@ -1273,6 +1301,12 @@ extern "C" int spmv_amd_cg_slab_placement(const SpmvAmdCgSlab* s, double* out, i
     for (int i = 0; i < count && i < cap; ++i) out[i] = s->placement[i];
     return count;
 }
+// Wall ms of creation's set-up phases (none of it inside any timed region): {matrix to HBM, streams + vectors, verification +
+// launch plans, coefficient placement trial, tile-run trial}. Returns 5.
+extern "C" int spmv_amd_cg_slab_setup_ms(const SpmvAmdCgSlab* s, double* out, int cap) {
+    for (int i = 0; i < 5 && i < cap; ++i) out[i] = s->setup_ms[i];
+    return 5;
+}
 // Row-lds tiles per XCD and run as tuned at creation: {rule, kept, SpMV ms with the rule, ms kept}. Returns 4, or 0 if the
 // trial did not run (small slab, another kernel, SPMV_AMD_ROWLDS_GROUP set).
 extern "C" int spmv_amd_cg_slab_tile_runs(const SpmvAmdCgSlab* s, double* out, int cap) {
@@ -1471,7 +1505,7 @@ int cg_solve_mgpu_partitioned(SpmvOperator* spmv_op, MatrixData* mat, const doub
         printf("Tolerance: %.1e\n", config.tolerance);
         printf("========================================\n\n");
     }
-    SpmvAmdCgSlab* s = spmv_amd_cg_slab_create(mat, comm);
+    SpmvAmdCgSlab* s = create_from_matrix(mat, comm, /*setup_trials=*/false);  // one solve, then destroyed: no timed trials
     if (!s) return 1;
     if (config.verbose >= 1)
         printf("[Rank %d] Rows: [%d:%d) (%d rows), local nnz %lld\n", rank, s->row_offset,

@@ -355,6 +355,10 @@ int spmv_amd_cg_slab_placement(const SpmvAmdCgSlab* s, double* out, int cap);
 /* Row-lds tiles per XCD and run, timed at creation on slabs of >= 16 Mi rows (csrc/device_runtime.hpp, tune_rowlds_xcd_run):
  * {rule, kept, SpMV ms with the rule, ms kept}. Returns 4, or 0 if the trial did not run. Workgroup -> tile mapping only. */
 int spmv_amd_cg_slab_tile_runs(const SpmvAmdCgSlab* s, double* out, int cap);
+/* Wall ms of creation's set-up phases, each closed by a device synchronisation; none of it lies inside a timed region (the
+ * reference builds and uploads before its own, cg_solver_mgpu_partitioned.cu:303-413): {matrix to HBM (upload or generation),
+ * streams + vectors, verification + launch plans, coefficient placement trial, tile-run trial}. Returns 5. */
+int spmv_amd_cg_slab_setup_ms(const SpmvAmdCgSlab* s, double* out, int cap);
 /* The timed in-loop SpMV launches of the last solve, one by one (ms, iteration order). Returns their number. */
 int spmv_amd_cg_slab_spmv_launch_ms(const SpmvAmdCgSlab* s, float* out, int cap);
 /* Loop options of an existing slab (A/B runs on the same allocations; results are bit-identical under every option):

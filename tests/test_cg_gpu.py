@@ -302,6 +302,9 @@ def test_placement_at_set_up_changes_addresses_only(B, O, fresh_host_matrices, m
         assert (rec is None) if cand == "1" else (rec["kind"] == "coefficient candidates" and rec["candidates"] == 3 and rec["spmv_ms_kept"] <= rec["spmv_ms_before"] * 1.001)
         runs = slab.tile_runs()  # row-lds tiles per XCD and run: the rule's neighbours timed at creation, the fastest kept
         assert runs is not None and runs["rule"] == 4 and 1 <= runs["kept"] <= 6 and runs["spmv_ms_kept"] <= runs["spmv_ms_rule"]
+        phases = slab.setup_ms()  # wall time of creation's phases, reported by bench.py beside the timed region
+        assert len(phases) == 5 and all(v >= 0.0 for v in phases.values()) and phases["matrix_to_hbm"] > 0 and phases["tile_runs"] > 0
+        assert (phases["coefficient_placement"] > 1.0) == (cand == "3")  # the trial copies and times 3 x 141 MB; without it the phase is empty
         st = slab.solve()
         each = slab.spmv_launch_ms()
         assert 0 < len(each) <= st.iterations and np.all(each > 0)
