@@ -292,7 +292,7 @@ def probe_role(B, grid, P, r, full_iterations, mailbox, steps=5):
     rec = {"as_rank": r, "neighbours": (1 if r > 0 else 0) + (1 if r < P - 1 else 0), "row_offset": slab.row_offset, "rows": slab.n_local,
            "halo_doubles": grid, "iterations": st.iterations, "ms_per_solve": ms, "wall_ms_per_solve": float(np.median(wall)),
            "us_per_iteration": ms / max(st.iterations, 1) * 1e3, "spmv_us_per_launch": spmv_ms / steps / max(st.iterations, 1) * 1e3,
-           "spmv_us_per_launch_covers": "the interior rows' launch (all but one or two grid rows of the slab), timed every 7th iteration"}
+           "spmv_us_per_launch_covers": "the interior rows' launch (all but one or two grid rows of the slab), every 7th launch timed, phase advancing with every solve"}
     try:  # where this slab's iteration goes: one more solve with stage-boundary events (no host syncs)
         _, tl = slab.timeline_solve(max_iters=full_iterations, tol=0.0)
         rec["stage_us"] = {k: round(v, 1) for k, v in tl.items() if k.endswith("_us")}
@@ -588,12 +588,15 @@ def measure_leg(c, allreduce_kind):
         barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        spmv_ms, spmv_launches, event_ms = 0.0, 0, []
+        # in-loop SpMV launches are event-timed on their own stream inside the solver: every 7th launch, the phase moving on by
+        # one with every solve, so the timed steps cover every iteration of the loop (each pair of events costs two barrier
+        # packets next to the launch; csrc/cg_slab.hip, spmv_event_stride)
+        spmv_each, event_ms = [], []
         for _ in range(args.steps):
             st = slab.solve()
-            spmv_ms += st.time_spmv_ms
-            spmv_launches += st.iterations
+            spmv_each.extend(float(v) for v in slab.spmv_launch_ms())
             event_ms.append(st.time_total_ms)
+        spmv_ms, spmv_launches = float(np.sum(spmv_each)), len(spmv_each)
         torch.cuda.synchronize()
         barrier()
         dt = time.perf_counter() - t0

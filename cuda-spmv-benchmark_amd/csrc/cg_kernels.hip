@@ -346,6 +346,21 @@ __global__ __launch_bounds__(kBlock) void cg_step_and_edges_kernel(StepArgs step
     edge_update_after_step(edges, stage, step.sequence, (int)blockIdx.x, (int)gridDim.x, &s_flag);
 }
 
+// Side stream, in front of the halo exchange: waits until the step's launch `sequence` has raised edges_ready (bounded; a wait
+// that gives up sets *late = 3 and lets the exchange go). Stands where a cross-stream event stood: an event record between
+// the step's launch and the direction update it is followed by cost the compute stream a barrier packet per iteration.
+__global__ void edges_wait_kernel(const unsigned* ready, unsigned sequence, long long timeout_ticks, int* late) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const long long t0 = wall_clock64();
+    while ((int)(__hip_atomic_load(ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - sequence) < 0) {
+        if (wall_clock64() - t0 > timeout_ticks) {
+            __hip_atomic_store(late, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            break;
+        }
+        __builtin_amdgcn_s_sleep(8);
+    }
+}
+
 // Direction update written out of place (deferred x update, cg_slab.hip): p_out = 1.0*r + beta*p_in.
 __global__ __launch_bounds__(kStream) void cg_update_p_ring_kernel(size_t n, const CgScalars* __restrict__ s,
                                                                    const double* __restrict__ r,
@@ -563,7 +578,12 @@ bool launch_cg_scalars_step_and_edges(CgScalars* s, double tol, double* history,
     return true;
 }
 
-int reduce_scratch_doubles() { return kReduceStageBlocks + kReduceExtraMax + 3; }  // sums | extras | ticket | beta | step_ready
+void launch_edges_wait(const ReduceScratch& scratch, int sequence, long long timeout_ticks, int* late, hipStream_t stream) {
+    hipLaunchKernelGGL(edges_wait_kernel, dim3(1), dim3(64), 0, stream, reduce_stage_of(scratch.base).edges_ready, (unsigned)sequence, timeout_ticks,
+                       late);
+}
+
+int reduce_scratch_doubles() { return kReduceStageBlocks + kReduceExtraMax + 4; }  // sums | extras | ticket | beta | step_ready | edges_ready
 
 double* reduce_scratch_alloc() {
     // uncached device memory where the runtime offers it: the slice sums and the ticket are handed between workgroups on

@@ -140,6 +140,7 @@ struct SpmvAmdCgSlab {
     unsigned* d_halo_flag = nullptr;
     unsigned halo_sequence = 0;
     bool halo_flag = true;
+    bool edges_flag = true;     // set_option("edges_flag", 0): a cross-stream event between the step's launch and the exchange instead of the device flag
     bool edges_in_step = true;  // set_option("edges_in_step", 0): RCCL path, the early direction update of the edge rows as a launch of its own (rounds 3-4)
     // Measurement hook, set_option("stop_at", k): iteration k counts as the converging one whatever its residual (kernels.hpp,
     // CgScalars::stop_at). A stand-in slab's periodic system never converges; with max_iters alone it would run one direction
@@ -173,10 +174,13 @@ struct SpmvAmdCgSlab {
     std::vector<double> history;
     // event pairs around every spmv_event_stride-th in-loop SpMV (recorded without any host sync,
     // resolved after the loop): time_spmv_ms with timers off is the live average of those launches
-    // times the iteration count. Stride 1 = every launch; set_option("spmv_event_stride", 4 / 0 (none))
-    // changed a 16 ms solve at 50 M rows by < 0.5 %, so every launch is timed.
+    // times the iteration count. Each pair puts two barrier packets (~7 us each, profiles/r02_slab_timeline.txt) next to the
+    // launch it times, so every 7th launch is timed and the phase moves on by one with every solve: a run of solves covers
+    // every iteration of the loop (later iterations work on other ring slots and are up to 2 % faster or slower).
+    // set_option("spmv_event_stride", 1) times every launch, 0 none.
     std::vector<hipEvent_t> spmv_ev;
-    int spmv_event_stride = 1;
+    int spmv_event_stride = 7;
+    int spmv_event_phase = 0;  // solves so far
     // Sweep-direction alternation: consecutive streaming kernels of the loop walk the vectors in opposite
     // directions, so each starts on the addresses its predecessor touched last and finds part of them in
     // the 256 MiB Infinity Cache. Results and partial slots are independent of the direction. Measured on
@@ -332,10 +336,6 @@ void make_common(SpmvAmdCgSlab* s) {
         HIP_CHECK(hipMemset(s->d_alpha_ring, 0, kMaxRingSlots * sizeof(double)));
     }
     s->shape = current_launch_shape();
-    // every launch is timed on big slabs; below 100 M rows (multi-GPU slabs: an iteration under 2 ms) every 7th, since
-    // each event pair puts ~7 us of queue barriers next to the SpMV (rocprofv3 timeline, profiles/r02_slab_timeline.txt);
-    // set_option("spmv_event_stride") changes it
-    s->spmv_event_stride = nl >= 100000000 ? 1 : 7;
     if (const char* v = getenv("SPMV_AMD_NO_OVERLAP")) s->no_overlap = v[0] == '1';
     if (const char* v = getenv("SPMV_AMD_TEST_WEDGE_OVERLAPPED_EXCHANGE")) s->test_wedge_overlapped_exchange = v[0] == '1';
     if (const char* v = getenv("SPMV_AMD_ROCTX")) s->roctx_always = v[0] == '1';
@@ -890,6 +890,10 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
         printf("[%s] Initial residual: %e\n", s->label, now.b_norm);
     }
     bool halo_in_flight = false;
+    // edges_by_flag (RCCL path, round 5): the rows to send were written by the step's launch, which raises a device flag once
+    // they have reached memory; the side stream waits for that flag with a one-thread launch instead of for an event recorded
+    // between the step's launch and the direction update (a barrier packet on the compute stream per iteration).
+    bool edges_by_flag = false;
     auto start_p_halo = [&] {  // halo rows of the new p: side stream, under the interior SpMV
         if (!multi) return;
         // SPMV_AMD_NO_OVERLAP=1: exchange on the compute stream, for A/B runs of the overlap
@@ -898,8 +902,13 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
             halo_in_flight = false;
             return;
         }
-        HIP_CHECK(hipEventRecord(s->ev_p_ready, s->compute));
-        HIP_CHECK(hipStreamWaitEvent(s->side, s->ev_p_ready, 0));
+        if (edges_by_flag) {
+            const double limit_s = watchdog_limit_seconds() > 0.0 && watchdog_limit_seconds() < 40.0 ? 0.5 * watchdog_limit_seconds() : 20.0;
+            launch_edges_wait(s->scratch(), s->poll_sequence, (long long)(limit_s * 1e8), &s->h_poll->halo_late, s->side);
+        } else {
+            HIP_CHECK(hipEventRecord(s->ev_p_ready, s->compute));
+            HIP_CHECK(hipStreamWaitEvent(s->side, s->ev_p_ready, 0));
+        }
         if (timeline) HIP_CHECK(hipEventRecord(tl_event(s->tl_side, 2 * (size_t)tl_exchanges), s->side));
         exchange_p_halo(s, s->side);
         launch_halo_arrived(s->d_halo_flag, ++s->halo_sequence, s->side);
@@ -938,7 +947,7 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
         } else if (detail) {
             timed(&stats->time_spmv_ms, nullptr, [&] { slab_spmv(s, true, halo_in_flight, skip); });
         } else {
-            const bool sample = s->spmv_event_stride > 0 && enqueued % s->spmv_event_stride == 0;
+            const bool sample = s->spmv_event_stride > 0 && (enqueued + s->spmv_event_phase) % s->spmv_event_stride == 0;
             if (sample) {
                 while (s->spmv_ev.size() < 2 * (size_t)(sampled + 1)) {
                     hipEvent_t e;
@@ -1098,6 +1107,7 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
             };
             timed(&stats->time_blas1_ms, &stats->time_axpby_update_p_ms, [&] {
                 if (early_halo) {
+                    edges_by_flag = edges_done && s->edges_flag;
                     if (edges_done)
                         ;  // those rows were updated behind the scalar step, inside its launch
                     else if (head_rows > 0 && tail_rows > 0)  // a rank with two neighbours: both grid rows in one launch
@@ -1110,6 +1120,7 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
                         TraceScope r(trace, "Halo_Exchange");
                         start_p_halo();
                     }
+                    edges_by_flag = false;
                     trace.push("BLAS_AXPBY");
                     bulk(ring_update, head_rows, tail_start);
                 } else {
@@ -1131,8 +1142,9 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
             // worded like the host watchdog's report: bench.py's supervisors read that sentence and restart the ranks once without the overlap
             fprintf(stderr, "\n[spmv_amd watchdog] rank %d: no progress for %.1f s in stage '%s' (CG iteration %d)\n", comm->rank,
                     watchdog_limit_seconds() > 0.0 && watchdog_limit_seconds() < 40.0 ? 0.5 * watchdog_limit_seconds() : 20.0,
-                    gave_up == 2 ? "scalar step's hand-over (in-kernel wait of the edge rows' direction update)"
-                                 : "halo arrival flag (in-kernel wait of the boundary rows)",
+                    gave_up == 3   ? "edge rows' ready flag (side-stream wait in front of the halo exchange)"
+                    : gave_up == 2 ? "scalar step's hand-over (in-kernel wait of the edge rows' direction update)"
+                                   : "halo arrival flag (in-kernel wait of the boundary rows)",
                     enqueued - 1);
             report_slab_state(s, stderr);
             exit(EXIT_FAILURE);
@@ -1235,6 +1247,7 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
         }
         stats->time_spmv_ms = used > 0 ? ms_sum / used * fin.iterations : 0.0;
     }
+    ++s->spmv_event_phase;
     s->last_spmv_ms = stats->time_spmv_ms;
     s->last_spmv_launches = fin.iterations;
     stats->iterations = fin.iterations;
@@ -1337,6 +1350,7 @@ extern "C" int spmv_amd_cg_slab_set_option(SpmvAmdCgSlab* s, const char* name, l
     else if (strcmp(name, "no_overlap") == 0) s->no_overlap = value != 0;
     else if (strcmp(name, "halo_flag") == 0) s->halo_flag = value != 0;
     else if (strcmp(name, "edges_in_step") == 0) s->edges_in_step = value != 0;
+    else if (strcmp(name, "edges_flag") == 0) s->edges_flag = value != 0;
     else if (strcmp(name, "stop_at") == 0) s->stop_at = value > 0 ? (int)value : 0;
     else if (strcmp(name, "spmv_event_stride") == 0) s->spmv_event_stride = (int)value;
     else return -1;

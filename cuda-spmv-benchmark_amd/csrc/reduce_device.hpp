@@ -112,13 +112,15 @@ struct ReduceStage {
     unsigned* ticket;
     unsigned long long* beta;   // EdgeUpdate: beta of the step just taken, as bits
     unsigned* step_ready;       // EdgeUpdate: 2 * sequence + converged, raised behind beta
+    unsigned* edges_ready;      // EdgeUpdate: sequence, raised once every workgroup's share of the edge rows has reached memory
 };
 
-// scratch layout (kernels.hpp, ReduceScratch): [kReduceStageBlocks sums | kReduceExtraMax extras | ticket]
+// scratch layout (kernels.hpp, ReduceScratch): [kReduceStageBlocks sums | kReduceExtraMax extras | ticket | beta | step_ready | edges_ready]
 __host__ __device__ inline ReduceStage reduce_stage_of(double* base) {
     unsigned long long* b = reinterpret_cast<unsigned long long*>(base);
-    return ReduceStage{b, b + kReduceStageBlocks, reinterpret_cast<unsigned*>(b + kReduceStageBlocks + kReduceExtraMax),
-                       b + kReduceStageBlocks + kReduceExtraMax + 1, reinterpret_cast<unsigned*>(b + kReduceStageBlocks + kReduceExtraMax + 2)};
+    unsigned long long* tail = b + kReduceStageBlocks + kReduceExtraMax;
+    return ReduceStage{b, b + kReduceStageBlocks, reinterpret_cast<unsigned*>(tail), tail + 1, reinterpret_cast<unsigned*>(tail + 2),
+                       reinterpret_cast<unsigned*>(tail + 3)};
 }
 // Slice workgroups of a reduction over `count` partials: one up to 1024 partials, else ceil(count / slice) with
 // slice = ceil(count / kReduceStageBlocks).
@@ -223,17 +225,32 @@ __device__ __forceinline__ void edge_update_after_step(const EdgeUpdate& e, cons
         *s_flag = (int)(seen & 1u);
     }
     __syncthreads();
-    if (*s_flag != 0) return;  // the iteration converged (or the wait gave up): no direction is needed
-    const double beta = published(stage.beta);
-    typedef double edge_d2 __attribute__((ext_vector_type(2)));
-    const size_t pairs_a = e.count_a >> 1, pairs = (e.count_a + e.count_b) >> 1, shift = (e.second - e.count_a) >> 1;
-    for (size_t i = (size_t)block * kReduceBlock + threadIdx.x; i < pairs; i += (size_t)blocks * kReduceBlock) {
-        const size_t at = i < pairs_a ? i : i + shift;
-        const edge_d2 rv = reinterpret_cast<const edge_d2*>(e.r)[at];
-        edge_d2 pv = reinterpret_cast<const edge_d2*>(e.p_in)[at];
-        pv.x = e.fma_form ? fma(beta, pv.x, rv.x) : fma(1.0, rv.x, beta * pv.x);  // cg_kernels.hip, direction()
-        pv.y = e.fma_form ? fma(beta, pv.y, rv.y) : fma(1.0, rv.y, beta * pv.y);
-        reinterpret_cast<edge_d2*>(e.p_out)[at] = pv;
+    if (*s_flag == 0) {  // else the iteration converged (or the wait gave up): no direction is needed
+        const double beta = published(stage.beta);
+        const size_t pairs_a = e.count_a >> 1, pairs = (e.count_a + e.count_b) >> 1, shift = (e.second - e.count_a) >> 1;
+        for (size_t i = (size_t)block * kReduceBlock + threadIdx.x; i < pairs; i += (size_t)blocks * kReduceBlock) {
+            const size_t at = 2 * (i < pairs_a ? i : i + shift);
+            const double p0 = e.fma_form ? fma(beta, e.p_in[at], e.r[at]) : fma(1.0, e.r[at], beta * e.p_in[at]);  // cg_kernels.hip, direction()
+            const double p1 = e.fma_form ? fma(beta, e.p_in[at + 1], e.r[at + 1]) : fma(1.0, e.r[at + 1], beta * e.p_in[at + 1]);
+            // agent-scope stores: written through to the memory side, so that the launch that sends these rows may be released by
+            // edges_ready instead of by this launch's end (no L2 write-back of everything else the XCD holds)
+            __hip_atomic_store(reinterpret_cast<unsigned long long*>(e.p_out + at), (unsigned long long)__double_as_longlong(p0), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(reinterpret_cast<unsigned long long*>(e.p_out + at + 1), (unsigned long long)__double_as_longlong(p1), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this lane's stores have been acknowledged
+    }
+    // edges_ready <- sequence by the workgroup that finishes last, converged or not: the side stream's wait in front of the halo
+    // exchange (cg_kernels.hip, edges_wait_kernel) is released either way. The ticket is the reductions' (no reduction is in
+    // flight on this stream while the step's launch runs) and returns to zero.
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned drawn = __hip_atomic_fetch_add(stage.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (drawn == (unsigned)(blocks - 1)) {
+            __hip_atomic_store(stage.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(stage.edges_ready, (unsigned)sequence, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 

@@ -366,7 +366,8 @@ int spmv_amd_cg_slab_spmv_launch_ms(const SpmvAmdCgSlab* s, float* out, int cap)
  * rounds 2-4 and a separate boundary-row launch), "no_overlap" 0/1 (1 = halo exchange on the compute stream),
  * "halo_flag" 0/1 (0 = a cross-stream event wait in front of the boundary rows instead of their own wait for the arrival flag),
  * "edges_in_step" 0/1 (RCCL path; 0 = the early direction update of the edge rows as a launch of its own, not inside the step's),
- * "spmv_event_stride" N (time every N-th in-loop SpMV launch, 0 = none). The one option that is NOT result-neutral, a timing
+ * "edges_flag" 0/1 (RCCL path; 0 = the exchange behind those rows waits for a cross-stream event, not for the launch's device flag),
+ * "spmv_event_stride" N (time every N-th in-loop SpMV launch -- default 7, phase advancing with every solve --, 0 = none). The one option that is NOT result-neutral, a timing
  * aid for stand-in slabs: "stop_at" K (iteration K counts as the converging one whatever its residual; 0 = off).
  * 0, or -1 = unknown name. */
 int spmv_amd_cg_slab_set_option(SpmvAmdCgSlab* s, const char* name, long long value);

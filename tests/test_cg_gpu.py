@@ -395,11 +395,13 @@ def test_loop_options_leave_every_bit_alone(B, monkeypatch, n, P, r):
         for opts in ({"late_bulk": 1, "lead_rows": 50000}, {"late_bulk": 1, "lead_rows": 512}, {"late_bulk": 0, "reduce_one_launch": 1},
                      {"late_bulk": 1, "lead_rows": 50000, "reduce_one_launch": 1}, {"reduce_one_launch": 1, "no_overlap": 1},
                      {"reduce_one_launch": 0, "no_overlap": 1}, {"reduce_one_launch": 1, "halo_flag": 0}, {"reduce_one_launch": 1, "halo_flag": 1, "late_bulk": 1, "lead_rows": 512},
-                     {"reduce_one_launch": 1, "edges_in_step": 0}, {"reduce_one_launch": 0, "edges_in_step": 0, "late_bulk": 1, "lead_rows": 512}):
+                     {"reduce_one_launch": 1, "edges_in_step": 0}, {"reduce_one_launch": 0, "edges_in_step": 0, "late_bulk": 1, "lead_rows": 512},
+                     {"reduce_one_launch": 1, "edges_flag": 0}):
             for k in ("late_bulk", "reduce_one_launch", "no_overlap"):
                 slab.set_option(k, opts.get(k, 0))
             slab.set_option("halo_flag", opts.get("halo_flag", 1))
             slab.set_option("edges_in_step", opts.get("edges_in_step", 1))
+            slab.set_option("edges_flag", opts.get("edges_flag", 1))
             slab.set_option("lead_rows", opts.get("lead_rows", 1 << 24))
             st = slab.solve(**kw)
             assert (st.iterations, st.converged) == (st0.iterations, st0.converged) and np.array_equal(slab.history(), h0), (ring, opts)
@@ -421,8 +423,9 @@ def test_edge_rows_updated_inside_the_step_launch(B, monkeypatch, collectives, n
     the step (kernels.hpp, EdgeRows), once the step's workgroup has handed beta on. Against the separate launch of rounds 3-4
     (edges_in_step = 0), with the direction ring wrapping (ring 4: every fourth iteration falls back to the separate launch)
     and not, on wide slabs with one and two neighbours: the residual history (every direction feeds the next residual)
-    bit-identical. collectives = 0 (no all-reduce call between sum and step: the shape of the mailbox path, where the merge
-    is not built) checks that the option is inert there."""
+    bit-identical. The exchange behind it is released by the device flag the step's launch raises once its rows have reached
+    memory (edges_flag, default) or by a cross-stream event (edges_flag = 0). collectives = 0 (no all-reduce call between sum
+    and step: the shape of the mailbox path, where the merge is not built) checks that the options are inert there."""
     monkeypatch.setenv("SPMV_AMD_SELF_NEIGHBOUR", "1")
     monkeypatch.setenv("SPMV_AMD_FORCE_COLLECTIVES", collectives)
     for ring in ("16", "4"):
@@ -433,9 +436,9 @@ def test_edge_rows_updated_inside_the_step_launch(B, monkeypatch, collectives, n
         slab.set_option("edges_in_step", 0)
         st0 = slab.solve(**kw)
         h0 = slab.history().copy()
-        for opts in ({}, {"late_bulk": 0}, {"halo_flag": 0}, {"reduce_one_launch": 0}):
+        for opts in ({}, {"late_bulk": 0}, {"halo_flag": 0}, {"reduce_one_launch": 0}, {"edges_flag": 0}, {"edges_flag": 0, "halo_flag": 0}):
             slab.set_option("edges_in_step", 1)
-            for k in ("late_bulk", "halo_flag", "reduce_one_launch"):
+            for k in ("late_bulk", "halo_flag", "reduce_one_launch", "edges_flag"):
                 slab.set_option(k, opts.get(k, 1))
             st = slab.solve(**kw)
             assert st.iterations == st0.iterations and np.array_equal(slab.history(), h0), (ring, opts)
