@@ -9,7 +9,17 @@ import sys
 path = sys.argv[1]
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 14
 rows = list(csv.DictReader(open(path)))
-ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows), key=lambda e: e[0])
+# idle time is that of the COMPUTE stream: the queue the SpMV launches run on. Side-stream launches (the halo exchange, its arrival
+# flag, round 5's one-thread wait in front of it, which polls for most of an iteration) overlap it and are listed separately.
+queues = {}
+for r in rows:
+    if "stencil5" in r["Kernel_Name"] or "csr_" in r["Kernel_Name"] or "ell_" in r["Kernel_Name"]:
+        queues[r["Queue_Id"]] = queues.get(r["Queue_Id"], 0) + 1
+compute_queue = max(queues, key=queues.get) if queues else None
+side = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows if compute_queue is not None and r["Queue_Id"] != compute_queue),
+              key=lambda e: e[0])
+ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows if compute_queue is None or r["Queue_Id"] == compute_queue),
+            key=lambda e: e[0])
 # A solve starts with its initial SpMV. Anchors, in order of preference: the mode-2 SpMV launches (row-lds / row-planes
 # with the initial residual fused in: the default), else cg_init_residual (slabs that do not run row-lds) backed up
 # over the SpMV launches in front of it, else cg_scalars_init (which directly follows the initial reductions).
@@ -57,6 +67,16 @@ by_next = collections.defaultdict(lambda: [0, 0])
 for g, nxt in gaps:
     by_next[nxt][0] += g
     by_next[nxt][1] += 1
+side_busy = collections.OrderedDict()
+for s, e, name in side:
+    if s < t_begin:
+        continue
+    short = name.replace("(anonymous namespace)::", "").replace("spmv_amd::", "").replace("void ", "").split("(")[0]
+    side_busy.setdefault(short, [0, 0])
+    side_busy[short][0] += e - s
+    side_busy[short][1] += 1
+for k, (ns, cnt) in side_busy.items():
+    print(f"  (other queue) {cnt:4d} x {ns / cnt / 1e3:8.2f} us  {k[:100]}")
 print("idle time in front of each kernel kind:")
 for k, (ns, cnt) in sorted(by_next.items(), key=lambda kv: -kv[1][0]):
     print(f"  {ns / 1e3:10.1f} us  {cnt:4d} x {ns / cnt / 1e3:8.2f} us  before {k[:90]}")
