@@ -12,6 +12,6 @@ export TMPDIR=/tmp
 for AR in rccl mailbox; do
   rocprofv3 --kernel-trace --output-format csv -d "$OUT/trace_$AR" -- python3 tools/probe_slab.py $P $R 5 $AR > "$OUT/probe_$AR.txt" 2>&1
   F=$(find "$OUT/trace_$AR" -name "*kernel_trace.csv" | head -1)
-  { echo "== slab $R of $P, all-reduce: $AR"; grep -E "^slab|^stage timeline" "$OUT/probe_$AR.txt"; python3 tools/trace_gaps.py "$F" 14; } > "$OUT/timeline_$AR.txt" 2>&1
+  { echo "== slab $R of $P, all-reduce: $AR"; grep -E "^slab|^stage timeline" "$OUT/probe_$AR.txt"; python3 tools/trace_gaps.py "$F" 14 -2; echo "-- the extra solve with stage-boundary events (a barrier packet in front of every stage):"; python3 tools/trace_gaps.py "$F" 14 -1 | tail -8; } > "$OUT/timeline_$AR.txt" 2>&1
   cat "$OUT/timeline_$AR.txt"
 done

@@ -1,13 +1,17 @@
 #!/usr/bin/env python3
 """Per-iteration timeline from a rocprofv3 --kernel-trace CSV of tools/probe_slab.py: for the LAST solve in the trace,
 the busy time of each kernel kind, the idle time between consecutive kernels on the GPU, and the wall span.
-usage: python tools/trace_gaps.py <..._kernel_trace.csv> [iterations=14]"""
+usage: python tools/trace_gaps.py <..._kernel_trace.csv> [iterations=14] [solve=-2]
+solve: which solve of the trace, counted from the end; -1 is the LAST one -- in tools/probe_slab.py and bench.py that is the extra solve
+with stage-boundary events (spmv_amd_cg_slab_set_timeline), whose event records put a barrier packet (~6 us) between ALL stages;
+-2 (default) is the last plain solve, where dependent launches follow each other without such packets."""
 import csv
 import collections
 import sys
 
 path = sys.argv[1]
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 14
+which = int(sys.argv[3]) if len(sys.argv) > 3 else -2
 rows = list(csv.DictReader(open(path)))
 # idle time is that of the COMPUTE stream: the queue the SpMV launches run on. Side-stream launches (the halo exchange, its arrival
 # flag, round 5's one-thread wait in front of it, which polls for most of an iteration) overlap it and are listed separately.
@@ -28,10 +32,12 @@ def is_init_spmv(name):
 
 
 idx = [i for i, e in enumerate(ev) if is_init_spmv(e[2])]
+stop = len(ev)
 if idx:
-    start = idx[-1]
-    while start > 0 and is_init_spmv(ev[start - 1][2]):  # interior + boundary-row launches of a split initial SpMV
-        start -= 1
+    starts = [i for i in idx if i == 0 or not is_init_spmv(ev[i - 1][2])]  # interior + boundary-row launches of a split initial SpMV count once
+    k = which if -len(starts) <= which < 0 else -1
+    start = starts[k]
+    stop = starts[k + 1] if k + 1 < 0 else len(ev)
 else:
     idx = [i for i, e in enumerate(ev) if "cg_init_residual" in e[2]]
     if idx:
@@ -45,7 +51,7 @@ else:
         start = idx[-1]
         while start > 0 and ("reduce_" in ev[start - 1][2] or "stencil5" in ev[start - 1][2] or "Generic" in ev[start - 1][2]):
             start -= 1
-solve = ev[max(start, 0):]
+solve = ev[max(start, 0):stop]
 t_begin, t_end = solve[0][0], max(e[1] for e in solve)
 busy = collections.OrderedDict()
 covered, cursor, gaps = 0, solve[0][0], []
@@ -59,7 +65,7 @@ for s, e, name in solve:
     if e > cursor:
         covered += e - max(s, cursor)
         cursor = e
-print(f"last solve: {len(solve)} kernels, span {(t_end - t_begin) / 1e3:.1f} us, GPU busy (union) {covered / 1e3:.1f} us, "
+print(f"solve {which} of the trace: {len(solve)} kernels, span {(t_end - t_begin) / 1e3:.1f} us, GPU busy (union) {covered / 1e3:.1f} us, "
       f"idle {(t_end - t_begin - covered) / 1e3:.1f} us = {(t_end - t_begin - covered) / 1e3 / iters:.1f} us per iteration")
 for k, (ns, cnt) in sorted(busy.items(), key=lambda kv: -kv[1][0]):
     print(f"  {ns / 1e3:10.1f} us  {cnt:4d} x {ns / cnt / 1e3:8.2f} us  {k[:100]}")
@@ -69,7 +75,7 @@ for g, nxt in gaps:
     by_next[nxt][1] += 1
 side_busy = collections.OrderedDict()
 for s, e, name in side:
-    if s < t_begin:
+    if s < t_begin or s > t_end:
         continue
     short = name.replace("(anonymous namespace)::", "").replace("spmv_amd::", "").replace("void ", "").split("(")[0]
     side_busy.setdefault(short, [0, 0])
