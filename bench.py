@@ -57,6 +57,7 @@ configuration of reference docs/PROBLEM_SIZE_SCALING_RESULTS.md:40-47, on N row 
             iteration and around every halo exchange (no host syncs, overlap intact): interior SpMV, wait for the halo +
             boundary rows, p.Ap sum + all-reduce, r update, r.r sum + all-reduce + scalar step, direction update, gap
             before the next iteration; max / min over the ranks as the reference reports its timers (mgpu :748-800).
+            Each of those events is a barrier packet (~6 us): the breakdown solve is ~40 us per iteration slower than a timed one.
   allreduce_ab  (opt-in: --allreduce-ab, multi-rank runs) `value` is north_star's path: RCCL send/recv halos + ncclAllReduce on
             the two dot products. With the flag the same K steps are then repeated with the peer-mailbox all-reduce
             (csrc/mailbox.hip) in CHILD processes, one per rank: {"rccl": ms, "mailbox": ms | null, "other_leg": {...}}. The
@@ -649,7 +650,9 @@ def breakdown_summary(per_rank):
     keys = [k for k in per_rank[0] if k not in ("rank", "rows", "iterations")]
     return {"unit": "us per iteration, average over the counted iterations of ONE extra solve with stage-boundary HIP events (no host "
                     "syncs, outside the timed region); solve_ms / timeline_solve_ms in ms; a stage runs from the end of the previous "
-                    "stage to the end of its own last kernel, so waiting is inside the stage that waits",
+                    "stage to the end of its own last kernel, so waiting is inside the stage that waits; every event record is a barrier packet "
+                    "on the stream (~6 us), so this solve is ~40 us per iteration slower than a timed one and the small stages are mostly "
+                    "that packet (profiles/r05_slab_timeline_p8.txt)",
             "max_over_ranks": {k: max(r[k] for r in per_rank) for k in keys}, "min_over_ranks": {k: min(r[k] for r in per_rank) for k in keys},
             "per_rank": per_rank}
 
