@@ -115,9 +115,12 @@ def test_trace_gaps_finds_the_last_solve_by_every_anchor(tmp_path):
                "spmv_amd::(anonymous namespace)::cg_init_residual_kernel(unsigned long, ...)"]
     bare = ["spmv_amd::(anonymous namespace)::reduce_partials_kernel(double const*, ...)"]
     for first, kernels_in_solve in ((fused, 2 + 1 + 12), (unfused, 2 + 1 + 12), (bare, 1 + 1 + 12)):
-        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "trace_gaps.py"), str(trace(first)), "3"], capture_output=True, text=True, timeout=60)
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "trace_gaps.py"), str(trace(first)), "3", "-1"], capture_output=True, text=True, timeout=60)
         assert out.returncode == 0, out.stderr
-        assert f"last solve: {kernels_in_solve} kernels" in out.stdout, out.stdout
+        assert f"solve -1 of the trace: {kernels_in_solve} kernels" in out.stdout, out.stdout
+    # the default is the last solve BUT ONE (the last one of a probe's trace carries stage-boundary events): same length here
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "trace_gaps.py"), str(trace(fused)), "3"], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0 and "solve -2 of the trace: 15 kernels" in out.stdout, out.stdout + out.stderr
 
 
 def test_bench_parity_gate_logic_on_the_cpu(golden):

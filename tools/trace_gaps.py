@@ -18,11 +18,11 @@ rows = list(csv.DictReader(open(path)))
 queues = {}
 for r in rows:
     if "stencil5" in r["Kernel_Name"] or "csr_" in r["Kernel_Name"] or "ell_" in r["Kernel_Name"]:
-        queues[r["Queue_Id"]] = queues.get(r["Queue_Id"], 0) + 1
+        queues[r.get("Queue_Id", "")] = queues.get(r.get("Queue_Id", ""), 0) + 1
 compute_queue = max(queues, key=queues.get) if queues else None
-side = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows if compute_queue is not None and r["Queue_Id"] != compute_queue),
+side = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows if compute_queue is not None and r.get("Queue_Id", "") != compute_queue),
               key=lambda e: e[0])
-ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows if compute_queue is None or r["Queue_Id"] == compute_queue),
+ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows if compute_queue is None or r.get("Queue_Id", "") == compute_queue),
             key=lambda e: e[0])
 # A solve starts with its initial SpMV. Anchors, in order of preference: the mode-2 SpMV launches (row-lds / row-planes
 # with the initial residual fused in: the default), else cg_init_residual (slabs that do not run row-lds) backed up
