@@ -5,9 +5,10 @@
 // way, completes the sum across the ranks (peer mailbox, optional) and runs the CG scalar step (optional). The slice stage is
 // round 2's, so every sum without extras keeps its bits; the EXTRA values are the partials of a split SpMV's boundary rows
 // (the slab's first / last grid row), which enter in the second stage whichever launch computed them -- the same sum, bit
-// for bit, whether the rows ran in a launch of their own or inside the reducing launch (spmv_kernels.hip). Rounds 2-4 issued these as two launches (reduce_slices_kernel, reduce_partials_kernel): 13-17 us per
-// dot product on the P = 8 slab of the headline grid and 29 us at 4e8 rows, two of them per iteration -- half of the fixed cost
-// that keeps a 1/P slab from costing T1/P (profiles/r05_slab_attribution.txt). Two changes:
+// for bit, whether the rows ran in a launch of their own or inside the reducing launch (spmv_kernels.hip). Rounds 2-4 issued
+// these as two launches (reduce_slices_kernel, reduce_final_kernel): 13-17 us per dot product on the P = 8 slab of the headline
+// grid and 29 us at 4e8 rows, two of them per iteration -- half of the fixed cost that keeps a 1/P slab from costing T1/P
+// (profiles/r05_slab_attribution.txt). Two changes:
 //  * the slice loop issues sixteen independent loads before it adds them (same order of additions): the two-launch kernel walked
 //    its 6-48 partials per thread as a chain of dependent load -> add steps, ~0.6 us each;
 //  * the workgroup that finishes LAST does the second stage in the same launch. Hand-over without cache maintenance: a slice
