@@ -346,6 +346,15 @@ __global__ __launch_bounds__(kBlock) void cg_step_and_edges_kernel(StepArgs step
     edge_update_after_step(edges, stage, step.sequence, (int)blockIdx.x, (int)gridDim.x, &s_flag);
 }
 
+// The edge rows' direction update as a launch of its own (behind a launch that held the scalar step: the peer-mailbox path, a single
+// rank with neighbours, the ring's wrap iterations), announcing them like the step's launch does -- the exchange behind it is
+// then released by edges_ready as well. The launch of a converged iteration writes nothing and still announces.
+__global__ __launch_bounds__(kBlock) void cg_edges_kernel(const CgScalars* __restrict__ s, int iteration, ReduceStage stage, EdgeUpdate edges,
+                                                          int sequence) {
+    const bool skip = s->iterations != iteration || s->converged != 0;
+    edge_rows_write_and_announce(edges, skip ? 0.0 : s->beta, skip, stage, sequence, (int)blockIdx.x, (int)gridDim.x);
+}
+
 // Side stream, in front of the halo exchange: waits until the step's launch `sequence` has raised edges_ready (bounded; a wait
 // that gives up sets *late = 3 and lets the exchange go). Stands where a cross-stream event stood: an event record between
 // the step's launch and the direction update it is followed by cost the compute stream a barrier packet per iteration.
@@ -575,6 +584,16 @@ bool launch_cg_scalars_step_and_edges(CgScalars* s, double tol, double* history,
     hipLaunchKernelGGL(cg_step_and_edges_kernel, dim3(blocks < 1 ? 1 : (blocks > 256 ? 256 : blocks)), dim3(kBlock), 0, stream,
                        StepArgs{s, tol, history, host_record, sequence, alpha_ring, ring_slots}, reduce_stage_of(scratch.base),
                        EdgeUpdate{e.r, e.p_in, e.p_out, e.count_a, e.second, e.count_b, e.fma_form ? 1 : 0, e.timeout_ticks, e.late});
+    return true;
+}
+
+bool launch_cg_edges(const CgScalars* s, int iteration, int sequence, hipStream_t stream, const ReduceScratch& scratch, const EdgeRows& e) {
+    if (scratch.base == nullptr || e.count_a + e.count_b == 0) return false;
+    const size_t pairs = (e.count_a + e.count_b) >> 1;
+    const unsigned blocks = (unsigned)((pairs + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(cg_edges_kernel, dim3(blocks < 1 ? 1 : (blocks > 256 ? 256 : blocks)), dim3(kBlock), 0, stream, s, iteration,
+                       reduce_stage_of(scratch.base),
+                       EdgeUpdate{e.r, e.p_in, e.p_out, e.count_a, e.second, e.count_b, e.fma_form ? 1 : 0, e.timeout_ticks, e.late}, sequence);
     return true;
 }
 

@@ -1006,7 +1006,7 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
         const bool edges_in_step = separate && early_halo && s->edges_in_step && slots > 1 && next_iteration - window_start < slots;
         bool edges_done = false;
         EdgeRows edge_rows{};
-        if (edges_in_step) {
+        if (early_halo && slots > 1) {
             const double limit_s = watchdog_limit_seconds() > 0.0 && watchdog_limit_seconds() < 40.0 ? 0.5 * watchdog_limit_seconds() : 20.0;
             edge_rows = EdgeRows{r_cur, s->p, s->ring[(size_t)(next_iteration % slots)], head_rows, tail_start, tail_rows, s->device_form,
                                  (long long)(limit_s * 1e8), &s->h_poll->halo_late};
@@ -1107,9 +1107,13 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
             };
             timed(&stats->time_blas1_ms, &stats->time_axpby_update_p_ms, [&] {
                 if (early_halo) {
+                    // (edge_rows was filled in before a window flush could move the ring on: this iteration's output slot)
+                    edge_rows.p_out = p_next;
+                    if (!edges_done && s->edges_flag)  // a launch of their own that announces them by flag, like the step's launch does
+                        edges_done = launch_cg_edges(s->d_s, enqueued, s->poll_sequence, s->compute, s->scratch(), edge_rows);
                     edges_by_flag = edges_done && s->edges_flag;
                     if (edges_done)
-                        ;  // those rows were updated behind the scalar step, inside its launch
+                        ;  // those rows were updated behind the scalar step (inside its launch, or by launch_cg_edges)
                     else if (head_rows > 0 && tail_rows > 0)  // a rank with two neighbours: both grid rows in one launch
                         launch_cg_update_p_ring_two_ranges(head_rows, tail_start, tail_rows, s->d_s, r_cur, p_in, p_next, enqueued, s->compute, s->device_form);
                     else

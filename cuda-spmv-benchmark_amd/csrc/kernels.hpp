@@ -272,6 +272,9 @@ void launch_reduce_partials_and_step(const double* partials, int count, double* 
 // Returns false, having launched nothing, without a scratch.
 bool launch_cg_scalars_step_and_edges(CgScalars* s, double tol, double* history, int* host_record, int sequence, hipStream_t stream,
                                       double* alpha_ring, int ring_slots, const ReduceScratch& scratch, const EdgeRows& edge_rows);
+// The same update as a launch of its own behind a launch that already took the step (iteration: as launch_cg_update_p_ring's),
+// announcing the rows through the scratch like the step's launch does. Returns false, having launched nothing, without a scratch.
+bool launch_cg_edges(const CgScalars* s, int iteration, int sequence, hipStream_t stream, const ReduceScratch& scratch, const EdgeRows& edge_rows);
 // Side stream: one thread waits (bounded) until the step-and-edges launch `sequence` on the compute stream has written its edge
 // rows through to memory; the halo exchange enqueued behind it then needs no cross-stream event. *late = 3 if it gave up.
 void launch_edges_wait(const ReduceScratch& scratch, int sequence, long long timeout_ticks, int* late, hipStream_t stream);

@@ -208,8 +208,38 @@ __device__ __forceinline__ void publish_step(const ReduceStage& stage, const CgS
     __hip_atomic_store(stage.step_ready, 2u * (unsigned)sequence + (s->converged ? 1u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Called by ALL threads of EVERY workgroup of the launch (block `block` of `blocks`): waits for publish_step of `sequence`,
-// then updates this workgroup's share of the edge rows. s_flag: one int of LDS.
+// Called by ALL threads of EVERY workgroup of a launch of `blocks` workgroups: this workgroup's share of the edge rows (unless
+// `skip`: the iteration converged), written THROUGH to the memory side with agent-scope stores -- so that the launch that
+// sends these rows may be released by edges_ready instead of by this launch's end, with no L2 write-back of everything else
+// the XCD holds -- then edges_ready <- sequence by the workgroup that finishes last, converged or not: the side stream's wait
+// in front of the halo exchange (cg_kernels.hip, edges_wait_kernel) is released either way. The ticket is the reductions'
+// (no reduction is in flight on this stream while such a launch runs) and returns to zero.
+__device__ __forceinline__ void edge_rows_write_and_announce(const EdgeUpdate& e, double beta, bool skip, const ReduceStage& stage, int sequence,
+                                                             int block, int blocks) {
+    if (!skip) {
+        const size_t pairs_a = e.count_a >> 1, pairs = (e.count_a + e.count_b) >> 1, shift = (e.second - e.count_a) >> 1;
+        for (size_t i = (size_t)block * kReduceBlock + threadIdx.x; i < pairs; i += (size_t)blocks * kReduceBlock) {
+            const size_t at = 2 * (i < pairs_a ? i : i + shift);
+            const double p0 = e.fma_form ? fma(beta, e.p_in[at], e.r[at]) : fma(1.0, e.r[at], beta * e.p_in[at]);  // cg_kernels.hip, direction()
+            const double p1 = e.fma_form ? fma(beta, e.p_in[at + 1], e.r[at + 1]) : fma(1.0, e.r[at + 1], beta * e.p_in[at + 1]);
+            __hip_atomic_store(reinterpret_cast<unsigned long long*>(e.p_out + at), (unsigned long long)__double_as_longlong(p0), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(reinterpret_cast<unsigned long long*>(e.p_out + at + 1), (unsigned long long)__double_as_longlong(p1), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this lane's stores have been acknowledged
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned drawn = __hip_atomic_fetch_add(stage.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (drawn == (unsigned)(blocks - 1)) {
+            __hip_atomic_store(stage.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(stage.edges_ready, (unsigned)sequence, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// The same inside the step's own launch: every workgroup first waits (bounded) for publish_step of `sequence`. s_flag: one int of LDS.
 __device__ __forceinline__ void edge_update_after_step(const EdgeUpdate& e, const ReduceStage& stage, int sequence, int block, int blocks,
                                                        int* __restrict__ s_flag) {
     if (threadIdx.x == 0) {
@@ -226,33 +256,8 @@ __device__ __forceinline__ void edge_update_after_step(const EdgeUpdate& e, cons
         *s_flag = (int)(seen & 1u);
     }
     __syncthreads();
-    if (*s_flag == 0) {  // else the iteration converged (or the wait gave up): no direction is needed
-        const double beta = published(stage.beta);
-        const size_t pairs_a = e.count_a >> 1, pairs = (e.count_a + e.count_b) >> 1, shift = (e.second - e.count_a) >> 1;
-        for (size_t i = (size_t)block * kReduceBlock + threadIdx.x; i < pairs; i += (size_t)blocks * kReduceBlock) {
-            const size_t at = 2 * (i < pairs_a ? i : i + shift);
-            const double p0 = e.fma_form ? fma(beta, e.p_in[at], e.r[at]) : fma(1.0, e.r[at], beta * e.p_in[at]);  // cg_kernels.hip, direction()
-            const double p1 = e.fma_form ? fma(beta, e.p_in[at + 1], e.r[at + 1]) : fma(1.0, e.r[at + 1], beta * e.p_in[at + 1]);
-            // agent-scope stores: written through to the memory side, so that the launch that sends these rows may be released by
-            // edges_ready instead of by this launch's end (no L2 write-back of everything else the XCD holds)
-            __hip_atomic_store(reinterpret_cast<unsigned long long*>(e.p_out + at), (unsigned long long)__double_as_longlong(p0), __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(reinterpret_cast<unsigned long long*>(e.p_out + at + 1), (unsigned long long)__double_as_longlong(p1), __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this lane's stores have been acknowledged
-    }
-    // edges_ready <- sequence by the workgroup that finishes last, converged or not: the side stream's wait in front of the halo
-    // exchange (cg_kernels.hip, edges_wait_kernel) is released either way. The ticket is the reductions' (no reduction is in
-    // flight on this stream while the step's launch runs) and returns to zero.
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned drawn = __hip_atomic_fetch_add(stage.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (drawn == (unsigned)(blocks - 1)) {
-            __hip_atomic_store(stage.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(stage.edges_ready, (unsigned)sequence, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
+    const bool skip = *s_flag != 0;  // the iteration converged (or the wait gave up): no direction is needed
+    edge_rows_write_and_announce(e, skip ? 0.0 : published(stage.beta), skip, stage, sequence, block, blocks);
 }
 
 // Called by ALL threads of a workgroup once everything it contributes has been published (by any of its threads, each
