@@ -730,8 +730,9 @@ def run_leg_children(c, kind, role, extra_env, timeout_s):
 def supervise_headline(c, kind, timeout_s):
     """The headline leg of a multi-rank run, in child processes. Returns (leg or None, reason or None, extras).
     If a rank of the first attempt ended through the library's watchdog -- the overlapped pipeline drives two RCCL communicators
-    from two streams, the one construction of this solver no run between devices has exercised yet -- the
-    ranks are started ONCE more, as fresh processes on a fresh rendezvous, with SPMV_AMD_NO_OVERLAP=1 (halo exchange on the
+    from two streams, the one construction of this solver no run between devices has exercised yet -- or the
+    attempt finished with WRONG NUMBERS (ranks disagreeing on the residual history, or a history off the committed golden:
+    the overlapped pipeline hands rows between streams by device flags, proven on one device only), the ranks are started ONCE more, as fresh processes on a fresh rendezvous, with SPMV_AMD_NO_OVERLAP=1 (halo exchange on the
     compute stream: the reference's own, non-overlapped shape, cg_solver_mgpu_partitioned.cu:173-231). A line measured that way
     says so: "degraded": "no-overlap after <the watchdog's sentence>", with the first attempt's outcome per rank beside it."""
     first = run_leg_children(c, kind, "headline", {}, timeout_s)
@@ -740,10 +741,14 @@ def supervise_headline(c, kind, timeout_s):
         return (first["rec"] or {}).get("leg"), None, {}
     reasons = "; ".join(f"rank {o['rank']}: {o['error']}" for o in outcomes if o["rc"] != 0)
     sentences = [o["watchdog"] for o in outcomes if o["watchdog"]]
+    wrong = [o["error"] for o in outcomes if o["error"] and ("residual histories" in o["error"] or "residual history" in o["error"])]
+    if c.multi and not sentences and wrong:
+        sentences = [wrong[0]]  # (every rank raises the same sentence: the histories are gathered before they are compared)
     if not sentences or os.environ.get("SPMV_AMD_NO_OVERLAP") == "1":
         return None, reasons, {}
     if c.rank == 0:
-        print(f"bench.py: the overlapped leg ended through the watchdog ({sentences[0]}); starting fresh ranks once with SPMV_AMD_NO_OVERLAP=1", file=sys.stderr)
+        print(f"bench.py: the overlapped leg {'produced wrong numbers' if wrong and sentences[0] == wrong[0] else 'ended through the watchdog'} "
+              f"({sentences[0]}); starting fresh ranks once with SPMV_AMD_NO_OVERLAP=1", file=sys.stderr)
     second = run_leg_children(c, kind, "headline", {"SPMV_AMD_NO_OVERLAP": "1"}, timeout_s)
     outcomes2 = gather(c, {"rank": c.rank, "rc": second["rc"], "watchdog": second["watchdog"], "error": (second["rec"] or {}).get("error")})
     extras = {"degraded": f"no-overlap after {sentences[0]}", "first_leg_failure": {"per_rank": outcomes}}

@@ -191,7 +191,7 @@ struct SpmvAmdCgSlab {
     bool pingpong = true;
     bool roctx_always = false;  // SPMV_AMD_ROCTX=1: roctx ranges even without detailed timers
     bool no_overlap = false;  // SPMV_AMD_NO_OVERLAP=1: halo exchange on the compute stream (the reference's shape; bench.py's fallback)
-    bool test_wedge_overlapped_exchange = false;  // SPMV_AMD_TEST_WEDGE_OVERLAPPED_EXCHANGE=1, see exchange_halo
+    int test_wedge_overlapped_exchange = 0;  // SPMV_AMD_TEST_WEDGE_OVERLAPPED_EXCHANGE=1 / 2, see exchange_halo
     bool early_halo = true;   // set_option("early_halo", 0): halo exchange only after the whole direction update (round 2's order)
     // Late bulk (round 4): the direction update of iteration k is enqueued before the host knows whether k converged, and on
     // the converging iteration that launch only reads a flag -- 3.1 M one-wave workgroups at 4e8 rows, 0.65 ms of pure
@@ -337,7 +337,7 @@ void make_common(SpmvAmdCgSlab* s) {
     }
     s->shape = current_launch_shape();
     if (const char* v = getenv("SPMV_AMD_NO_OVERLAP")) s->no_overlap = v[0] == '1';
-    if (const char* v = getenv("SPMV_AMD_TEST_WEDGE_OVERLAPPED_EXCHANGE")) s->test_wedge_overlapped_exchange = v[0] == '1';
+    if (const char* v = getenv("SPMV_AMD_TEST_WEDGE_OVERLAPPED_EXCHANGE")) s->test_wedge_overlapped_exchange = atoi(v);
     if (const char* v = getenv("SPMV_AMD_ROCTX")) s->roctx_always = v[0] == '1';
     s->late_bulk = nl >= 100000000;
     s->partials_blas = device_alloc<double>(dot_scratch_doubles(nl));
@@ -654,7 +654,14 @@ void exchange_halo(SpmvAmdCgSlab* s, double* v, hipStream_t stream) {
     // SPMV_AMD_TEST_WEDGE_OVERLAPPED_EXCHANGE=1 (test hook): an exchange issued on the SIDE stream never returns -- the host
     // thread stays in here, as it would behind an RCCL call that blocks -- so that the watchdog ends the process and a
     // supervisor can be shown to restart the ranks without the overlap (tests/test_distributed.py). Nothing is wedged on the GPU.
-    while (s->test_wedge_overlapped_exchange && stream == s->side && s->side != nullptr) std::this_thread::sleep_for(std::chrono::milliseconds(200));
+    // = 2: the exchange returns, but a pipeline that overlaps delivers WRONG NUMBERS (the right-hand side is nudged once): what a
+    // hand-over between the streams that loses rows between two devices would look like to the supervisor.
+    while (s->test_wedge_overlapped_exchange == 1 && stream == s->side && s->side != nullptr) std::this_thread::sleep_for(std::chrono::milliseconds(200));
+    if (s->test_wedge_overlapped_exchange == 2 && stream == s->side && s->side != nullptr) {
+        static const double nudged = 1.001;
+        HIP_CHECK(hipMemcpyAsync(s->b, &nudged, sizeof nudged, hipMemcpyHostToDevice, stream));
+        s->test_wedge_overlapped_exchange = 0;
+    }
     s->comm->halo_exchange(s->has_prev ? v : nullptr, s->has_next ? v + (s->n_local - s->halo) : nullptr,
                            s->has_prev ? v - s->halo : nullptr, s->has_next ? v + s->n_local : nullptr, s->halo, stream);
 }

@@ -287,6 +287,30 @@ def test_bench_restarts_fresh_ranks_without_overlap_after_a_watchdog_exit(tmp_pa
 
 
 @pytest.mark.gpu
+def test_bench_restarts_fresh_ranks_without_overlap_after_wrong_numbers(tmp_path):
+    """Round 5: the overlapped pipeline hands rows between its streams by device flags (halo arrival, edge rows ready), proven on
+    one device only. If its ranks FINISH but with a residual history off the committed golden (or ranks disagreeing), the
+    supervisors start fresh ranks once with SPMV_AMD_NO_OVERLAP=1 as after a watchdog exit. Here the overlapped pipeline is made
+    to deliver wrong numbers by a test hook (SPMV_AMD_TEST_WEDGE_OVERLAPPED_EXCHANGE=2: b[0] nudged by the first side-stream
+    exchange): one line, measured, parity-checked, marked degraded with the parity sentence."""
+    log = tmp_path / "procs.jsonl"
+    env = dict(os.environ, SPMV_AMD_BENCH_PROCESS_LOG=str(log), SPMV_AMD_TEST_WEDGE_OVERLAPPED_EXCHANGE="2", **FORCED_MULTI_ENV)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--grid", "2000",
+                          "--no-cpu-baseline", "--no-spmv"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = _json_lines(out.stdout)
+    assert len(lines) == 1
+    line = lines[0]
+    check_multi_rank_line(line, 1)
+    assert line["degraded"].startswith("no-overlap after residual history of the timed solves differs from the committed golden"), line["degraded"]
+    first = line["first_leg_failure"]["per_rank"]
+    assert len(first) == 1 and first[0]["rc"] != 0 and first[0]["watchdog"] is None and "golden" in first[0]["error"]
+    assert line["parity_vs_golden"]["ok"] and line["breakdown"]["per_rank"][0]["halo_exchange_on_side_stream_us"] == 0
+    assert [p["role"] for p in read_process_log(log)] == ["rank", "leg-child", "leg-child"]
+    assert "produced wrong numbers" in out.stderr and "starting fresh ranks once with SPMV_AMD_NO_OVERLAP=1" in out.stderr
+
+
+@pytest.mark.gpu
 def test_bench_multi_rank_line_carries_both_allreduce_legs_when_asked():
     """--allreduce-ab: the headline line first, alone; then the mailbox leg in a child process and the line again with
     allreduce_ab added."""
