@@ -649,7 +649,7 @@ class CgSlab:
         return np.array(out[:min(count, 1024)], dtype=np.float64)
 
     def set_option(self, name, value):
-        """Loop option of this slab ("late_bulk", "lead_rows", "early_halo", "pingpong", "r_pingpong"): A/B runs on the same allocations."""
+        """Loop option of this slab (include/spmv_amd/api.h, spmv_amd_cg_slab_set_option, lists them): A/B runs on the same allocations."""
         if lib().spmv_amd_cg_slab_set_option(self.h, name.encode(), int(value)) != 0:
             raise ValueError(f"unknown slab option {name!r}")
 

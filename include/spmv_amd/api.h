@@ -213,14 +213,12 @@ int spmv_amd_operator_placement(const char* mode, int* candidates, double* gain)
 
 /* Which kernel variant the last init selected: a static string, one of
  * "stencil5/row-lds" (default on verified stencils with grid >= 512), "stencil5/row-direct"
- * (default on smaller verified stencils), "stencil5/column-march",
- * "stencil5/wave-tile", "stencil5/row-generic", "stencil5/row-generic(csr-loop)";
- * "csr/row-scalar", "csr/subwave4|8|16|32", "csr/wavefront"; "ell/slot-major",
- * "ell/stencil5-direct". */
+ * (default on smaller verified stencils), "stencil5/row-generic", "stencil5/row-generic(csr-loop)";
+ * "csr/stream", "csr/adaptive", "csr/row-scalar", "csr/wavefront"; "ell/slot-major", "ell/stencil5-direct". */
 const char* spmv_amd_operator_variant(const char* mode);
 
-/* Forces a kernel variant of `mode` ("row-lds", "row-direct", "column-march", "wave-tile", "row-generic" /
- * "row-scalar", "subwave4".."subwave32", "wavefront"; NULL or "auto" = automatic). A variant
+/* Forces a kernel variant of `mode` ("row-lds", "row-direct", "row-generic" / "stream", "adaptive", "row-scalar",
+ * "wavefront"; NULL or "auto" = automatic). A variant
  * whose preconditions the matrix does not meet falls back to the next applicable one. */
 int spmv_amd_operator_select_variant(const char* mode, const char* variant);
 
