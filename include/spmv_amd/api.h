@@ -343,6 +343,8 @@ int spmv_amd_cg_slab_time_spmv(SpmvAmdCgSlab* s, int reps, float* ms_each);
  * solve -- averages per counted iteration, microseconds -- in the order of the comma-separated names
  * spmv_amd_cg_slab_timeline_names() returns; 0 values if the last solve ran without the timeline. Each stage runs from
  * the end of the previous stage's last kernel to the end of its own, so queue gaps are inside the stage that waits.
+ * Every event record is a barrier packet on the stream (~6 us on MI355X): a solve with the timeline on is ~40 us per iteration
+ * slower than a plain one and its small stages consist mostly of that packet (profiles/r05_slab_timeline_p8.txt).
  * The direction-update stage is averaged over the launches that did work ("direction_updates": the converging
  * iteration's update is never needed -- the reference tests convergence before its p update, :652-676). */
 void spmv_amd_cg_slab_set_timeline(SpmvAmdCgSlab* s, int on);
