@@ -319,6 +319,7 @@ __global__ __launch_bounds__(kStream) void cg_update_px_kernel(size_t n, const C
 __global__ void cg_scalars_init_kernel(CgScalars* s, double* history) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     s->rr_old = s->rr_new;
+    s->rr_ring[0] = s->rr_new;
     s->b_norm = sqrt(s->rr_new);
     s->residual = s->b_norm;
     s->converged = 0;
@@ -334,25 +335,68 @@ __global__ void cg_scalars_step_kernel(CgScalars* s, double tol, double* history
     cg_scalars_step(s, tol, history, host_record, sequence, alpha_ring, ring_slots);
 }
 
-// The scalar step as a launch of its own (behind an ncclAllReduce) that ALSO updates the direction on the rows the neighbours
-// wait for: workgroup 0's first thread takes the step and hands beta on, every workgroup then takes a share (reduce_device.hpp,
-// EdgeUpdate). One launch instead of two on the RCCL path.
-__global__ __launch_bounds__(kBlock) void cg_step_and_edges_kernel(StepArgs step, ReduceStage stage, EdgeUpdate edges) {
-    __shared__ int s_flag;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        cg_scalars_step(step.scalars, step.tol, step.history, step.host_record, step.sequence, step.alpha_ring, step.ring_slots);
-        publish_step(stage, step.scalars, step.sequence);
+// Step k (optional), the edge rows (optional) and a range of the direction update in one launch; see kernels.hpp, DirectionLaunch.
+// Workgroup 0's first thread takes the step; NOBODY waits for it: beta_k and the verdict come from scalars the step does not
+// write. A reader that sees `converged` set -- before this launch, or by this launch's step -- skips, as its own verdict would.
+struct DirectionArgs {
+    StepArgs step;  // step.host_record == nullptr: no step here (step.scalars, step.tol are always set)
+    int iteration;
+    const double* r;
+    const double* p_in;
+    double* p_out;
+    size_t bulk_lo, bulk_pairs;
+    unsigned edge_blocks;
+    int reverse, fma_form;
+};
+__global__ __launch_bounds__(kStream) void cg_direction_kernel(DirectionArgs a, EdgeRows e, ReduceStage stage) {
+    CgScalars* s = a.step.scalars;
+    // (scalars first, vectors second, as in cg_update_p_ring_kernel: the launch of a converging iteration reads no vector)
+    const bool edge_block = blockIdx.x < a.edge_blocks;
+    const size_t pairs_a = e.count_a >> 1, edge_pairs = (e.count_a + e.count_b) >> 1, shift = (e.second - e.count_a) >> 1;
+    size_t at = 0;
+    bool live_lane = false;
+    if (edge_block) {
+        const size_t i = (size_t)blockIdx.x * kStream + threadIdx.x;
+        live_lane = i < edge_pairs;
+        at = i < pairs_a ? i : i + shift;
+    } else {
+        const unsigned bulk_blocks = gridDim.x - a.edge_blocks, logical = blockIdx.x - a.edge_blocks;
+        const size_t i = (size_t)(a.reverse ? bulk_blocks - 1 - logical : logical) * kStream + threadIdx.x;
+        live_lane = i < a.bulk_pairs;
+        at = (a.bulk_lo >> 1) + i;
     }
-    edge_update_after_step(edges, stage, step.sequence, (int)blockIdx.x, (int)gridDim.x, &s_flag);
-}
-
-// The edge rows' direction update as a launch of its own (behind a launch that held the scalar step: the peer-mailbox path, a single
-// rank with neighbours, the ring's wrap iterations), announcing them like the step's launch does -- the exchange behind it is
-// then released by edges_ready as well. The launch of a converged iteration writes nothing and still announces.
-__global__ __launch_bounds__(kBlock) void cg_edges_kernel(const CgScalars* __restrict__ s, int iteration, ReduceStage stage, EdgeUpdate edges,
-                                                          int sequence) {
-    const bool skip = s->iterations != iteration || s->converged != 0;
-    edge_rows_write_and_announce(edges, skip ? 0.0 : s->beta, skip, stage, sequence, (int)blockIdx.x, (int)gridDim.x);
+    const int was_converged = s->converged;
+    const double rr_new = s->rr_new, rr_prev = s->rr_ring[(a.iteration - 1) & 1], b_norm = s->b_norm;
+    const int stop_at = s->stop_at;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && a.step.host_record != nullptr)
+        cg_scalars_step(s, a.step.tol, a.step.history, a.step.host_record, a.step.sequence, a.step.alpha_ring, a.step.ring_slots);
+    const bool live = was_converged == 0 && !cg_converging(rr_new, b_norm, a.step.tol, stop_at, a.iteration);
+    if (live && live_lane) {
+        const double beta = rr_new / rr_prev;
+        const d2 rv = load_once(a.r, at);
+        d2 pv = load_once(a.p_in, at);
+        pv.x = direction(rv.x, beta, pv.x, a.fma_form);
+        pv.y = direction(rv.y, beta, pv.y, a.fma_form);
+        if (edge_block) {
+            // written through (agent-scope stores): the exchange is released by edges_ready, not by this launch's end
+            __hip_atomic_store(reinterpret_cast<unsigned long long*>(a.p_out + 2 * at), (unsigned long long)__double_as_longlong(pv.x),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(reinterpret_cast<unsigned long long*>(a.p_out + 2 * at + 1), (unsigned long long)__double_as_longlong(pv.y),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            reinterpret_cast<d2*>(a.p_out)[at] = pv;  // plain: the next SpMV's neighbour loads re-use these lines
+        }
+    }
+    if (edge_block) {  // one wave per workgroup: no barrier needed between the stores' acknowledgement and the ticket
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (threadIdx.x == 0) {
+            const unsigned drawn = __hip_atomic_fetch_add(stage.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (drawn == a.edge_blocks - 1) {
+                __hip_atomic_store(stage.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(stage.edges_ready, (unsigned)a.step.sequence, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
 }
 
 // Side stream, in front of the halo exchange: waits until the step's launch `sequence` has raised edges_ready (bounded; a wait
@@ -576,25 +620,17 @@ void launch_reduce_partials_and_step(const double* partials, int count, double* 
                 StepArgs{s, tol, history, host_record, sequence, alpha_ring, ring_slots});
 }
 
-bool launch_cg_scalars_step_and_edges(CgScalars* s, double tol, double* history, int* host_record, int sequence, hipStream_t stream,
-                                      double* alpha_ring, int ring_slots, const ReduceScratch& scratch, const EdgeRows& e) {
-    if (scratch.base == nullptr || e.count_a + e.count_b == 0) return false;
-    const size_t pairs = (e.count_a + e.count_b) >> 1;
-    const unsigned blocks = (unsigned)((pairs + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL(cg_step_and_edges_kernel, dim3(blocks < 1 ? 1 : (blocks > 256 ? 256 : blocks)), dim3(kBlock), 0, stream,
-                       StepArgs{s, tol, history, host_record, sequence, alpha_ring, ring_slots}, reduce_stage_of(scratch.base),
-                       EdgeUpdate{e.r, e.p_in, e.p_out, e.count_a, e.second, e.count_b, e.fma_form ? 1 : 0, e.timeout_ticks, e.late});
-    return true;
-}
-
-bool launch_cg_edges(const CgScalars* s, int iteration, int sequence, hipStream_t stream, const ReduceScratch& scratch, const EdgeRows& e) {
-    if (scratch.base == nullptr || e.count_a + e.count_b == 0) return false;
-    const size_t pairs = (e.count_a + e.count_b) >> 1;
-    const unsigned blocks = (unsigned)((pairs + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL(cg_edges_kernel, dim3(blocks < 1 ? 1 : (blocks > 256 ? 256 : blocks)), dim3(kBlock), 0, stream, s, iteration,
-                       reduce_stage_of(scratch.base),
-                       EdgeUpdate{e.r, e.p_in, e.p_out, e.count_a, e.second, e.count_b, e.fma_form ? 1 : 0, e.timeout_ticks, e.late}, sequence);
-    return true;
+void launch_cg_direction(const DirectionLaunch& d, const EdgeRows* edge_rows, const ReduceScratch& scratch, hipStream_t stream) {
+    const bool edges = edge_rows != nullptr && scratch.base != nullptr && edge_rows->count_a + edge_rows->count_b > 0;
+    const EdgeRows e = edges ? *edge_rows : EdgeRows{0, 0, 0};
+    const unsigned edge_blocks = (unsigned)((((e.count_a + e.count_b) >> 1) + kStream - 1) / kStream);
+    const size_t bulk_pairs = d.bulk_rows >> 1;
+    const unsigned bulk_blocks = (unsigned)((bulk_pairs + kStream - 1) / kStream);
+    const unsigned blocks = edge_blocks + bulk_blocks;
+    hipLaunchKernelGGL(cg_direction_kernel, dim3(blocks < 1 ? 1 : blocks), dim3(kStream), 0, stream,
+                       DirectionArgs{StepArgs{d.s, d.tol, d.history, d.step_host_record, d.sequence, d.alpha_ring, d.ring_slots}, d.iteration, d.r,
+                                     d.p_in, d.p_out, d.bulk_lo, bulk_pairs, edge_blocks, d.reverse ? 1 : 0, d.fma_form ? 1 : 0},
+                       e, scratch.base != nullptr ? reduce_stage_of(scratch.base) : ReduceStage{});
 }
 
 void launch_edges_wait(const ReduceScratch& scratch, int sequence, long long timeout_ticks, int* late, hipStream_t stream) {
@@ -602,7 +638,7 @@ void launch_edges_wait(const ReduceScratch& scratch, int sequence, long long tim
                        late);
 }
 
-int reduce_scratch_doubles() { return kReduceStageBlocks + kReduceExtraMax + 4; }  // sums | extras | ticket | beta | step_ready | edges_ready
+int reduce_scratch_doubles() { return kReduceStageBlocks + kReduceExtraMax + 2; }  // sums | extras | ticket | edges_ready
 
 double* reduce_scratch_alloc() {
     // uncached device memory where the runtime offers it: the slice sums and the ticket are handed between workgroups on

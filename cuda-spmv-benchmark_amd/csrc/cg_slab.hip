@@ -37,7 +37,14 @@
 //    removed in round 5: profiles/r04_class_pool_*.txt, history up to commit 258dcef.);
 //  * (round 4) the direction update of an iteration is enqueued as a lead piece + -- once the status record says the loop goes
 //    on -- the rest (late bulk, slabs of >= 1e8 rows): the converging iteration no longer dispatches 3 M workgroups that only
-//    read a flag.
+//    read a flag;
+//  * (round 5) no event and no cross-stream wait inside an iteration: an event record is a barrier packet (~6 us), a small
+//    launch 7-10 us. Every dot product is ONE launch (the workgroup that finishes last sums the slice sums); a slab's boundary
+//    rows ride in the launch that sums p.Ap and wait for the halo's device-side arrival flag themselves; the direction update
+//    is ONE launch whose first workgroups write the rows the neighbours need through to memory and raise the flag the side
+//    stream's exchange waits for -- on the RCCL path it also takes the scalar step, and nobody waits for it (every workgroup
+//    derives beta and the verdict from scalars the step does not write). Five launches per iteration on a slab with neighbours
+//    (+ two ncclAllReduce); every option combination gives the same bits (tests/test_cg_gpu.py).
 //
 // The same loop also serves the reference's SINGLE-GPU entry point, cg_solve_device (cg_solver.cu:436-706): a slab that
 // borrows the caller's SpmvOperator instead of owning a CSR (cg_solve_on_operator, near the end of this file), and it can
@@ -140,8 +147,10 @@ struct SpmvAmdCgSlab {
     unsigned* d_halo_flag = nullptr;
     unsigned halo_sequence = 0;
     bool halo_flag = true;
-    bool edges_flag = true;     // set_option("edges_flag", 0): a cross-stream event between the step's launch and the exchange instead of the device flag
-    bool edges_in_step = true;  // set_option("edges_in_step", 0): RCCL path, the early direction update of the edge rows as a launch of its own (rounds 3-4)
+    bool edges_flag = true;     // set_option("edges_flag", 0): same as edges_in_step = 0 (the fused launch needs the flag: its end is too late for the exchange)
+    // set_option("edges_in_step", 0): the early direction update of the edge rows as a launch of its own, the scalar step of the
+    // RCCL path too, the exchange released by an event (rounds 3-4); 1: one launch for step, edge rows and the first piece of the rest
+    bool edges_in_step = true;
     // Measurement hook, set_option("stop_at", k): iteration k counts as the converging one whatever its residual (kernels.hpp,
     // CgScalars::stop_at). A stand-in slab's periodic system never converges; with max_iters alone it would run one direction
     // update + halo exchange more than the rank of a real job, whose 14th iteration converges. Timing only.
@@ -1006,18 +1015,15 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
         const size_t tail_rows = nl - tail_start;
         const bool early_halo = multi && !detail && !s->no_overlap && s->early_halo && (nl % 2) == 0 && nl >= 4 * (size_t)s->halo + 4 * kAlign &&
                                 head_rows < tail_start;
-        // Round 5, RCCL path: that early update rides in the scalar step's launch (which follows the ncclAllReduce), behind the
-        // step: one launch fewer per iteration (kernels.hpp, EdgeRows). Ring mode, and not in the iteration whose new direction
-        // re-uses a slot the pending x flush still has to read.
+        // Round 5: the rows the neighbours need, the first piece of the rest and -- on the RCCL path, where the scalar step is not
+        // part of the r.r sum's launch -- the step itself share ONE launch (kernels.hpp, DirectionLaunch): its first workgroups
+        // take the edge rows, write them through and raise the flag the side stream's exchange waits for; nobody waits for the
+        // step. Ring mode. The step stays a launch of its own in the iteration whose new direction re-uses a slot the pending
+        // x flush still has to read (the flush needs that step's alpha and must run before the slot is overwritten).
         const int next_iteration = enqueued + 1;
-        const bool edges_in_step = separate && early_halo && s->edges_in_step && slots > 1 && next_iteration - window_start < slots;
-        bool edges_done = false;
-        EdgeRows edge_rows{};
-        if (early_halo && slots > 1) {
-            const double limit_s = watchdog_limit_seconds() > 0.0 && watchdog_limit_seconds() < 40.0 ? 0.5 * watchdog_limit_seconds() : 20.0;
-            edge_rows = EdgeRows{r_cur, s->p, s->ring[(size_t)(next_iteration % slots)], head_rows, tail_start, tail_rows, s->device_form,
-                                 (long long)(limit_s * 1e8), &s->h_poll->halo_late};
-        }
+        const bool direction_fused = early_halo && s->edges_in_step && s->edges_flag && slots > 1 && s->scratch().base != nullptr;
+        bool step_in_direction = direction_fused && separate && next_iteration - window_start < slots;
+        const EdgeRows edge_rows{head_rows, tail_start, tail_rows};
         ++s->poll_sequence;
         trace.push("Dot_Product");
         if (separate) {
@@ -1030,10 +1036,7 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
                 TraceScope r(trace, "AllReduce");
                 timed(&stats->time_allreduce_ms, nullptr, [&] { allreduce_scalar(s, &s->d_s->rr_new, "all-reduce of r.r"); });
             }
-            if (edges_in_step)
-                edges_done = launch_cg_scalars_step_and_edges(s->d_s, config->tolerance, s->d_hist, &s->h_poll->sequence, s->poll_sequence, s->compute,
-                                                              s->d_alpha_ring, slots, s->scratch(), edge_rows);
-            if (!edges_done)
+            if (!step_in_direction)  // else: inside the direction update's first launch, further down
                 launch_cg_scalars_step(s->d_s, config->tolerance, s->d_hist, &s->h_poll->sequence, s->poll_sequence,
                                        s->compute, s->d_alpha_ring, slots);
         } else {
@@ -1108,20 +1111,33 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
             }
             double* p_next = s->ring[(size_t)(enqueued % slots)];
             const double* p_in = s->p;
+            bool first_piece = direction_fused;
             auto ring_update = [&](size_t off, size_t count, bool reverse) {
-                if (count > 0)
+                if (first_piece) {
+                    // the edge rows first (they raise the flag the exchange waits for), then this piece; the step too where it is due
+                    first_piece = false;
+                    launch_cg_direction(DirectionLaunch{s->d_s, config->tolerance, enqueued, s->d_hist, step_in_direction ? &s->h_poll->sequence : nullptr,
+                                                        s->poll_sequence, s->d_alpha_ring, slots, r_cur, p_in, p_next, off, count, reverse, s->device_form},
+                                        &edge_rows, s->scratch(), s->compute);
+                    step_in_direction = false;
+                    s->p = p_next;
+                    edges_by_flag = true;
+                    trace.pop();
+                    {
+                        TraceScope r(trace, "Halo_Exchange");
+                        start_p_halo();
+                    }
+                    edges_by_flag = false;
+                    trace.push("BLAS_AXPBY");
+                } else if (count > 0) {
                     launch_cg_update_p_ring(count, s->d_s, r_cur + off, p_in + off, p_next + off, enqueued, s->compute, reverse, s->device_form);
+                }
             };
             timed(&stats->time_blas1_ms, &stats->time_axpby_update_p_ms, [&] {
-                if (early_halo) {
-                    // (edge_rows was filled in before a window flush could move the ring on: this iteration's output slot)
-                    edge_rows.p_out = p_next;
-                    if (!edges_done && s->edges_flag)  // a launch of their own that announces them by flag, like the step's launch does
-                        edges_done = launch_cg_edges(s->d_s, enqueued, s->poll_sequence, s->compute, s->scratch(), edge_rows);
-                    edges_by_flag = edges_done && s->edges_flag;
-                    if (edges_done)
-                        ;  // those rows were updated behind the scalar step (inside its launch, or by launch_cg_edges)
-                    else if (head_rows > 0 && tail_rows > 0)  // a rank with two neighbours: both grid rows in one launch
+                if (direction_fused) {
+                    bulk(ring_update, head_rows, tail_start);  // its first piece carries the edge rows (and the step) and starts the exchange
+                } else if (early_halo) {
+                    if (head_rows > 0 && tail_rows > 0)  // a rank with two neighbours: both grid rows in one launch
                         launch_cg_update_p_ring_two_ranges(head_rows, tail_start, tail_rows, s->d_s, r_cur, p_in, p_next, enqueued, s->compute, s->device_form);
                     else
                         ring_update(0, head_rows, false), ring_update(tail_start, tail_rows, false);
@@ -1131,7 +1147,6 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
                         TraceScope r(trace, "Halo_Exchange");
                         start_p_halo();
                     }
-                    edges_by_flag = false;
                     trace.push("BLAS_AXPBY");
                     bulk(ring_update, head_rows, tail_start);
                 } else {
@@ -1153,9 +1168,8 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
             // worded like the host watchdog's report: bench.py's supervisors read that sentence and restart the ranks once without the overlap
             fprintf(stderr, "\n[spmv_amd watchdog] rank %d: no progress for %.1f s in stage '%s' (CG iteration %d)\n", comm->rank,
                     watchdog_limit_seconds() > 0.0 && watchdog_limit_seconds() < 40.0 ? 0.5 * watchdog_limit_seconds() : 20.0,
-                    gave_up == 3   ? "edge rows' ready flag (side-stream wait in front of the halo exchange)"
-                    : gave_up == 2 ? "scalar step's hand-over (in-kernel wait of the edge rows' direction update)"
-                                   : "halo arrival flag (in-kernel wait of the boundary rows)",
+                    gave_up == 3 ? "edge rows' ready flag (side-stream wait in front of the halo exchange)"
+                                 : "halo arrival flag (in-kernel wait of the boundary rows)",
                     enqueued - 1);
             report_slab_state(s, stderr);
             exit(EXIT_FAILURE);

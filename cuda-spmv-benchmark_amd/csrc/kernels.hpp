@@ -148,6 +148,10 @@ struct CgScalars {
     int max_history;
     int stop_at;  // measurement hook (set_option "stop_at"): the scalar step of this iteration declares convergence whatever the
                   // residual, so that a stand-in slab (whose periodic system never converges) does a converging solve's work: 0 = off
+    // r.r after step k in slot k & 1 (slot 0: the initial r.r): a launch that holds step k AND work that needs beta_k reads
+    // beta_k = rr_new / rr_ring[(k - 1) & 1] in every workgroup without waiting for the step -- the step writes the OTHER slot
+    // (and rr_old, which only later launches read)
+    double rr_ring[2];
 };
 
 void launch_fill(double* d, size_t n, double value, hipStream_t stream);
@@ -249,17 +253,10 @@ void launch_reduce_partials(const double* partials, int count, double* d_out,
                             const int* d_skip_flag, hipStream_t stream, const ReduceScratch& scratch = ReduceScratch{},
                             int* host_progress = nullptr, int progress_value = 0,
                             const PeerMailbox* mailbox = nullptr, const double* extra = nullptr, int extra_count = 0);
-// The direction update of the rows a slab's neighbours wait for -- p_out = r + beta p_in on rows [0, count_a) and
-// [second, second + count_b), all even -- to be run BEHIND the scalar step inside the step's launch on the RCCL path
-// (reduce_device.hpp, EdgeUpdate): one launch fewer per iteration than launch_cg_update_p_ring_two_ranges.
+// The rows a slab's neighbours wait for: [0, count_a) and [second, second + count_b), all even (its first / last grid row,
+// rounded outwards to 4 KiB).
 struct EdgeRows {
-    const double* r;
-    const double* p_in;
-    double* p_out;
     size_t count_a, second, count_b;
-    bool fma_form;
-    long long timeout_ticks;  // bound of the in-launch wait for the step (100 MHz wall clock)
-    int* late;                // host-coherent int, set to 2 by a workgroup that gave up
 };
 // The same reduction followed by launch_cg_scalars_step() in the same launch
 // (only valid when no all-reduce has to happen between the sum and the step).
@@ -268,13 +265,29 @@ void launch_reduce_partials_and_step(const double* partials, int count, double* 
                                      int* host_record, int sequence, double* alpha_ring = nullptr, int ring_slots = 0,
                                      const PeerMailbox* mailbox = nullptr, int* host_progress = nullptr,
                                      int progress_value = 0);
-// launch_cg_scalars_step() + the EdgeRows update in one launch (the RCCL path, where the step follows an ncclAllReduce).
-// Returns false, having launched nothing, without a scratch.
-bool launch_cg_scalars_step_and_edges(CgScalars* s, double tol, double* history, int* host_record, int sequence, hipStream_t stream,
-                                      double* alpha_ring, int ring_slots, const ReduceScratch& scratch, const EdgeRows& edge_rows);
-// The same update as a launch of its own behind a launch that already took the step (iteration: as launch_cg_update_p_ring's),
-// announcing the rows through the scratch like the step's launch does. Returns false, having launched nothing, without a scratch.
-bool launch_cg_edges(const CgScalars* s, int iteration, int sequence, hipStream_t stream, const ReduceScratch& scratch, const EdgeRows& edge_rows);
+// The scalar step (optional: step_host_record == nullptr means an earlier launch took it), the direction update p_out = r + beta p_in
+// of the EdgeRows (optional) and of rows [bulk_lo, bulk_lo + bulk_rows) in ONE launch (round 5): no workgroup waits for the
+// step -- each derives beta and the convergence verdict from the scalars the step does not touch (CgScalars::rr_ring) with
+// the step's own expressions. The first workgroups take the edge rows, write them through and raise the scratch's edges_ready
+// to `sequence` (the side stream's exchange is released by that flag, launch_edges_wait), the rest streams the bulk.
+// iteration: as launch_cg_update_p_ring's. All row counts even. One launch instead of three on the RCCL path (step | edge rows |
+// rest), instead of two elsewhere; no event between them.
+struct DirectionLaunch {
+    CgScalars* s;
+    double tol;
+    int iteration;
+    double* history;       // the step's (may be null)
+    int* step_host_record; // null: no step in this launch
+    int sequence;
+    double* alpha_ring;
+    int ring_slots;
+    const double* r;
+    const double* p_in;
+    double* p_out;
+    size_t bulk_lo, bulk_rows;
+    bool reverse, fma_form;
+};
+void launch_cg_direction(const DirectionLaunch& d, const EdgeRows* edge_rows, const ReduceScratch& scratch, hipStream_t stream);
 // Side stream: one thread waits (bounded) until the step-and-edges launch `sequence` on the compute stream has written its edge
 // rows through to memory; the halo exchange enqueued behind it then needs no cross-stream event. *late = 3 if it gave up.
 void launch_edges_wait(const ReduceScratch& scratch, int sequence, long long timeout_ticks, int* late, hipStream_t stream);

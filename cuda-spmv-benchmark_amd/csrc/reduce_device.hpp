@@ -35,6 +35,12 @@ constexpr int kReduceStageBlocks = 256;
 // The CG scalar step after the (all-reduced) r.r is known: stopping test (strict <, on ||r|| / ||r0||), iteration count
 // including the converging iteration, beta, rr_old <- rr_new (reference cg_solver_mgpu_partitioned.cu:652-676,716), and the
 // status record for the host.
+// The stopping test of step k on the all-reduced r.r (one expression for the step and for every workgroup that derives the
+// verdict by itself, cg_direction_kernel): strict <, on ||r|| / ||r0||.
+__device__ __forceinline__ bool cg_converging(double rr_new, double b_norm, double tol, int stop_at, int k) {
+    return sqrt(rr_new) / b_norm < tol || (stop_at > 0 && k == stop_at);
+}
+
 __device__ __forceinline__ void cg_scalars_step(CgScalars* s, double tol, double* history, int* host_record,
                                                 int sequence, double* alpha_ring, int ring_slots) {
     if (!s->converged) {
@@ -42,9 +48,10 @@ __device__ __forceinline__ void cg_scalars_step(CgScalars* s, double tol, double
         const double res = sqrt(s->rr_new);
         s->residual = res;
         s->iterations += 1;
+        s->rr_ring[s->iterations & 1] = s->rr_new;
         if (alpha_ring != nullptr) alpha_ring[(s->iterations - 1) % ring_slots] = s->alpha;
         if (history != nullptr && s->iterations < s->max_history) history[s->iterations] = res;
-        if (res / s->b_norm < tol || (s->stop_at > 0 && s->iterations == s->stop_at)) {
+        if (cg_converging(s->rr_new, s->b_norm, tol, s->stop_at, s->iterations)) {
             s->converged = 1;
         } else {
             s->beta = s->rr_new / s->rr_old;
@@ -71,25 +78,6 @@ struct StepArgs {
     int ring_slots;
 };
 
-// The direction update of the rows a slab's neighbours wait for (its first / last grid row, rounded outwards to 4 KiB), run
-// BEHIND the scalar step inside the step's own launch on the RCCL path (round 5, cg_step_and_edges_kernel): p_out = r + beta p_in
-// on rows [0, count_a) and [second, second + count_b). Every workgroup of the launch takes a share once the step's workgroup
-// has published beta and the convergence verdict through the scratch (agent-scope stores / loads, the hand-over below) -- a
-// wait among workgroups of ONE launch, all of them resident (<= 256 of 256 threads), bounded by timeout_ticks of the 100 MHz
-// wall clock. One launch fewer per iteration than the separate update of rounds 3-4: -0.2 % per solve on the 20 000^2 P = 8
-// slab, -0.6 % on the 10 000^2 one (profiles/r05_ab_edges_in_step.txt). Inside the one-launch r.r reduction (no all-reduce
-// call between sum and step: single rank, mailbox) the same merge measured +0.0 / +0.1 % -- the hand-over costs what the
-// launch saved -- and is not built.
-struct EdgeUpdate {
-    const double* r = nullptr;
-    const double* p_in = nullptr;
-    double* p_out = nullptr;
-    size_t count_a = 0, second = 0, count_b = 0;  // all even
-    int fma_form = 0;
-    long long timeout_ticks = 0;
-    int* late = nullptr;  // host-coherent: set by a workgroup that gave up waiting
-};
-
 // What happens to the finished sum.
 //  * mailbox (may be null): the sum is completed ACROSS THE RANKS by the finishing workgroup's first wave (comm.hpp);
 //  * step.scalars (may be null): the CG scalar step runs on the finished sum in the same launch;
@@ -111,17 +99,14 @@ struct ReduceStage {
     unsigned long long* sums;   // kReduceStageBlocks doubles, as bits
     unsigned long long* extra;  // kReduceExtraMax doubles, as bits
     unsigned* ticket;
-    unsigned long long* beta;   // EdgeUpdate: beta of the step just taken, as bits
-    unsigned* step_ready;       // EdgeUpdate: 2 * sequence + converged, raised behind beta
-    unsigned* edges_ready;      // EdgeUpdate: sequence, raised once every workgroup's share of the edge rows has reached memory
+    unsigned* edges_ready;      // cg_direction_kernel: sequence, raised once every workgroup's share of the edge rows has reached memory
 };
 
-// scratch layout (kernels.hpp, ReduceScratch): [kReduceStageBlocks sums | kReduceExtraMax extras | ticket | beta | step_ready | edges_ready]
+// scratch layout (kernels.hpp, ReduceScratch): [kReduceStageBlocks sums | kReduceExtraMax extras | ticket | edges_ready]
 __host__ __device__ inline ReduceStage reduce_stage_of(double* base) {
     unsigned long long* b = reinterpret_cast<unsigned long long*>(base);
     unsigned long long* tail = b + kReduceStageBlocks + kReduceExtraMax;
-    return ReduceStage{b, b + kReduceStageBlocks, reinterpret_cast<unsigned*>(tail), tail + 1, reinterpret_cast<unsigned*>(tail + 2),
-                       reinterpret_cast<unsigned*>(tail + 3)};
+    return ReduceStage{b, b + kReduceStageBlocks, reinterpret_cast<unsigned*>(tail), reinterpret_cast<unsigned*>(tail + 1)};
 }
 // Slice workgroups of a reduction over `count` partials: one up to 1024 partials, else ceil(count / slice) with
 // slice = ceil(count / kReduceStageBlocks).
@@ -200,64 +185,6 @@ __device__ __forceinline__ void publish(unsigned long long* slot, double value) 
 }
 __device__ __forceinline__ double published(const unsigned long long* slot) {
     return __longlong_as_double((long long)__hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-}
-
-// The step's workgroup (thread 0, right behind cg_scalars_step) hands beta and the verdict to the other workgroups.
-__device__ __forceinline__ void publish_step(const ReduceStage& stage, const CgScalars* s, int sequence) {
-    publish(stage.beta, s->beta);
-    __hip_atomic_store(stage.step_ready, 2u * (unsigned)sequence + (s->converged ? 1u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// Called by ALL threads of EVERY workgroup of a launch of `blocks` workgroups: this workgroup's share of the edge rows (unless
-// `skip`: the iteration converged), written THROUGH to the memory side with agent-scope stores -- so that the launch that
-// sends these rows may be released by edges_ready instead of by this launch's end, with no L2 write-back of everything else
-// the XCD holds -- then edges_ready <- sequence by the workgroup that finishes last, converged or not: the side stream's wait
-// in front of the halo exchange (cg_kernels.hip, edges_wait_kernel) is released either way. The ticket is the reductions'
-// (no reduction is in flight on this stream while such a launch runs) and returns to zero.
-__device__ __forceinline__ void edge_rows_write_and_announce(const EdgeUpdate& e, double beta, bool skip, const ReduceStage& stage, int sequence,
-                                                             int block, int blocks) {
-    if (!skip) {
-        const size_t pairs_a = e.count_a >> 1, pairs = (e.count_a + e.count_b) >> 1, shift = (e.second - e.count_a) >> 1;
-        for (size_t i = (size_t)block * kReduceBlock + threadIdx.x; i < pairs; i += (size_t)blocks * kReduceBlock) {
-            const size_t at = 2 * (i < pairs_a ? i : i + shift);
-            const double p0 = e.fma_form ? fma(beta, e.p_in[at], e.r[at]) : fma(1.0, e.r[at], beta * e.p_in[at]);  // cg_kernels.hip, direction()
-            const double p1 = e.fma_form ? fma(beta, e.p_in[at + 1], e.r[at + 1]) : fma(1.0, e.r[at + 1], beta * e.p_in[at + 1]);
-            __hip_atomic_store(reinterpret_cast<unsigned long long*>(e.p_out + at), (unsigned long long)__double_as_longlong(p0), __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(reinterpret_cast<unsigned long long*>(e.p_out + at + 1), (unsigned long long)__double_as_longlong(p1), __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this lane's stores have been acknowledged
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned drawn = __hip_atomic_fetch_add(stage.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (drawn == (unsigned)(blocks - 1)) {
-            __hip_atomic_store(stage.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(stage.edges_ready, (unsigned)sequence, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-}
-
-// The same inside the step's own launch: every workgroup first waits (bounded) for publish_step of `sequence`. s_flag: one int of LDS.
-__device__ __forceinline__ void edge_update_after_step(const EdgeUpdate& e, const ReduceStage& stage, int sequence, int block, int blocks,
-                                                       int* __restrict__ s_flag) {
-    if (threadIdx.x == 0) {
-        const long long t0 = wall_clock64();
-        unsigned seen;
-        while (((seen = __hip_atomic_load(stage.step_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 1) != (unsigned)sequence) {
-            if (wall_clock64() - t0 > e.timeout_ticks) {
-                __hip_atomic_store(e.late, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                seen = 1u;  // treated as converged: nothing is written
-                break;
-            }
-            __builtin_amdgcn_s_sleep(2);
-        }
-        *s_flag = (int)(seen & 1u);
-    }
-    __syncthreads();
-    const bool skip = *s_flag != 0;  // the iteration converged (or the wait gave up): no direction is needed
-    edge_rows_write_and_announce(e, skip ? 0.0 : published(stage.beta), skip, stage, sequence, block, blocks);
 }
 
 // Called by ALL threads of a workgroup once everything it contributes has been published (by any of its threads, each

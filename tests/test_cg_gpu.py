@@ -396,7 +396,7 @@ def test_loop_options_leave_every_bit_alone(B, monkeypatch, n, P, r):
                      {"late_bulk": 1, "lead_rows": 50000, "reduce_one_launch": 1}, {"reduce_one_launch": 1, "no_overlap": 1},
                      {"reduce_one_launch": 0, "no_overlap": 1}, {"reduce_one_launch": 1, "halo_flag": 0}, {"reduce_one_launch": 1, "halo_flag": 1, "late_bulk": 1, "lead_rows": 512},
                      {"reduce_one_launch": 1, "edges_in_step": 0}, {"reduce_one_launch": 0, "edges_in_step": 0, "late_bulk": 1, "lead_rows": 512},
-                     {"reduce_one_launch": 1, "edges_flag": 0}):
+                     {"reduce_one_launch": 1, "edges_flag": 0}, {"reduce_one_launch": 1, "edges_in_step": 0, "late_bulk": 1, "lead_rows": 512}):
             for k in ("late_bulk", "reduce_one_launch", "no_overlap"):
                 slab.set_option(k, opts.get(k, 0))
             slab.set_option("halo_flag", opts.get("halo_flag", 1))
@@ -418,14 +418,16 @@ def test_loop_options_leave_every_bit_alone(B, monkeypatch, n, P, r):
 
 @pytest.mark.parametrize("collectives", ["1", "0"])
 @pytest.mark.parametrize("n,P,r", [(4096, 2, 0), (4096, 2, 1), (6000, 4, 1)])
-def test_edge_rows_updated_inside_the_step_launch(B, monkeypatch, collectives, n, P, r):
-    """Round 5, RCCL path: the direction update of the rows the neighbours wait for runs inside the scalar step's launch, behind
-    the step (kernels.hpp, EdgeRows), once the step's workgroup has handed beta on. Against the separate launch of rounds 3-4
-    (edges_in_step = 0), with the direction ring wrapping (ring 4: every fourth iteration falls back to the separate launch)
-    and not, on wide slabs with one and two neighbours: the residual history (every direction feeds the next residual)
-    bit-identical. The exchange behind it is released by the device flag the step's launch raises once its rows have reached
-    memory (edges_flag, default) or by a cross-stream event (edges_flag = 0). collectives = 0 (no all-reduce call between sum
-    and step: the shape of the mailbox path, where the merge is not built) checks that the options are inert there."""
+def test_direction_update_in_one_launch_with_the_step(B, monkeypatch, collectives, n, P, r):
+    """Round 5: on a slab with neighbours the rows they wait for, the first piece of the rest of the direction update and -- on
+    the RCCL path (collectives forced), where the scalar step follows an ncclAllReduce -- the step itself share ONE launch
+    (kernels.hpp, DirectionLaunch). Nobody in it waits for the step: every workgroup derives beta and the convergence verdict
+    from scalars the step does not write, with the step's own expressions. Its first workgroups write the edge rows through and
+    raise the flag that releases the halo exchange on the side stream. Against rounds 3-4's form (edges_in_step = 0: step |
+    edge rows | event | rest), with the direction ring wrapping (ring 4: every fourth iteration keeps the step a launch of its
+    own in front of the x flush) and not, with the late bulk's lead piece as the first piece, on wide slabs with one and two
+    neighbours: the residual history (every direction feeds the next residual) bit-identical. collectives = 0: no all-reduce
+    call between sum and step (the shape of the peer-mailbox path): the step stays in the sum's launch, the rest is fused."""
     monkeypatch.setenv("SPMV_AMD_SELF_NEIGHBOUR", "1")
     monkeypatch.setenv("SPMV_AMD_FORCE_COLLECTIVES", collectives)
     for ring in ("16", "4"):
@@ -436,12 +438,18 @@ def test_edge_rows_updated_inside_the_step_launch(B, monkeypatch, collectives, n
         slab.set_option("edges_in_step", 0)
         st0 = slab.solve(**kw)
         h0 = slab.history().copy()
-        for opts in ({}, {"late_bulk": 0}, {"halo_flag": 0}, {"reduce_one_launch": 0}, {"edges_flag": 0}, {"edges_flag": 0, "halo_flag": 0}):
+        for opts in ({}, {"late_bulk": 0}, {"halo_flag": 0}, {"reduce_one_launch": 0}, {"edges_flag": 0}, {"edges_flag": 0, "halo_flag": 0},
+                     {"late_bulk": 1, "lead_rows": 4096}, {"late_bulk": 1, "lead_rows": 512, "pingpong": 0}):
             slab.set_option("edges_in_step", 1)
-            for k in ("late_bulk", "halo_flag", "reduce_one_launch", "edges_flag"):
+            for k in ("late_bulk", "halo_flag", "reduce_one_launch", "edges_flag", "pingpong"):
                 slab.set_option(k, opts.get(k, 1))
+            slab.set_option("lead_rows", opts.get("lead_rows", 1 << 24))
             st = slab.solve(**kw)
             assert st.iterations == st0.iterations and np.array_equal(slab.history(), h0), (ring, opts)
+        # a converging solve: the launch of the converging iteration writes no direction, the loop ends on the step's record
+        slab.set_option("stop_at", 7)
+        st = slab.solve(max_iters=20, tol=0.0)
+        assert st.iterations == 7 and st.converged == 1 and np.array_equal(slab.history(), h0[:8])
         slab.destroy()
         comm.destroy()
 
