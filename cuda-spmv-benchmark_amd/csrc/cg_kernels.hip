@@ -399,9 +399,9 @@ __global__ __launch_bounds__(kStream) void cg_direction_kernel(DirectionArgs a, 
     }
 }
 
-// Side stream, in front of the halo exchange: waits until the step's launch `sequence` has raised edges_ready (bounded; a wait
-// that gives up sets *late = 3 and lets the exchange go). Stands where a cross-stream event stood: an event record between
-// the step's launch and the direction update it is followed by cost the compute stream a barrier packet per iteration.
+// Side stream, in front of the halo exchange: waits until the direction update's launch `sequence` has raised edges_ready
+// (bounded; a wait that gives up sets *late = 3 and lets the exchange go). Stands where a cross-stream event stood: an event
+// record cost the compute stream a barrier packet per iteration and could only follow a whole launch.
 __global__ void edges_wait_kernel(const unsigned* ready, unsigned sequence, long long timeout_ticks, int* late) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const long long t0 = wall_clock64();

@@ -906,9 +906,9 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
         printf("[%s] Initial residual: %e\n", s->label, now.b_norm);
     }
     bool halo_in_flight = false;
-    // edges_by_flag (RCCL path, round 5): the rows to send were written by the step's launch, which raises a device flag once
-    // they have reached memory; the side stream waits for that flag with a one-thread launch instead of for an event recorded
-    // between the step's launch and the direction update (a barrier packet on the compute stream per iteration).
+    // edges_by_flag (round 5): the rows to send were written by the first workgroups of the direction update's launch, which raise
+    // a device flag once the rows have reached memory; the side stream waits for that flag with a one-thread launch instead of
+    // for an event recorded on the compute stream (a barrier packet per iteration, and too late: the launch's end).
     bool edges_by_flag = false;
     auto start_p_halo = [&] {  // halo rows of the new p: side stream, under the interior SpMV
         if (!multi) return;
