@@ -343,6 +343,8 @@ int spmv_amd_cg_slab_time_spmv(SpmvAmdCgSlab* s, int reps, float* ms_each);
  * solve -- averages per counted iteration, microseconds -- in the order of the comma-separated names
  * spmv_amd_cg_slab_timeline_names() returns; 0 values if the last solve ran without the timeline. Each stage runs from
  * the end of the previous stage's last kernel to the end of its own, so queue gaps are inside the stage that waits.
+ * (Since round 5 the scalar step of the RCCL path runs inside the direction update's launch: the stage named
+ * "reduce_rr_allreduce_and_scalar_step" then holds the sum and the all-reduce only.)
  * Every event record is a barrier packet on the stream (~6 us on MI355X): a solve with the timeline on is ~40 us per iteration
  * slower than a plain one and its small stages consist mostly of that packet (profiles/r05_slab_timeline_p8.txt).
  * The direction-update stage is averaged over the launches that did work ("direction_updates": the converging
