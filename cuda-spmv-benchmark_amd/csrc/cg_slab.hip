@@ -147,7 +147,6 @@ struct SpmvAmdCgSlab {
     unsigned* d_halo_flag = nullptr;
     unsigned halo_sequence = 0;
     bool halo_flag = true;
-    bool edges_flag = true;     // set_option("edges_flag", 0): same as edges_in_step = 0 (the fused launch needs the flag: its end is too late for the exchange)
     // set_option("edges_in_step", 0): the early direction update of the edge rows as a launch of its own, the scalar step of the
     // RCCL path too, the exchange released by an event (rounds 3-4); 1: one launch for step, edge rows and the first piece of the rest
     bool edges_in_step = true;
@@ -1021,7 +1020,7 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
         // step. Ring mode. The step stays a launch of its own in the iteration whose new direction re-uses a slot the pending
         // x flush still has to read (the flush needs that step's alpha and must run before the slot is overwritten).
         const int next_iteration = enqueued + 1;
-        const bool direction_fused = early_halo && s->edges_in_step && s->edges_flag && slots > 1 && s->scratch().base != nullptr;
+        const bool direction_fused = early_halo && s->edges_in_step && slots > 1 && s->scratch().base != nullptr;
         bool step_in_direction = direction_fused && separate && next_iteration - window_start < slots;
         const EdgeRows edge_rows{head_rows, tail_start, tail_rows};
         ++s->poll_sequence;
@@ -1375,7 +1374,6 @@ extern "C" int spmv_amd_cg_slab_set_option(SpmvAmdCgSlab* s, const char* name, l
     else if (strcmp(name, "no_overlap") == 0) s->no_overlap = value != 0;
     else if (strcmp(name, "halo_flag") == 0) s->halo_flag = value != 0;
     else if (strcmp(name, "edges_in_step") == 0) s->edges_in_step = value != 0;
-    else if (strcmp(name, "edges_flag") == 0) s->edges_flag = value != 0;
     else if (strcmp(name, "stop_at") == 0) s->stop_at = value > 0 ? (int)value : 0;
     else if (strcmp(name, "spmv_event_stride") == 0) s->spmv_event_stride = (int)value;
     else return -1;

@@ -369,7 +369,6 @@ int spmv_amd_cg_slab_spmv_launch_ms(const SpmvAmdCgSlab* s, float* out, int cap)
  * "halo_flag" 0/1 (0 = a cross-stream event wait in front of the boundary rows instead of their own wait for the arrival flag),
  * "edges_in_step" 0/1 (slabs with neighbours; 1 = the rows they wait for, the first piece of the rest of the direction update and, on the
  * RCCL path, the scalar step in ONE launch whose device flag releases the halo exchange; 0 = rounds 3-4's step | edge rows | event | rest),
- * "edges_flag" 0/1 (0 = the same as "edges_in_step" 0: an event cannot release the exchange before that launch ends),
  * "spmv_event_stride" N (time every N-th in-loop SpMV launch -- default 7, phase advancing with every solve --, 0 = none). The one option that is NOT result-neutral, a timing
  * aid for stand-in slabs: "stop_at" K (iteration K counts as the converging one whatever its residual; 0 = off).
  * 0, or -1 = unknown name. */

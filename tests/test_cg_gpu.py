@@ -396,12 +396,11 @@ def test_loop_options_leave_every_bit_alone(B, monkeypatch, n, P, r):
                      {"late_bulk": 1, "lead_rows": 50000, "reduce_one_launch": 1}, {"reduce_one_launch": 1, "no_overlap": 1},
                      {"reduce_one_launch": 0, "no_overlap": 1}, {"reduce_one_launch": 1, "halo_flag": 0}, {"reduce_one_launch": 1, "halo_flag": 1, "late_bulk": 1, "lead_rows": 512},
                      {"reduce_one_launch": 1, "edges_in_step": 0}, {"reduce_one_launch": 0, "edges_in_step": 0, "late_bulk": 1, "lead_rows": 512},
-                     {"reduce_one_launch": 1, "edges_flag": 0}, {"reduce_one_launch": 1, "edges_in_step": 0, "late_bulk": 1, "lead_rows": 512}):
+                     {"reduce_one_launch": 1, "edges_in_step": 0, "late_bulk": 1, "lead_rows": 512}):
             for k in ("late_bulk", "reduce_one_launch", "no_overlap"):
                 slab.set_option(k, opts.get(k, 0))
             slab.set_option("halo_flag", opts.get("halo_flag", 1))
             slab.set_option("edges_in_step", opts.get("edges_in_step", 1))
-            slab.set_option("edges_flag", opts.get("edges_flag", 1))
             slab.set_option("lead_rows", opts.get("lead_rows", 1 << 24))
             st = slab.solve(**kw)
             assert (st.iterations, st.converged) == (st0.iterations, st0.converged) and np.array_equal(slab.history(), h0), (ring, opts)
@@ -438,10 +437,10 @@ def test_direction_update_in_one_launch_with_the_step(B, monkeypatch, collective
         slab.set_option("edges_in_step", 0)
         st0 = slab.solve(**kw)
         h0 = slab.history().copy()
-        for opts in ({}, {"late_bulk": 0}, {"halo_flag": 0}, {"reduce_one_launch": 0}, {"edges_flag": 0}, {"edges_flag": 0, "halo_flag": 0},
+        for opts in ({}, {"late_bulk": 0}, {"halo_flag": 0}, {"reduce_one_launch": 0}, {"halo_flag": 0, "reduce_one_launch": 0},
                      {"late_bulk": 1, "lead_rows": 4096}, {"late_bulk": 1, "lead_rows": 512, "pingpong": 0}):
             slab.set_option("edges_in_step", 1)
-            for k in ("late_bulk", "halo_flag", "reduce_one_launch", "edges_flag", "pingpong"):
+            for k in ("late_bulk", "halo_flag", "reduce_one_launch", "pingpong"):
                 slab.set_option(k, opts.get(k, 1))
             slab.set_option("lead_rows", opts.get("lead_rows", 1 << 24))
             st = slab.solve(**kw)

@@ -4,7 +4,7 @@ with spmv_amd_cg_slab_set_option -- so that placement (worth up to +-1.3 % betwe
 profiles/r03_placement.txt) cannot enter. Solves run to the tolerance (14 iterations on the 20000 grid), alternating A B B A.
 
    python tools/ab_loop_options.py <option> [grid=20000] [as_world=1 as_rank=0] [rounds=8] [collectives=1]
-   options: late_bulk, early_halo, pingpong, reduce_one_launch, no_overlap, halo_flag, edges_in_step, edges_flag
+   options: late_bulk, early_halo, pingpong, reduce_one_launch, no_overlap, halo_flag, edges_in_step
 A slab of a larger job (as_world > 1) is a stand-in slab on a self-neighbour RCCL rank (see tools/ab_early_halo_rigorous.py)."""
 import os
 import sys
