@@ -870,6 +870,9 @@ def build_line(args, base, leg, spmv, extras, world, n, rows, nnz):
                            {"reference_formula": spmv["effective_gbs"], "published_formula": spmv["effective_gbs_published_formula"], "median_ms": spmv["median_ms"]},
                            "grid": n, "unknowns": rows, "nnz": nnz, "partition": f"{world} row slab(s)", "transport": transport,
                            "iterations_per_solve": iterations, "converged": leg["converged"], "final_residual": leg["final_residual"],
+                           # the solver's own clock (HIP events around the reference's timed region, median over the timed steps, rank 0):
+                           # `value` is the wall clock around the K steps, which also holds the host's work between two solves
+                           "solver_clock_ms_per_solve": leg.get("event_ms_per_solve"),
                            "residual_history": leg["history"]},
                    transport=transport, allreduce=allreduce, ranks_agree_on_history=leg["ranks_agree_on_history"], parity_vs_golden=leg["parity_vs_golden"],
                    rccl_ranks=leg["rccl_ranks"], devices=devices, rank_ms_per_step=leg["rank_ms"], breakdown=breakdown_summary(leg["breakdown"]),
