@@ -40,10 +40,17 @@ configuration of reference docs/PROBLEM_SIZE_SCALING_RESULTS.md:40-47, on N row 
             the reference's :405-413 -> :728-731), median of 5 solves, for the slab and for the full problem alike.
             The latency of an all-reduce BETWEEN devices cannot be measured on one GPU: the efficiency is given for a
             range of latencies.
-  cpu_baseline  (N = 1, rank 0) the serial C oracle (oracle/spmv_oracle.c, 1 core) on a bounded sample
-            (10 000 x 10 000 = 1/4 of the rows): its CG, scaled by rows to the 400 M-unknown problem
-            (~10 s), and `spmv` = its STENCIL5 and CSR SpMV (1 warm-up + 3 runs, median) in the reference's
+  cpu_baseline  (N = 1, rank 0) the serial C oracle (oracle/spmv_oracle.c, 1 core): its CG on the FULL 400 M-unknown
+            problem when the host's MemAvailable allows (~45 GB, ~33 s on one EPYC core; `history_vs_committed_golden_ok` then
+            re-verifies the golden history on the spot), else on a 10 000 x 10 000 sample scaled by rows (`sample` says which);
+            `spmv` = its STENCIL5 and CSR SpMV on the same matrix (1 warm-up + 3 runs, median) in the reference's
             effective-GB/s formula and in algorithmic GB/s; `all_cores` = the same loops under OpenMP.
+  compare   (N = 1; after the spmv leg) BASELINE configs 2 and 5 through get_operator with the reference's 5 + 10 / median rule,
+            each operator checksum-gated (sum y = n^2 + 4n, ||y||^2 exact): 10 000^2 stencil5-csr / cusparse-csr, 15 000^2 ellpack /
+            stencil5-ellpack / stencil5-csr / cusparse-csr. FLAT scalars in `roofline` (the driver's record keeps scalars of
+            roofline / config only): stencil10k_ms, csr10k_ms, stencil15k_ms, csr15k_ms, ell15k_ms, ell_stencil15k_ms, each
+            with its *_frac (algorithmic bytes of the format / median / 8 TB/s), beside spmv20k_median_ms,
+            spmv20k_effective_gbs, spmv20k_effective_gbs_published_formula, spmv20k_frac (BASELINE's first metric).
 
   placement (rank 0's slab) and spmv.output_placement: on this part a SpMV is ~4.5 % faster when the vector it writes lies in another
             class of 32 GiB address regions than the data it reads, and only hipMalloc decides the class (profiles/r04_spmv_regions.txt):
@@ -67,8 +74,9 @@ configuration of reference docs/PROBLEM_SIZE_SCALING_RESULTS.md:40-47, on N row 
 
 Wall time, worst case of every DEFAULT path (the driver's limit for this file is 600 s):
   N = 1   torch import + library (<= 120 s on a fresh box) + SpMV leg (~5 s) + (W + K + 1) solves of ~0.11 s + stream ceiling
-          (~0.2 s) + scaling probe (8 role processes one after the other under one child, the child ended after
-          --probe-timeout = 240 s; ~60 s when healthy) + CPU baseline (~25 s of host work, no GPU) : < 420 s, ~110 s when healthy.
+          (~0.2 s) + compare leg (six operator set-ups, ~15 s) + scaling probe (8 role processes one after the other under one
+          child, the child ended after --probe-timeout = 240 s; ~30 s when healthy) + CPU baseline (full size: ~70 s of host
+          work, no GPU; sample: ~25 s) : < 480 s, ~150 s when healthy.
   N > 1   the same import + rendezvous (gloo, 120 s limit for the store) + (W + K + 1) solves + nothing else: rank 0 prints
           the line as soon as the ranks have agreed on the measured leg. Every wait on a peer inside a solve ends after
           SPMV_AMD_WATCHDOG_S = 60 s with a report; gloo collectives give up after 180 s; a self-launched run is ended by
@@ -155,13 +163,14 @@ def spmv_headline(B, n, warmup=5, runs=10):
     ms = op.time_device(None, None, runs)
     median_ms, dropped = reference_stats(ms)
     placement = op.placement()
-    y_sum = None
-    if rows <= 50_000_000:
-        dx, dy = B.DeviceVector(rows, fill=1.0), B.DeviceVector(rows, fill=0.0)
-        op.run_device(dx, dy)
-        y = dy.to_host()
-        y_sum = float(y.sum())
-        dx.free(), dy.free()
+    # checksum gate on caller-owned vectors (the harness prints Sum(y), main.cu:176-183): x = 1 on the generator's stencil gives
+    # y[i] in {1, 2, 3}, sum(y) = n^2 + 4n exactly; 3.2 GB of y come back to the host at 20 000^2
+    dx, dy = B.DeviceVector(rows, fill=1.0), B.DeviceVector(rows, fill=-7.0)
+    op.run_device(dx, dy)
+    y = dy.to_host()
+    y_sum = float(y.sum())
+    del y
+    dx.free(), dy.free()
     variant = op.variant()
     op.free()
     secs = median_ms / 1e3
@@ -175,6 +184,65 @@ def spmv_headline(B, n, warmup=5, runs=10):
         "vectors": "the operator's own x (= 1) and y, the ones run_timed's kernel works on",
         "output_placement": None if placement is None else {"candidates_timed": placement[0], "first_candidate_over_kept": placement[1]},
     }
+
+
+COMPARE_CASES = ((10000, ("stencil5-csr", "cusparse-csr")),  # BASELINE config 2: STENCIL5 against the CSR kernel
+                 (15000, ("ellpack", "stencil5-ellpack", "stencil5-csr", "cusparse-csr")))  # config 5: ELLPACK against STENCIL5 and CSR
+COMPARE_KEYS = {"stencil5-csr": "stencil", "cusparse-csr": "csr", "ellpack": "ell", "stencil5-ellpack": "ell_stencil"}
+
+
+def algorithmic_bytes(mode, rows, nnz, width=5):
+    """Algorithmic bytes of one SpMV per format: what the kernel must move, padded ELLPACK slots included."""
+    return {"stencil5-csr": 8 * nnz + 16 * rows, "cusparse-csr": 12 * nnz + 4 * (rows + 1) + 16 * rows,
+            "ellpack": rows * width * 12 + 16 * rows, "stencil5-ellpack": rows * width * 8 + 16 * rows}[mode]
+
+
+def compare_leg(B, cases=COMPARE_CASES, warmup=5, runs=10):
+    """BASELINE configs 2 and 5 in brief, on the library the CG leg just ran on: every operator through get_operator, the
+    reference's rule (src/main/main.cu:136-187: x = 1, 5 warm-ups, 10 timed launches, > 2 sigma dropped, median) on the operator's
+    own staging vectors, and a checksum gate on caller-owned vectors: with the generator's stencil (centre 5, neighbours -1) and
+    x = 1 every y[i] is 1, 2 or 3, so sum(y) = n^2 + 4n and ||y||^2 = (n-2)^2 + 16(n-2) + 36 exactly. An operator
+    whose checksum is off gets no time. Returns (flat scalars for the roofline object, per-operator records)."""
+    flat, records, all_ok = {}, [], True
+    for n, modes in cases:
+        rows, nnz = n * n, 5 * n * n - 4 * n
+        want_sum, want_sq = float(n * n + 4 * n), float((n - 2) * (n - 2) + 16 * (n - 2) + 36)
+        dx, dy = B.DeviceVector(rows, fill=1.0), B.DeviceVector(rows, fill=0.0)
+        try:
+            for mode in modes:
+                key = f"{COMPARE_KEYS[mode]}{n // 1000}k"
+                rec = {"operator": mode, "grid": n}
+                try:
+                    op = B.Operator(mode)
+                    if op.init_synthetic(n) != 0:
+                        raise RuntimeError("synthetic init failed")
+                    try:
+                        B.lib().spmv_amd_device_fill_f64(dy.ptr, rows, -7.0)  # a launch that writes nothing cannot pass
+                        if op.run_device(dx, dy) != 0:
+                            raise RuntimeError("run_device failed")
+                        y = dy.to_host()
+                        rec["sum_y"], rec["sumsq_y"] = float(y.sum()), float(np.dot(y, y))
+                        del y
+                        rec["checksum_ok"] = rec["sum_y"] == want_sum and rec["sumsq_y"] == want_sq
+                        if rec["checksum_ok"]:
+                            op.time_device(None, None, warmup)
+                            ms = op.time_device(None, None, runs)
+                            med, dropped = reference_stats(ms)
+                            alg = algorithmic_bytes(mode, rows, nnz)
+                            rec.update(variant=op.variant(), median_ms=med, outliers_removed=dropped, algorithmic_bytes=alg,
+                                       algorithmic_gbs=alg / med / 1e6, frac=alg / med / 1e6 / HBM_PEAK_GBS,
+                                       effective_gbs=spmv_byte_formulas(rows, nnz)[0] / med / 1e6, gflops=2.0 * nnz / med / 1e6)
+                            flat[key + "_ms"], flat[key + "_frac"] = med, rec["frac"]
+                    finally:
+                        op.free()
+                except Exception as e:  # evidence only: the CG line stands
+                    rec["error"] = repr(e)
+                all_ok = all_ok and bool(rec.get("checksum_ok"))
+                records.append(rec)
+        finally:
+            dx.free(), dy.free()
+    flat["compare_checksums_ok"] = all_ok
+    return flat, records
 
 
 def stream_ceiling(B, rows=200_000_000, reps=20, mix="stencil5"):
@@ -228,34 +296,67 @@ def cpu_spmv_baseline(O, rp, ci, va, n, threads):
     return rec
 
 
-def cpu_baseline(sample_grid, full_rows):
-    """Oracle CG (serial C, 1 core) on a sample grid; cost is linear in rows, so iterations/s at the
-    full size = iterations/s on the sample * sample_rows / full_rows. Plus the oracle's SpMV on the same sample."""
+def mem_available_bytes():
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"):
+                return int(line.split()[1]) * 1024
+    except OSError:
+        pass
+    return 0
+
+
+def cpu_baseline(sample_grid, full_grid):
+    """Oracle CG (serial C, 1 core). On the FULL workload when the host has the memory (CSR 12 B per non-zero + row pointers +
+    six vectors: ~45 GB at 20 000^2, ~33 s on one EPYC core; asked for 1.6x that as MemAvailable) -- the history of that run is
+    then compared with the committed golden history on the spot; else on a sample grid, cost being linear in rows: iterations/s
+    at the full size = iterations/s on the sample * sample_rows / full_rows. Plus the oracle's SpMV on the same matrix.
+    --cpu-sample-grid N forces a sample."""
     from oracle import oracle as O
 
-    rp, ci, va = O.stencil5_csr(sample_grid)
-    rows = sample_grid * sample_grid
+    full_rows = full_grid * full_grid
+    need = 12 * (5 * full_rows - 4 * full_grid) + 4 * (full_rows + 1) + 6 * 8 * full_rows
+    have = mem_available_bytes()
+    at_full_size = sample_grid is None and have >= 1.6 * need
+    grid = full_grid if at_full_size else (sample_grid or min(10000, full_grid))
+    rp, ci, va = O.stencil5_csr(grid)
+    rows = grid * grid
     t0 = time.perf_counter()
-    x, hist, res = O.cg(rp, ci, va, sample_grid, np.ones(rows), np.zeros(rows), device_form=True)
+    x, hist, res = O.cg(rp, ci, va, grid, np.ones(rows), np.zeros(rows), device_form=True)
     dt = time.perf_counter() - t0
+    del x
     cpu = cpu_model()
+    what = (f"the full {grid}x{grid} workload, nothing scaled" if grid == full_grid else
+            f"the {grid}x{grid} stencil ({rows} rows = 1/{full_rows // rows} of the workload; host MemAvailable {have / 2**30:.0f} GiB, "
+            f"{1.6 * need / 2**30:.0f} GiB wanted for the full size)" if sample_grid is None else
+            f"the {grid}x{grid} stencil ({rows} rows = 1/{full_rows // rows} of the workload, --cpu-sample-grid)")
     rec = {
-        "value": res.iterations / dt * rows / full_rows, "unit": "CG iterations/s (scaled to 400M unknowns)", "cores": 1, "kind": "port",
-        "sample": f"oracle_cg on the {sample_grid}x{sample_grid} stencil ({rows} rows = 1/{full_rows // rows} of the workload), "
-                  f"{res.iterations} iterations in {dt:.2f} s on 1 core of {os.cpu_count()} ({cpu})",
+        "value": res.iterations / dt * rows / full_rows, "unit": "CG iterations/s" + ("" if grid == full_grid else f" (scaled by rows to {full_rows} unknowns)"),
+        "cores": 1, "kind": "port", "sample": f"oracle_cg on {what}: {res.iterations} iterations in {dt:.2f} s on 1 core of {os.cpu_count()} ({cpu})",
+        "grid": grid, "full_size": grid == full_grid, "seconds": dt, "iterations": int(res.iterations),
     }
+    # the oracle run that was just timed IS the checker of the GPU histories: its history against the committed fixture
+    # (tests/golden/known_answers.json was written by the same oracle on another machine; bit-equal unless libm / compiler differ)
+    gold = parity_vs_golden(grid, hist, res.iterations)
+    if gold.get("available"):
+        rec["history_vs_committed_golden_max_rel_err"] = gold["max_rel_err"]
+        rec["history_vs_committed_golden_ok"] = gold["ok"]
     # the same loops spread over the cores this job may use (a one-GPU box's CPU share is 16), BASELINE.md section 3
     threads = max(1, min(16, os.cpu_count() or 1))
     try:
         t0 = time.perf_counter()
-        x2, hist2, res2 = O.cg_all_cores(rp, ci, va, sample_grid, np.ones(rows), np.zeros(rows), threads)
+        x2, hist2, res2 = O.cg_all_cores(rp, ci, va, grid, np.ones(rows), np.zeros(rows), threads)
         dt2 = time.perf_counter() - t0
+        del x2
         rec["all_cores"] = {"value": res2.iterations / dt2 * rows / full_rows, "cores": threads, "kind": "port (OpenMP over the oracle's loops)",
-                            "sample": f"same sample, {res2.iterations} iterations in {dt2:.2f} s on {threads} threads"}
+                            "sample": f"same matrix, {res2.iterations} iterations in {dt2:.2f} s on {threads} threads"}
+        rec["all_cores_value"], rec["all_cores_cores"] = rec["all_cores"]["value"], threads
     except Exception as e:  # optional figure
         rec["all_cores"] = {"error": repr(e)}
     try:
-        rec["spmv"] = cpu_spmv_baseline(O, rp, ci, va, sample_grid, threads)
+        rec["spmv"] = cpu_spmv_baseline(O, rp, ci, va, grid, threads)
+        rec["spmv_stencil5_ms"], rec["spmv_csr_ms"] = rec["spmv"]["stencil5"]["median_ms"], rec["spmv"]["csr"]["median_ms"]
+        rec["spmv_stencil5_effective_gbs"] = rec["spmv"]["stencil5"]["effective_gbs"]
     except Exception as e:
         rec["spmv"] = {"error": repr(e)}
     return rec
@@ -776,7 +877,7 @@ def other_allreduce_leg(c, kind, timeout_s):
     return rec
 
 
-def build_line(args, base, leg, spmv, extras, world, n, rows, nnz):
+def build_line(args, base, leg, spmv, extras, world, n, rows, nnz, compare=None):
     """The benchmark line from a finished leg (rank 0 only; touches neither the GPU nor another rank)."""
     # template argument: <kMode = 1 (SpMV + p.Ap partials)>
     kernel_symbol = {"stencil5/row-lds": "stencil5_rowlds_kernel<1>", "stencil5/row-direct": "stencil5_rowdirect_kernel<true>"}.get(leg["variant"], leg["variant"])
@@ -855,9 +956,23 @@ def build_line(args, base, leg, spmv, extras, world, n, rows, nnz):
         # (src/spmv/spmv_metrics.cu:85-101; the published 12 nnz + 16 rows)
         roofline["spmv_standalone"] = {k: spmv[k] for k in ("operator", "variant", "grid", "median_ms", "effective_gbs", "effective_gbs_published_formula",
                                                              "algorithmic_gbs", "gflops", "vs_a100_published")} | {"frac": spmv["frac_of_hbm_peak"]}
+        # ... and as FLAT scalars: the driver's record keeps the scalars of `roofline` and `config` and drops nested objects
+        # (BENCH_r05.json.parsed lost spmv_standalone and config.spmv_effective_gbs). spmv20k_* at the headline grid.
+        tag = f"spmv{n // 1000}k" if n % 1000 == 0 else f"spmv{n}"
+        roofline[tag + "_median_ms"] = spmv["median_ms"]
+        roofline[tag + "_effective_gbs"] = spmv["effective_gbs"]
+        roofline[tag + "_effective_gbs_published_formula"] = spmv["effective_gbs_published_formula"]
+        roofline[tag + "_frac"] = spmv["frac_of_hbm_peak"]
+        roofline[tag + "_vs_a100_published"] = spmv["vs_a100_published"]
+        if spmv.get("sum_y") is not None:
+            roofline[tag + "_checksum_ok"] = spmv["sum_y"] == float(n * n + 4 * n)
         if spmv.get("output_placement") is not None:
             roofline.setdefault("placement", {})["spmv_output_vector"] = spmv["output_placement"]
 
+    if compare is not None:
+        # BASELINE configs 2 and 5 (10 000^2 STENCIL5 vs CSR; 15 000^2 ELLPACK vs STENCIL5 vs CSR), flat for the same reason:
+        # <operator><grid>k_ms = median kernel ms by the reference's rule, <...>_frac = algorithmic bytes / that / 8 TB/s
+        roofline.update(compare[0])
     devices = leg.get("devices")
     if True:
         value = args.steps * iterations / dt
@@ -866,8 +981,10 @@ def build_line(args, base, leg, spmv, extras, world, n, rows, nnz):
                    vs_baseline=value / A100_CG_ITERS_PER_S[world] if headline else None,
                    baseline_note="reference's published CG iters/s on the same problem at the same GPU count, A100-SXM4-80GB (BASELINE.md); no MI355X number is published",
                    config={"workload": f"CG on the {n}x{n} 5-point stencil ({rows} unknowns, {nnz} nnz), b=1, x0=0, tol 1e-6",
-                           "spmv_effective_gbs": None if spmv is None or "effective_gbs" not in spmv else
-                           {"reference_formula": spmv["effective_gbs"], "published_formula": spmv["effective_gbs_published_formula"], "median_ms": spmv["median_ms"]},
+                           # BASELINE's first metric as scalars (reference formula spmv_metrics.cu:85-101 / the published 12 nnz + 16 rows)
+                           "spmv_effective_gbs": None if spmv is None or "effective_gbs" not in spmv else spmv["effective_gbs"],
+                           "spmv_effective_gbs_published_formula": None if spmv is None or "effective_gbs" not in spmv else spmv["effective_gbs_published_formula"],
+                           "spmv_median_ms": None if spmv is None or "median_ms" not in spmv else spmv["median_ms"],
                            "grid": n, "unknowns": rows, "nnz": nnz, "partition": f"{world} row slab(s)", "transport": transport,
                            "iterations_per_solve": iterations, "converged": leg["converged"], "final_residual": leg["final_residual"],
                            # the solver's own clock (HIP events around the reference's timed region, median over the timed steps, rank 0):
@@ -887,6 +1004,8 @@ def build_line(args, base, leg, spmv, extras, world, n, rows, nnz):
             out["first_leg_failure"] = extras["first_leg_failure"]
         if spmv is not None:
             out["spmv"] = spmv
+        if compare is not None:
+            out["compare"] = compare[1]
 
     return out
 
@@ -897,9 +1016,12 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--grid", type=int, default=20000, help="n of the n x n stencil (default: the 400M-unknown headline)")
-    ap.add_argument("--cpu-sample-grid", type=int, default=10000, help="grid of the CPU-baseline sample (10000: ~10 s on one core)")
+    ap.add_argument("--cpu-sample-grid", type=int, default=None,
+                    help="grid of a CPU-baseline SAMPLE, scaled by rows (default: the full workload when the host's MemAvailable allows -- ~33 s on one "
+                         "core at 20000 -- else 10000)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-spmv", action="store_true", help="skip the N=1 SpMV headline leg")
+    ap.add_argument("--no-compare", action="store_true", help="skip the N=1 leg of BASELINE configs 2 and 5 (10k STENCIL5 vs CSR, 15k ELLPACK vs STENCIL5 vs CSR)")
     ap.add_argument("--no-scaling-probe", action="store_true", help="skip the N=1 one-GPU strong-scaling probe")
     ap.add_argument("--no-ceiling", action="store_true", help="skip the in-run stream-ceiling probe")
     ap.add_argument("--allreduce-ab", action="store_true",
@@ -1024,7 +1146,14 @@ def main():
         except Exception as e:  # the CG measurement above stands whatever happens to this leg
             spmv = {"error": repr(e)}
 
-    out = build_line(args, base, leg, spmv, extras, world, n, rows, nnz) if rank == 0 else None
+    compare = None
+    if world == 1 and not multi and not args.no_compare:
+        try:
+            compare = compare_leg(B)
+        except Exception as e:  # evidence only
+            compare = ({"compare_error": repr(e)[:200]}, [])
+
+    out = build_line(args, base, leg, spmv, extras, world, n, rows, nnz, compare) if rank == 0 else None
     iterations = leg["iterations"] if rank == 0 else None
 
     if multi:
@@ -1054,7 +1183,7 @@ def main():
             dict(os.environ), args.probe_timeout, "scaling probe")
     if rank == 0 and not args.no_cpu_baseline:
         try:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_sample_grid, rows)
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample_grid, n)
         except Exception as e:  # the checker failing to build or load must not take the GPU measurement with it
             out["cpu_baseline"] = {"value": None, "error": repr(e)}
     if rank == 0:

@@ -438,6 +438,27 @@ def test_bench_default_multi_gpu_command_starts_exactly_n_rank_processes(tmp_pat
     assert sorted(p["rank"] for p in procs if p["role"] == "rank") == [0, 1] == sorted(p["rank"] for p in procs if p["role"] == "leg-child")
 
 
+def test_bench_default_eight_gpu_command_is_boring_without_gpus(tmp_path):
+    """`python bench.py --gpus 8` with every default -- the command the driver's scaling tier runs (the reference's launch line is
+    `mpirun -np 8 cg_solver_mgpu_stencil`, README.md:345) -- on a machine with no GPU in sight: exactly 1 launcher + 8 supervisors
+    + 8 leg children, ONE line that says nothing was measured and names all eight ranks, exit status 3, long before --launch-timeout."""
+    log = tmp_path / "procs.jsonl"
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="", SPMV_AMD_BENCH_PROCESS_LOG=str(log), OMP_NUM_THREADS="1")
+    env.pop("RANK", None), env.pop("WORLD_SIZE", None)
+    t0 = time.monotonic()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"], env=env, capture_output=True, text=True, timeout=600)
+    took = time.monotonic() - t0
+    lines = _json_lines(out.stdout)
+    assert out.returncode == 3, out.stdout + out.stderr
+    assert took < 300, f"{took:.0f} s: the default launch limit is 420 s"
+    assert len(lines) == 1 and lines[0]["value"] is None and lines[0]["n_gpus"] == 8 and lines[0]["scaling"] == "strong"
+    for rank in range(8):
+        assert f"rank {rank}: device {rank} wanted, 0 HIP device(s) visible" in lines[0]["unmeasured"]
+    procs = read_process_log(log)
+    assert sorted(p["role"] for p in procs) == ["launcher"] + ["leg-child"] * 8 + ["rank"] * 8
+    assert sorted(p["rank"] for p in procs if p["role"] == "rank") == list(range(8)) == sorted(p["rank"] for p in procs if p["role"] == "leg-child")
+
+
 def load_bench_module():
     import importlib.util
     spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))

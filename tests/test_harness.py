@@ -148,3 +148,49 @@ def test_bench_parity_gate_logic_on_the_cpu(golden):
                                  {"rank": 1, "rows": 10, "iterations": 14.0, "iteration_us": 950.0, "update_r_us": 185.0}])
     assert s["max_over_ranks"] == {"iteration_us": 950.0, "update_r_us": 190.0} and s["min_over_ranks"]["iteration_us"] == 900.0
     assert [r["rank"] for r in s["per_rank"]] == [0, 1]
+
+
+def test_bench_line_carries_every_baseline_number_as_a_flat_scalar():
+    """The driver's record keeps the SCALARS of `roofline` / `config` / `cpu_baseline` and drops nested objects (BENCH_r05.json lost
+    roofline.spmv_standalone and config.spmv_effective_gbs that way). BASELINE's first metric (20k STENCIL5 SpMV: median ms,
+    effective GB/s by both of the reference's formulas, frac) and the numbers of configs 2 and 5 must therefore be flat keys."""
+    import argparse
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_module_flat", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    n, rows, nnz = 20000, 20000 * 20000, 5 * 20000 * 20000 - 4 * 20000
+    # the byte counts SURVEY 8d states
+    assert bench.algorithmic_bytes("stencil5-csr", rows, nnz) == 22_399_360_000
+    assert bench.algorithmic_bytes("cusparse-csr", 15000 ** 2, 5 * 15000 ** 2 - 60000) == 17_999_280_004
+    assert bench.algorithmic_bytes("ellpack", 15000 ** 2, 0) == 17_100_000_000
+    assert bench.spmv_byte_formulas(rows, nnz)[:2] == (31_999_040_004, 30_399_040_000)
+    leg = {"variant": "stencil5/row-lds", "transport": "single rank (no communicator)", "allreduce": "none (single rank)", "degraded": None, "dt": 1.04,
+           "iterations": 14, "local_rows": rows, "local_nnz": -1, "spmv_ms": 36.4, "spmv_launches": 10, "probes": {"mix_probe": {"gbs": 6177.0}},
+           "breakdown": [{"rank": 0, "rows": rows, "iterations": 14.0, "spmv_interior_us": 3650.0, "update_r_us": 1440.0, "direction_update_us": 1490.0,
+                          "final_x_flush_us": 8300.0}],
+           "placement": None, "tile_runs": None, "setup_ms": None, "converged": True, "final_residual": 0.0108, "event_ms_per_solve": 103.9,
+           "history": [2e4, 1e-2], "ranks_agree_on_history": None, "parity_vs_golden": {"ok": True}, "rccl_ranks": 0, "devices": [], "rank_ms": [104.0]}
+    secs = 3.64e-3
+    spmv = {"operator": "stencil5-csr", "variant": "stencil5/row-lds", "grid": n, "median_ms": 3.64, "effective_gbs": 31_999_040_004 / secs / 1e9,
+            "effective_gbs_published_formula": 30_399_040_000 / secs / 1e9, "algorithmic_gbs": 22_399_360_000 / secs / 1e9, "gflops": 2 * nnz / secs / 1e9,
+            "vs_a100_published": 3.5, "frac_of_hbm_peak": 22_399_360_000 / secs / 1e9 / 8000.0, "sum_y": float(n * n + 4 * n), "output_placement": None}
+    compare = ({"stencil10k_ms": 0.93, "stencil10k_frac": 0.75, "csr10k_ms": 1.38, "csr10k_frac": 0.72, "stencil15k_ms": 2.1, "stencil15k_frac": 0.75,
+                "csr15k_ms": 3.2, "csr15k_frac": 0.7, "ell15k_ms": 2.97, "ell15k_frac": 0.72, "ell_stencil15k_ms": 1.98, "ell_stencil15k_frac": 0.79,
+                "compare_checksums_ok": True}, [{"operator": "stencil5-csr", "grid": 10000}])
+    args = argparse.Namespace(steps=10, warmup=3)
+    base = {"metric": "cg_iterations_per_second", "unit": "CG iterations/s", "n_gpus": 1, "steps": 10, "warmup": 3}
+    line = bench.build_line(args, base, leg, spmv, {}, 1, n, rows, nnz, compare)
+
+    def scalars(obj):  # what the driver keeps of an object
+        return {k: v for k, v in obj.items() if isinstance(v, (int, float, str, bool)) or v is None}
+
+    roof, conf = scalars(line["roofline"]), scalars(line["config"])
+    for key in ("spmv20k_median_ms", "spmv20k_effective_gbs", "spmv20k_effective_gbs_published_formula", "spmv20k_frac", "spmv20k_checksum_ok",
+                "stencil10k_ms", "stencil10k_frac", "csr10k_ms", "csr10k_frac", "stencil15k_ms", "stencil15k_frac", "csr15k_ms", "csr15k_frac",
+                "ell15k_ms", "ell15k_frac", "ell_stencil15k_ms", "ell_stencil15k_frac", "compare_checksums_ok", "frac", "achieved", "peak", "traffic"):
+        assert key in roof, key
+    assert roof["spmv20k_median_ms"] == 3.64 and abs(roof["spmv20k_effective_gbs"] - 8790.9) < 0.1 and roof["spmv20k_checksum_ok"] is True
+    assert abs(roof["spmv20k_frac"] - 0.7692) < 1e-4 and roof["bound"] == "hbm" and roof["unit"] == "GB/s"
+    assert conf["spmv_effective_gbs"] == roof["spmv20k_effective_gbs"] and conf["spmv_median_ms"] == 3.64
+    assert json.dumps(line)  # one JSON line
