@@ -29,7 +29,8 @@ configuration of reference docs/PROBLEM_SIZE_SCALING_RESULTS.md:40-47, on N row 
             the reference's other headline: stencil5-csr operator on its own staging vectors (the ones run_timed's kernel
             works on), x = 1, 5 warm-ups + 10 timed launches, >2 sigma outliers dropped, median -> "effective" GB/s by both
             of the reference's byte formulas (spmv_metrics.cu:85-101 and the published 12*nnz+16*rows).
-  scaling_probe  (N = 1 only; a PROJECTION, never part of `value`) the real per-rank slabs of a 2 / 4 / 8-GPU
+  scaling_probe  (N = 1 only; a PROJECTION, never part of `value`; the role processes load the LAB build of the library,
+            lib/libspmv_amd_lab.so, the only one with stand-in slabs) the real per-rank slabs of a 2 / 4 / 8-GPU
             run of this problem (rows [r*N/P, (r+1)*N/P), 160 KB halos), edge rank and a two-neighbour rank,
             each in a FRESH process of its own (what a rank of a real job is: inside one process the second slab
             inherits the first one's freed memory and measured up to 3 % off either way, profiles/r05_slab_attribution.txt),
@@ -672,6 +673,13 @@ def measure_leg(c, allreduce_kind):
         if rank == 0:
             print(f"bench.py: dot-product all-reduce: {allreduce}", file=sys.stderr)
     slab = B.CgSlab.stencil5(n, comm)
+    # which loop shape the library chose: its creation check solves a few iterations in both shapes on the first slab of a
+    # communicator and refuses the overlapped pipeline if the histories differ (include/spmv_amd/api.h)
+    loop_shape = slab.loop_shape()
+    if loop_shape.startswith("plain: the pipeline"):
+        degraded = (degraded + "; " if degraded else "") + loop_shape
+        if rank == 0:
+            print(f"bench.py: {loop_shape}", file=sys.stderr)
     placement = slab.placement()  # set-up work, outside the timed region (csrc/cg_slab.hip, place_coefficients)
     tile_runs = slab.tile_runs()  # ditto: row-lds tiles per XCD and run, the rule's neighbours timed at creation
     setup_ms = slab.setup_ms()    # wall ms of creation's phases; none of it inside the timed region
@@ -727,7 +735,7 @@ def measure_leg(c, allreduce_kind):
                "local_rows": slab.n_local, "local_nnz": slab.local_nnz, "spmv_ms": spmv_ms, "spmv_launches": spmv_launches,
                "event_ms_per_solve": float(np.median(event_ms)),
                "rccl_ranks": comm.transport_ranks() if (comm is not None and transport == "rccl") else 0,
-               "placement": placement, "tile_runs": tile_runs, "setup_ms": setup_ms}
+               "placement": placement, "tile_runs": tile_runs, "setup_ms": setup_ms, "loop_shape": loop_shape}
     finally:
         slab.destroy()
         if comm is not None:
@@ -986,6 +994,7 @@ def build_line(args, base, leg, spmv, extras, world, n, rows, nnz, compare=None)
                            "spmv_effective_gbs_published_formula": None if spmv is None or "effective_gbs" not in spmv else spmv["effective_gbs_published_formula"],
                            "spmv_median_ms": None if spmv is None or "median_ms" not in spmv else spmv["median_ms"],
                            "grid": n, "unknowns": rows, "nnz": nnz, "partition": f"{world} row slab(s)", "transport": transport,
+                           "loop_shape": leg.get("loop_shape"),
                            "iterations_per_solve": iterations, "converged": leg["converged"], "final_residual": leg["final_residual"],
                            # the solver's own clock (HIP events around the reference's timed region, median over the timed steps, rank 0):
                            # `value` is the wall clock around the K steps, which also holds the host's work between two solves
@@ -1063,7 +1072,7 @@ def main():
         emit(scaling_probe(args.grid, float(args.scaling_probe_only[0]), int(args.scaling_probe_only[1])))
         return
     if args.probe_role is not None:
-        B = load_binding()
+        B = load_binding().use_lab()  # stand-in slabs, self-neighbour communicator, stop_at: the LAB build (include/spmv_amd/lab.h)
         B.lib()
         B.require_gpu()
         B.lib().spmv_amd_set_device(0)

@@ -12,8 +12,13 @@ import subprocess
 import numpy as np
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-# SPMV_AMD_LIB: measurement aid, lets an A/B build of the library be loaded instead
+# The LAB build: the same sources with the test and measurement hooks compiled in (include/spmv_amd/lab.h). A second instance of
+# this module bound to it: use_lab() below (tests' `Blab` fixture, tools/, bench.py's scaling probe).
+LAB_LIB_PATH = os.path.join(PKG_DIR, "lib", "libspmv_amd_lab.so")
+# SPMV_AMD_LIB: measurement aid, lets another build of the library be loaded instead ("lab" = the LAB build)
 LIB_PATH = os.environ.get("SPMV_AMD_LIB") or os.path.join(PKG_DIR, "lib", "libspmv_amd.so")
+if LIB_PATH == "lab":
+    LIB_PATH = LAB_LIB_PATH
 
 ENTRY_DTYPE = np.dtype([("row", np.int32), ("col", np.int32), ("value", np.float64)], align=True)
 assert ENTRY_DTYPE.itemsize == 16
@@ -91,12 +96,14 @@ DECLARED_SYMBOLS = [
     "spmv_amd_comm_barrier", "spmv_amd_comm_transport", "spmv_amd_comm_transport_ranks",
     "spmv_amd_comm_mailbox_enable", "spmv_amd_comm_mailbox_prepare", "spmv_amd_comm_mailbox_connect", "spmv_amd_comm_mailbox_selftest",
     "spmv_amd_comm_mailbox_disable", "spmv_amd_comm_mailbox_ready",
-    "spmv_amd_cg_slab_create", "spmv_amd_cg_slab_create_stencil5", "spmv_amd_cg_slab_create_stencil5_as", "spmv_amd_cg_slab_set_vectors", "spmv_amd_cg_slab_solve",
-    "spmv_amd_cg_slab_gather", "spmv_amd_cg_slab_history", "spmv_amd_cg_slab_spmv", "spmv_amd_cg_slab_info",
-    "spmv_amd_cg_slab_time_spmv", "spmv_amd_cg_slab_set_timeline", "spmv_amd_cg_slab_set_option", "spmv_amd_operator_placement", "spmv_amd_cg_slab_placement", "spmv_amd_cg_slab_tile_runs", "spmv_amd_cg_slab_setup_ms", "spmv_amd_cg_slab_spmv_launch_ms",  "spmv_amd_cg_release_workspace", "spmv_amd_cg_slab_timeline_names", "spmv_amd_cg_slab_timeline", "spmv_amd_cg_slab_variant", "spmv_amd_cg_slab_destroy", "spmv_amd_version", "spmv_amd_write_stencil5_values",
+    "spmv_amd_cg_slab_create", "spmv_amd_cg_slab_create_stencil5", "spmv_amd_cg_slab_set_vectors", "spmv_amd_cg_slab_solve",
+    "spmv_amd_cg_slab_gather", "spmv_amd_cg_slab_loop_shape", "spmv_amd_cg_slab_history", "spmv_amd_cg_slab_spmv", "spmv_amd_cg_slab_info",
+    "spmv_amd_cg_slab_time_spmv", "spmv_amd_cg_slab_set_timeline", "spmv_amd_operator_placement", "spmv_amd_cg_slab_placement", "spmv_amd_cg_slab_tile_runs", "spmv_amd_cg_slab_setup_ms", "spmv_amd_cg_slab_spmv_launch_ms",  "spmv_amd_cg_release_workspace", "spmv_amd_cg_slab_timeline_names", "spmv_amd_cg_slab_timeline", "spmv_amd_cg_slab_variant", "spmv_amd_cg_slab_destroy", "spmv_amd_version", "spmv_amd_write_stencil5_values",
     "spmv_amd_blas1_axpy", "spmv_amd_blas1_axpby", "spmv_amd_blas1_axpy_dev", "spmv_amd_blas1_update_p_dev", "spmv_amd_blas1_dot",
     "spmv_amd_cg_fused_step",
 ]
+# What the LAB build exports on top of that (include/spmv_amd/lab.h); the product library must NOT have these.
+LAB_ONLY_SYMBOLS = ["spmv_amd_cg_slab_create_stencil5_as", "spmv_amd_cg_slab_set_option"]
 # C++-linkage entry points kept under the reference's own names (Itanium-mangled).
 DECLARED_CXX_SYMBOLS = [
     "SPMV_CSR", "SPMV_STENCIL5_CSR", "SPMV_STENCIL_HALO_MGPU", "SPMV_ELLPACK", "SPMV_STENCIL5_ELLPACK",
@@ -115,8 +122,9 @@ def build(force=False):
     done = subprocess.run(["make", "-C", PKG_DIR, "-j8"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if done.returncode != 0:
         raise RuntimeError(f"building libspmv_amd.so failed (make exit {done.returncode}); compiler output:\n{done.stdout[-8000:]}")
-    if not os.path.exists(LIB_PATH):
-        raise RuntimeError("libspmv_amd.so was not produced by the build")
+    for path in (LIB_PATH, LAB_LIB_PATH):
+        if not os.path.exists(path):
+            raise RuntimeError(f"{os.path.basename(path)} was not produced by the build")
 
 
 _lib = None
@@ -181,8 +189,11 @@ def lib():
     L.spmv_amd_comm_transport.restype = C.c_char_p
     L.spmv_amd_comm_transport.argtypes = [C.c_void_p]
     L.spmv_amd_comm_transport_ranks.argtypes = [C.c_void_p]
-    L.spmv_amd_cg_slab_create_stencil5_as.restype = C.c_void_p
-    L.spmv_amd_cg_slab_create_stencil5_as.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p]
+    if hasattr(L, "spmv_amd_cg_slab_create_stencil5_as"):  # LAB build only
+        L.spmv_amd_cg_slab_create_stencil5_as.restype = C.c_void_p
+        L.spmv_amd_cg_slab_create_stencil5_as.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.spmv_amd_cg_slab_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_longlong]
+        L.spmv_amd_cg_slab_set_option.restype = C.c_int
     L.spmv_amd_cg_slab_create.restype = C.c_void_p
     L.spmv_amd_cg_slab_create.argtypes = [C.POINTER(MatrixData), C.c_void_p]
     L.spmv_amd_cg_slab_create_stencil5.restype = C.c_void_p
@@ -197,12 +208,12 @@ def lib():
     L.spmv_amd_cg_slab_destroy.argtypes = [C.c_void_p]
     L.spmv_amd_cg_slab_set_timeline.argtypes = [C.c_void_p, C.c_int]
     L.spmv_amd_cg_slab_set_timeline.restype = None
-    L.spmv_amd_cg_slab_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_longlong]
-    L.spmv_amd_cg_slab_set_option.restype = C.c_int
     L.spmv_amd_cg_slab_timeline_names.restype = C.c_char_p
     L.spmv_amd_cg_slab_timeline.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     L.spmv_amd_cg_slab_variant.restype = C.c_char_p
     L.spmv_amd_cg_slab_variant.argtypes = [C.c_void_p]
+    L.spmv_amd_cg_slab_loop_shape.restype = C.c_char_p
+    L.spmv_amd_cg_slab_loop_shape.argtypes = [C.c_void_p]
     L.load_matrix_market.argtypes = [C.c_char_p, C.POINTER(MatrixData)]
     L.write_matrix_market_stencil5.argtypes = [C.c_int, C.c_char_p]
     L.spmv_amd_write_stencil5_values.argtypes = [C.c_int, C.c_char_p, C.c_char_p, C.c_char_p]
@@ -211,6 +222,23 @@ def lib():
     L.benchmark_with_stats.argtypes = [RUN_TIMED_FN, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(BenchmarkStats)]
     _lib = L
     return L
+
+
+def is_lab():
+    """True when the loaded library is the LAB build (it has the hooks of include/spmv_amd/lab.h)."""
+    return hasattr(lib(), "spmv_amd_cg_slab_set_option")
+
+
+def use_lab():
+    """A SECOND instance of this module bound to the LAB build (this one stays on the product library). Both libraries can be
+    loaded in one process: each has its own globals (ctypes loads them RTLD_LOCAL)."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("spmv_amd_binding_lab", os.path.abspath(__file__))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.LIB_PATH = LAB_LIB_PATH
+    return mod
 
 
 def require_gpu():
@@ -570,8 +598,10 @@ class CgSlab:
 
     @classmethod
     def stencil5_as(cls, n, as_rank, as_world, comm):
-        """The slab rank `as_rank` of an `as_world`-GPU run would own, on a single self-neighbour rank (timing only)."""
+        """The slab rank `as_rank` of an `as_world`-GPU run would own, on a single self-neighbour rank (LAB build only)."""
         require_gpu()
+        if not is_lab():
+            raise RuntimeError("stand-in slabs exist in the LAB build only (binding.use_lab(), lib/libspmv_amd_lab.so)")
         return cls(lib().spmv_amd_cg_slab_create_stencil5_as(int(n), int(as_rank), int(as_world), comm.handle), n * n)
 
     def set_vectors(self, b=None, x0=None):
@@ -605,6 +635,10 @@ class CgSlab:
 
     def variant(self):
         return lib().spmv_amd_cg_slab_variant(self.h).decode()
+
+    def loop_shape(self):
+        """"single rank" | "pipeline ..." | "plain: <who decided>" (include/spmv_amd/api.h)."""
+        return lib().spmv_amd_cg_slab_loop_shape(self.h).decode()
 
     def timeline_solve(self, max_iters=1000, tol=1e-6):
         """One solve with stage-boundary events (no host syncs); returns (stats, {name: value})."""
@@ -649,7 +683,9 @@ class CgSlab:
         return np.array(out[:min(count, 1024)], dtype=np.float64)
 
     def set_option(self, name, value):
-        """Loop option of this slab (include/spmv_amd/api.h, spmv_amd_cg_slab_set_option, lists them): A/B runs on the same allocations."""
+        """Option of this slab (LAB build only; include/spmv_amd/lab.h lists them): A/B runs on the same allocations."""
+        if not is_lab():
+            raise RuntimeError("slab options exist in the LAB build only (binding.use_lab(), lib/libspmv_amd_lab.so)")
         if lib().spmv_amd_cg_slab_set_option(self.h, name.encode(), int(value)) != 0:
             raise ValueError(f"unknown slab option {name!r}")
 

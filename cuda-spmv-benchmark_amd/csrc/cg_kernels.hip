@@ -152,27 +152,6 @@ __global__ __launch_bounds__(kBlock) void reduce_one_launch_kernel(const double*
                        (int)gridDim.x, stage, tail, s, &s_last);
 }
 
-// Two launches (ReduceScratch::one_launch = false, the form of rounds 2-4; A/B aid): stage one ...
-__global__ __launch_bounds__(kBlock) void reduce_slices_kernel(const double* __restrict__ partials, int count, int slice,
-                                                               double* __restrict__ sums, const int* __restrict__ skip_flag) {
-    __shared__ double s[kBlock];
-    if (skip_flag != nullptr && *skip_flag != 0) return;
-    const int lo = blockIdx.x * slice;
-    block_tree(strided_sum(partials, lo, min(lo + slice, count)), s);
-    if (threadIdx.x == 0) sums[blockIdx.x] = s[0];
-}
-
-// ... and stage two over [sums | extra].
-__global__ __launch_bounds__(kBlock) void reduce_final_kernel(const double* __restrict__ sums, int blocks, const double* __restrict__ extra,
-                                                              int extra_count, ReduceTail tail) {
-    __shared__ double s[kBlock];
-    if (tail.skip_flag != nullptr && *tail.skip_flag != 0) {
-        reduce_skipped(tail, true);
-        return;
-    }
-    reduce_finish(blocks + extra_count, [&](int i) { return i < blocks ? sums[i] : extra[i - blocks]; }, s, tail);
-}
-
 // A short list of partials (count <= 1024): one workgroup does both stages -- the one slice, then [its sum | extra].
 __global__ __launch_bounds__(kBlock) void reduce_single_kernel(const double* __restrict__ partials, int count, const double* __restrict__ extra,
                                                                int extra_count, ReduceTail tail) {
@@ -285,16 +264,14 @@ __global__ __launch_bounds__(kStream) void cg_update_px_kernel(size_t n, const C
                                                               const double* __restrict__ r,
                                                               double* __restrict__ p,
                                                               const double* x_in, double* x, int iteration,
-                                                              int reverse, int fma_form, size_t pairs_first, size_t pair_shift) {
+                                                              int reverse, int fma_form) {
     if (s->iterations != iteration) return;
     const bool advance = s->converged == 0;
     const double alpha = s->alpha, beta = s->beta;
     const unsigned block = reverse ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
     const size_t pairs = n >> 1;
-    size_t i = (size_t)block * kStream + threadIdx.x;
-    const bool live = i < pairs;
-    if (i >= pairs_first) i += pair_shift;  // two row ranges in one launch (cg_slab.hip, early halo): the second starts pair_shift later
-    if (live) {
+    const size_t i = (size_t)block * kStream + threadIdx.x;
+    if (i < pairs) {
         d2 pv = load_once(p, i);
         d2 xv = load_once(x_in, i);
         xv.x = fma(alpha, pv.x, xv.x);
@@ -365,9 +342,11 @@ __global__ __launch_bounds__(kStream) void cg_direction_kernel(DirectionArgs a, 
         live_lane = i < a.bulk_pairs;
         at = (a.bulk_lo >> 1) + i;
     }
-    const int was_converged = s->converged;
+    // (atomic: when the step rides in this launch, workgroup 0 may be storing `converged` while the others load it -- either
+    // value leads to the verdict every workgroup derives below, but the load must not be one the compiler may assume unraced)
+    const int was_converged = __hip_atomic_load(&s->converged, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const double rr_new = s->rr_new, rr_prev = s->rr_ring[(a.iteration - 1) & 1], b_norm = s->b_norm;
-    const int stop_at = s->stop_at;
+    const int stop_at = cg_stop_at(s);
     if (blockIdx.x == 0 && threadIdx.x == 0 && a.step.host_record != nullptr)
         cg_scalars_step(s, a.step.tol, a.step.history, a.step.host_record, a.step.sequence, a.step.alpha_ring, a.step.ring_slots);
     const bool live = was_converged == 0 && !cg_converging(rr_new, b_norm, a.step.tol, stop_at, a.iteration);
@@ -419,7 +398,7 @@ __global__ __launch_bounds__(kStream) void cg_update_p_ring_kernel(size_t n, con
                                                                    const double* __restrict__ r,
                                                                    const double* __restrict__ p_in,
                                                                    double* __restrict__ p_out, int iteration,
-                                                                   int reverse, int fma_form, size_t pairs_first, size_t pair_shift) {
+                                                                   int reverse, int fma_form) {
     // Scalars FIRST here, unlike cg_update_r_kernel: this launch is enqueued before the host knows whether the
     // iteration converged, and the launch of the converging iteration must cost nothing (loading first would read
     // 16 B/row for nothing once per solve).
@@ -427,10 +406,8 @@ __global__ __launch_bounds__(kStream) void cg_update_p_ring_kernel(size_t n, con
     const double beta = s->beta;
     const unsigned block = reverse ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
     const size_t pairs = n >> 1;
-    size_t i = (size_t)block * kStream + threadIdx.x;
-    const bool live = i < pairs;
-    if (i >= pairs_first) i += pair_shift;  // two row ranges in one launch (see cg_update_px_kernel)
-    if (live) {
+    const size_t i = (size_t)block * kStream + threadIdx.x;
+    if (i < pairs) {
         const d2 rv = load_once(r, i);
         d2 pv = load_once(p_in, i);
         pv.x = direction(rv.x, beta, pv.x, fma_form);
@@ -535,7 +512,7 @@ void launch_dot(size_t n, const double* x, const double* y, double* scratch, dou
     // scratch = [one partial per block | the reduction's own scratch]
     const unsigned blocks = stream_grid(n);
     hipLaunchKernelGGL(dot_partials_kernel, dim3(blocks), dim3(kStream), 0, stream, n, x, y, scratch);
-    launch_reduce_partials(scratch, (int)blocks, d_result, nullptr, stream, ReduceScratch{scratch + blocks, true});
+    launch_reduce_partials(scratch, (int)blocks, d_result, nullptr, stream, ReduceScratch{scratch + blocks});
 }
 
 void launch_scalar_divide(const double* d_num, const double* d_den, double* d_out, hipStream_t stream) {
@@ -563,20 +540,7 @@ void launch_cg_update_r(size_t n, const CgScalars* s, const double* Ap, double* 
 void launch_cg_update_px(size_t n, const CgScalars* s, const double* r, double* p, const double* x_in,
                          double* x, int iteration, hipStream_t stream, bool reverse, bool fma_form) {
     hipLaunchKernelGGL(cg_update_px_kernel, dim3(stream_grid(n)), dim3(kStream), 0, stream, n, s, r, p, x_in, x,
-                       iteration, reverse ? 1 : 0, fma_form ? 1 : 0, ~(size_t)0, (size_t)0);
-}
-
-// The same two kernels over TWO row ranges in one launch: [0, count_a) and [second, second + count_b), all three even -- the
-// slab's first and last grid row (rounded outwards to 4 KiB), whose new direction values the neighbours are waiting for.
-void launch_cg_update_px_two_ranges(size_t count_a, size_t second, size_t count_b, const CgScalars* s, const double* r, double* p,
-                                    const double* x_in, double* x, int iteration, hipStream_t stream, bool fma_form) {
-    hipLaunchKernelGGL(cg_update_px_kernel, dim3(stream_grid(count_a + count_b)), dim3(kStream), 0, stream, count_a + count_b, s, r, p, x_in, x,
-                       iteration, 0, fma_form ? 1 : 0, count_a >> 1, (second - count_a) >> 1);
-}
-void launch_cg_update_p_ring_two_ranges(size_t count_a, size_t second, size_t count_b, const CgScalars* s, const double* r,
-                                        const double* p_in, double* p_out, int iteration, hipStream_t stream, bool fma_form) {
-    hipLaunchKernelGGL(cg_update_p_ring_kernel, dim3(stream_grid(count_a + count_b)), dim3(kStream), 0, stream, count_a + count_b, s, r, p_in,
-                       p_out, iteration, 0, fma_form ? 1 : 0, count_a >> 1, (second - count_a) >> 1);
+                       iteration, reverse ? 1 : 0, fma_form ? 1 : 0);
 }
 
 namespace {
@@ -596,12 +560,9 @@ void reduce_impl(const double* partials, int count, const double* extra, int ext
     }
     if (blocks <= 1) {
         hipLaunchKernelGGL(reduce_single_kernel, dim3(1), dim3(kBlock), 0, stream, partials, count, extra, extra_count, tail);
-    } else if (scratch.one_launch) {
+    } else {
         hipLaunchKernelGGL(reduce_one_launch_kernel, dim3(blocks), dim3(kBlock), 0, stream, partials, count, slice, extra, extra_count,
                            reduce_stage_of(scratch.base), tail);
-    } else {
-        hipLaunchKernelGGL(reduce_slices_kernel, dim3(blocks), dim3(kBlock), 0, stream, partials, count, slice, scratch.base, d_skip_flag);
-        hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(kBlock), 0, stream, scratch.base, blocks, extra, extra_count, tail);
     }
 }
 }  // namespace
@@ -666,7 +627,7 @@ void launch_cg_scalars_step(CgScalars* s, double tol, double* history, int* host
 void launch_cg_update_p_ring(size_t n, const CgScalars* s, const double* r, const double* p_in, double* p_out,
                              int iteration, hipStream_t stream, bool reverse, bool fma_form) {
     hipLaunchKernelGGL(cg_update_p_ring_kernel, dim3(stream_grid(n)), dim3(kStream), 0, stream, n, s, r, p_in, p_out,
-                       iteration, reverse ? 1 : 0, fma_form ? 1 : 0, ~(size_t)0, (size_t)0);
+                       iteration, reverse ? 1 : 0, fma_form ? 1 : 0);
 }
 
 void launch_cg_flush_x(size_t n, const double* alphas, const RingSlots& ring, int slots, int first_slot, int count,

@@ -25,9 +25,9 @@
 //  * the halo exchange of iteration k+1 runs on a side stream under the interior rows' SpMV; the
 //    first and last grid row of the slab are launched once the halo has landed. Each row is
 //    computed by the same code whichever launch it falls in, so overlap cannot change results;
-//  * (round 3) the direction update runs on the slab's first / last grid row FIRST and the exchange starts behind that
-//    launch: the RCCL send / recv kernel, which otherwise competes for CUs with a SpMV that fills the chip and ends after
-//    it, is over long before the interior rows are (early halo; set_option("early_halo", 0) = the old order, same bits);
+//  * (round 3) the direction update runs on the slab's first / last grid row FIRST and the exchange starts behind them:
+//    the RCCL send / recv kernel, which otherwise competes for CUs with a SpMV that fills the chip and ends after
+//    it, is over long before the interior rows are (early halo);
 //  * every wait on another rank is bounded (watchdog.hpp): a wedged peer becomes a report and a non-zero exit;
 //  * (round 4) WHERE the vectors lie is part of the design: on MI355X kernels that walk several vectors in lock step lose 6.5 %
 //    when the vectors lie in different classes of 32 GiB address regions, and only hipMalloc decides the class. r, Ap and the
@@ -44,7 +44,14 @@
 //    is ONE launch whose first workgroups write the rows the neighbours need through to memory and raise the flag the side
 //    stream's exchange waits for -- on the RCCL path it also takes the scalar step, and nobody waits for it (every workgroup
 //    derives beta and the verdict from scalars the step does not write). Five launches per iteration on a slab with neighbours
-//    (+ two ncclAllReduce); every option combination gives the same bits (tests/test_cg_gpu.py).
+//    (+ two ncclAllReduce).
+//  * (round 6) TWO shapes of the loop, chosen once per solve (LoopShape): the PIPELINE above, and the PLAIN order -- halo
+//    exchange on the compute stream behind the whole direction update, the reference's own (:680-703) -- for detailed timers,
+//    SPMV_AMD_NO_OVERLAP=1 (bench.py's fallback), the in-place form and slabs too thin to split. The A/B switches that kept the
+//    shapes of rounds 2-5 alive (two-launch reductions, event-ordered hand-overs, the direction update in three launches, no
+//    sweep alternation) are gone with their code; both shapes give the same bits (tests/test_cg_gpu.py). Test and measurement
+//    hooks (stand-in slabs, stop_at, loop options, fault injection) exist in the LAB build only (-DSPMV_AMD_LAB,
+//    lib/libspmv_amd_lab.so): the product library has no switch that can change a result.
 //
 // The same loop also serves the reference's SINGLE-GPU entry point, cg_solve_device (cg_solver.cu:436-706): a slab that
 // borrows the caller's SpmvOperator instead of owning a CSR (cg_solve_on_operator, near the end of this file), and it can
@@ -55,6 +62,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <mutex>
 #include <thread>
@@ -127,11 +135,9 @@ struct SpmvAmdCgSlab {
     double* partials_spmv = nullptr;  // dot partials of the SpMV launches (interior, head, tail back to back)
     double* partials_blas = nullptr;
     double* reduce_stage = nullptr;  // scratch of this slab's reductions (kernels.hpp, ReduceScratch)
-    // One launch per dot product (round 5, reduce_device.hpp); set_option("reduce_one_launch", 0):
-    // the two launches of rounds 2-4, same sums bit for bit (A/B aid). With it the boundary rows of a split SpMV ride in the
-    // launch that reduces the SpMV's partials (launch_stencil5_edges_and_reduce).
-    bool reduce_one_launch = true;
-    ReduceScratch scratch() const { return ReduceScratch{reduce_stage, reduce_one_launch}; }
+    // One launch per dot product (round 5, reduce_device.hpp); the boundary rows of a split SpMV ride in the launch that
+    // reduces the SpMV's partials (launch_stencil5_edges_and_reduce).
+    ReduceScratch scratch() const { return ReduceScratch{reduce_stage}; }
     CgScalars* d_s = nullptr;
     double* d_hist = nullptr;
     int hist_cap = 0;
@@ -143,17 +149,15 @@ struct SpmvAmdCgSlab {
     // raises *d_halo_flag to that exchange's sequence number, and the boundary waves of the launch that needs the halo rows
     // wait for it themselves -- no cross-stream event wait (a barrier packet, ~10 us in front of the launch it guards:
     // profiles/r05_ab_reduce_one_launch.txt, 17 us idle against 7) on the path between a SpMV and its dot product.
-    // set_option("halo_flag", 0): the event wait of rounds 1-4. Same launches, same bits.
     unsigned* d_halo_flag = nullptr;
     unsigned halo_sequence = 0;
-    bool halo_flag = true;
-    // set_option("edges_in_step", 0): the early direction update of the edge rows as a launch of its own, the scalar step of the
-    // RCCL path too, the exchange released by an event (rounds 3-4); 1: one launch for step, edge rows and the first piece of the rest
-    bool edges_in_step = true;
+#ifdef SPMV_AMD_LAB
     // Measurement hook, set_option("stop_at", k): iteration k counts as the converging one whatever its residual (kernels.hpp,
-    // CgScalars::stop_at). A stand-in slab's periodic system never converges; with max_iters alone it would run one direction
-    // update + halo exchange more than the rank of a real job, whose 14th iteration converges. Timing only.
+    // CgScalars::stop_at). A stand-in slab's mirrored system does not converge in 14 iterations; with max_iters alone it would run
+    // one direction update + halo exchange more than the rank of a real job, whose 14th iteration converges. Timing only.
     int stop_at = 0;
+    int test_wedge_overlapped_exchange = 0;  // SPMV_AMD_TEST_WEDGE_OVERLAPPED_EXCHANGE=1 / 2, see exchange_halo
+#endif
     // non-null while a solve runs on a communicator with a working peer mailbox: the last stage of every dot
     // product then completes the sum across the ranks itself (no all-reduce launch)
     const PeerMailbox* reduce_mailbox = nullptr;
@@ -185,7 +189,7 @@ struct SpmvAmdCgSlab {
     // times the iteration count. Each pair puts two barrier packets (~7 us each, profiles/r02_slab_timeline.txt) next to the
     // launch it times, so every 7th launch is timed and the phase moves on by one with every solve: a run of solves covers
     // every iteration of the loop (later iterations work on other ring slots and are up to 2 % faster or slower).
-    // set_option("spmv_event_stride", 1) times every launch, 0 none.
+    // (LAB build: set_option("spmv_event_stride", 1) times every launch, 0 none.)
     std::vector<hipEvent_t> spmv_ev;
     int spmv_event_stride = 7;
     int spmv_event_phase = 0;  // solves so far
@@ -194,21 +198,21 @@ struct SpmvAmdCgSlab {
     // the 256 MiB Infinity Cache. Results and partial slots are independent of the direction. Measured on
     // MI355X, whole solve: 50 M rows (the per-GPU slab of an 8-GPU run) 15.90 -> 15.60 ms, SpMV launches
     // 0.520 -> 0.496 ms; 100 M rows -0.5 %, 200 M rows -0.8 %, 400 M rows unchanged. Making the producers'
-    // stores / consumers' loads plain instead of nontemporal did not raise the hit share (set_option("pingpong", 0)
-    // switches the alternation off).
-    bool pingpong = true;
+    // stores / consumers' loads plain instead of nontemporal did not raise the hit share.
     bool roctx_always = false;  // SPMV_AMD_ROCTX=1: roctx ranges even without detailed timers
-    bool no_overlap = false;  // SPMV_AMD_NO_OVERLAP=1: halo exchange on the compute stream (the reference's shape; bench.py's fallback)
-    int test_wedge_overlapped_exchange = 0;  // SPMV_AMD_TEST_WEDGE_OVERLAPPED_EXCHANGE=1 / 2, see exchange_halo
-    bool early_halo = true;   // set_option("early_halo", 0): halo exchange only after the whole direction update (round 2's order)
+    bool no_overlap = false;  // SPMV_AMD_NO_OVERLAP=1: the PLAIN loop shape (halo exchange on the compute stream: the reference's; bench.py's fallback)
+    const char* no_overlap_why = "";  // who chose the plain shape: the environment switch, or the creation check (verify_pipeline)
+    // verify_pipeline's two short solves: waits on the other stream's flags give up after wait_limit_s instead of 20 s, and a
+    // wait that gave up ends that solve (selfcheck_late) instead of the process
+    bool selfcheck = false, selfcheck_late = false;
+    double wait_limit_s = 0.0;  // 0 = the default bound (halo_wait_limit_s)
     // Late bulk (round 4): the direction update of iteration k is enqueued before the host knows whether k converged, and on
     // the converging iteration that launch only reads a flag -- 3.1 M one-wave workgroups at 4e8 rows, 0.65 ms of pure
     // dispatch per solve. On large slabs the host enqueues a LEAD piece of lead_rows rows (long enough to cover one host
     // wake-up and a launch), reads the status record, and enqueues the rest only if the loop goes on: the reference tests
     // convergence before its p update too (cg_solver_mgpu_partitioned.cu:652-676). Same kernel over disjoint row ranges:
     // same bits. Measured at 4e8 rows on one slab, settings alternated between solves: 108.04 -> 107.34 ms per solve, -0.65 %
-    // (profiles/r04_ab_late_bulk.txt). Small slabs (a whole update is ~0.2 ms at 5e7 rows) keep the single launch;
-    // set_option("late_bulk", 0 / 1) forces. Ring mode only.
+    // (profiles/r04_ab_late_bulk.txt). Small slabs (a whole update is ~0.2 ms at 5e7 rows) keep the single launch. Ring mode only.
     bool late_bulk = false;
     size_t lead_rows = (size_t)1 << 24;
     int poll_sequence = 0;
@@ -345,7 +349,10 @@ void make_common(SpmvAmdCgSlab* s) {
     }
     s->shape = current_launch_shape();
     if (const char* v = getenv("SPMV_AMD_NO_OVERLAP")) s->no_overlap = v[0] == '1';
+    if (s->no_overlap) s->no_overlap_why = "SPMV_AMD_NO_OVERLAP=1";
+#ifdef SPMV_AMD_LAB
     if (const char* v = getenv("SPMV_AMD_TEST_WEDGE_OVERLAPPED_EXCHANGE")) s->test_wedge_overlapped_exchange = atoi(v);
+#endif
     if (const char* v = getenv("SPMV_AMD_ROCTX")) s->roctx_always = v[0] == '1';
     s->late_bulk = nl >= 100000000;
     s->partials_blas = device_alloc<double>(dot_scratch_doubles(nl));
@@ -485,6 +492,13 @@ void tune_tile_runs(SpmvAmdCgSlab* s) {
     s->tile_runs.assign(rec, rec + 4);
 }
 
+// In-kernel / side-stream waits for the other stream's flags give up well inside the host's watchdog.
+double halo_wait_limit_s(const SpmvAmdCgSlab* s) {
+    if (s->wait_limit_s > 0.0) return s->wait_limit_s;
+    const double w = watchdog_limit_seconds();
+    return w > 0.0 && w < 40.0 ? 0.5 * w : 20.0;
+}
+
 bool partition_ok(const SpmvAmdComm* comm, int n, int grid, int n_local) {
     if (!comm->exchanges_halos()) return true;
     if (grid <= 0) {
@@ -573,14 +587,13 @@ int slab_spmv(SpmvAmdCgSlab* s, bool with_dot, bool overlap, const int* skip,
         // in-loop SpMV: the boundary rows ride in the launch that reduces the partials (one launch instead of three); the
         // launch timer and the timeline's boundary-row mark then stop behind the interior rows (all but one or two grid rows
         // of the slab), and the stage "reduce_pAp" holds the halo wait, the boundary rows and the sum
-        const bool fused_tail = with_dot && part != nullptr && init == nullptr && s->reduce_one_launch && lo % A.grid_size == 0 &&
+        const bool fused_tail = with_dot && part != nullptr && init == nullptr && lo % A.grid_size == 0 &&
                                 (s->n_local - hi) % A.grid_size == 0 && lo <= A.grid_size && s->n_local - hi <= A.grid_size;
         if (fused_tail && spmv_done) HIP_CHECK(hipEventRecord(spmv_done, s->compute));
         HaloArrival arrival;
-        if (fused_tail && overlap && s->halo_flag) {
+        if (fused_tail && overlap) {
             // the boundary waves wait for the exchange's arrival flag themselves; bounded well inside the host's watchdog
-            const double limit_s = watchdog_limit_seconds() > 0.0 && watchdog_limit_seconds() < 40.0 ? 0.5 * watchdog_limit_seconds() : 20.0;
-            arrival = HaloArrival{s->d_halo_flag, s->halo_sequence, (long long)(limit_s * 1e8), &s->h_poll->halo_late};
+            arrival = HaloArrival{s->d_halo_flag, s->halo_sequence, (long long)(halo_wait_limit_s(s) * 1e8), &s->h_poll->halo_late};
         } else if (overlap) {
             HIP_CHECK(hipStreamWaitEvent(s->compute, s->ev_halo_done, 0));
         }
@@ -659,17 +672,22 @@ void exchange_halo(SpmvAmdCgSlab* s, double* v, hipStream_t stream) {
     // a staged transport blocks in here on its host exchange, RCCL may block while it connects peers
     WatchdogScope guard("halo exchange (send/recv of the first and last grid row)", s->comm->rank, s->enqueued_iteration,
                         report_slab_state, s);
-    // SPMV_AMD_TEST_WEDGE_OVERLAPPED_EXCHANGE=1 (test hook): an exchange issued on the SIDE stream never returns -- the host
+    // LAB build, SPMV_AMD_TEST_WEDGE_OVERLAPPED_EXCHANGE=1 (test hook): an exchange issued on the SIDE stream never returns -- the host
     // thread stays in here, as it would behind an RCCL call that blocks -- so that the watchdog ends the process and a
     // supervisor can be shown to restart the ranks without the overlap (tests/test_distributed.py). Nothing is wedged on the GPU.
     // = 2: the exchange returns, but a pipeline that overlaps delivers WRONG NUMBERS (the right-hand side is nudged once): what a
     // hand-over between the streams that loses rows between two devices would look like to the supervisor.
+#ifdef SPMV_AMD_LAB
     while (s->test_wedge_overlapped_exchange == 1 && stream == s->side && s->side != nullptr) std::this_thread::sleep_for(std::chrono::milliseconds(200));
     if (s->test_wedge_overlapped_exchange == 2 && stream == s->side && s->side != nullptr) {
         static const double nudged = 1.001;
         HIP_CHECK(hipMemcpyAsync(s->b, &nudged, sizeof nudged, hipMemcpyHostToDevice, stream));
         s->test_wedge_overlapped_exchange = 0;
     }
+    // = 3: the rows of a side-stream exchange never travel (the halos keep what they held) -- what the creation check
+    // (verify_pipeline) must notice; = 4: the exchange runs but its arrival flag is never raised (SolveRun::start_halo)
+    if (s->test_wedge_overlapped_exchange == 3 && stream == s->side && s->side != nullptr) return;
+#endif
     s->comm->halo_exchange(s->has_prev ? v : nullptr, s->has_next ? v + (s->n_local - s->halo) : nullptr,
                            s->has_prev ? v - s->halo : nullptr, s->has_next ? v + s->n_local : nullptr, s->halo, stream);
 }
@@ -681,11 +699,57 @@ void allreduce_scalar(SpmvAmdCgSlab* s, double* d_value, const char* stage) {
     WatchdogScope guard(stage, s->comm->rank, s->enqueued_iteration, report_slab_state, s);
     s->comm->allreduce_sum(d_value, 1, s->compute);
 }
-void exchange_p_halo(SpmvAmdCgSlab* s, hipStream_t stream) { exchange_halo(s, s->p, stream); }
 
 }  // namespace
 
 namespace {
+// The pipeline hands rows between its two streams through device flags and reads the received halo rows inside a running
+// kernel -- constructions that were proven on ONE device (with the rank as its own neighbour) and cannot be proven between
+// devices on a one-GPU box. So the FIRST slab created on a communicator that exchanges halos checks them where it runs:
+// four iterations in the plain order (everything on the compute stream, no flag), four in the pipeline; the two shapes give
+// the same bits by construction, so any difference in the residual history on any rank -- lost or stale halo rows, a flag
+// that never comes (the waits give up after 2 s here) -- refuses the pipeline for every slab on that communicator: they run
+// the plain order, say so on stderr and in spmv_amd_cg_slab_loop_shape(). ~10 iterations' worth of set-up, once per
+// communicator, outside every timed region (the library needed the check bench.py had).
+void verify_pipeline(SpmvAmdCgSlab* s) {
+    SpmvAmdComm* comm = s->comm;
+    if (s->op != nullptr || !comm->exchanges_halos()) return;
+    if (s->no_overlap) return;  // the caller asked for the plain order: nothing to verify, nothing recorded
+    if (comm->pipeline_verdict == 0) {
+        const CGConfigMultiGPU few = {4, 0.0, 0, 0};
+        CGStatsMultiGPU st;
+        s->selfcheck = true, s->selfcheck_late = false, s->wait_limit_s = 2.0;
+        s->no_overlap = true;
+        spmv_amd_cg_slab_solve(s, &few, &st);
+        const std::vector<double> plain = s->history;
+        s->no_overlap = false;
+        spmv_amd_cg_slab_solve(s, &few, &st);
+        const bool same = !s->selfcheck_late && plain.size() == s->history.size() && plain.size() == 5 &&
+                          memcmp(plain.data(), s->history.data(), plain.size() * sizeof(double)) == 0;
+        s->selfcheck = false, s->selfcheck_late = false, s->wait_limit_s = 0.0;
+        double bad = same ? 0.0 : 1.0;
+        if (!same)
+            fprintf(stderr, "[cg-slab] rank %d: the overlapped pipeline did NOT reproduce the plain order's residual history in the creation check\n", comm->rank);
+        if (comm->world > 1) {  // every rank learns whether every rank agrees
+            double* d = device_alloc<double>(1);
+            upload(d, &bad, 1);
+            WatchdogScope guard("creation check: all-reduce of the ranks' verdicts", comm->rank, -1, report_slab_state, s);
+            comm->allreduce_sum(d, 1, s->compute);
+            HIP_CHECK(hipStreamSynchronize(s->compute));
+            download(&bad, d, 1);
+            device_release(d);
+        }
+        comm->pipeline_verdict = bad == 0.0 ? 1 : -1;
+        if (comm->pipeline_verdict < 0 && comm->rank == 0)
+            fprintf(stderr, "[cg-slab] %g rank(s) refused the overlapped pipeline: every solve on this communicator runs the plain order "
+                            "(halo exchange on the compute stream, the reference's own)\n", bad);
+    }
+    if (comm->pipeline_verdict < 0) {
+        s->no_overlap = true;
+        s->no_overlap_why = "creation check";
+    }
+}
+
 SpmvAmdCgSlab* create_from_matrix(MatrixData* mat, SpmvAmdComm* comm, bool setup_trials) {
     if (comm == nullptr) comm = self_comm();
     if (mat->rows != mat->cols) {
@@ -711,11 +775,20 @@ SpmvAmdCgSlab* create_from_matrix(MatrixData* mat, SpmvAmdComm* comm, bool setup
     s->A.upload_slab(csr_mat, row_offset, n_local, mat->grid_size);
     s->setup_ms[0] = setup_phase_ms(phase);
     make_common(s);
+    verify_pipeline(s);
     return s;
 }
 }  // namespace
 
 extern "C" SpmvAmdCgSlab* spmv_amd_cg_slab_create(MatrixData* mat, SpmvAmdComm* comm) { return create_from_matrix(mat, comm, true); }
+
+// Which shape this slab's loop takes and who decided: "single rank", "pipeline", "plain: <why>". A static string.
+extern "C" const char* spmv_amd_cg_slab_loop_shape(const SpmvAmdCgSlab* s) {
+    if (!s->comm->exchanges_halos()) return "single rank";
+    if (!s->no_overlap) return s->comm->pipeline_verdict > 0 ? "pipeline (verified against the plain order at creation)" : "pipeline";
+    return s->comm->pipeline_verdict < 0 ? "plain: the pipeline's residual history differed from the plain order's in the creation check"
+                                         : "plain: SPMV_AMD_NO_OVERLAP=1";
+}
 
 namespace {
 SpmvAmdCgSlab* create_stencil5_slab(int n, int part_rank, int part_world, SpmvAmdComm* comm) {
@@ -739,6 +812,7 @@ SpmvAmdCgSlab* create_stencil5_slab(int n, int part_rank, int part_world, SpmvAm
     s->A.generate_stencil5(n, row_offset, n_local, 5.0, -1.0, nullptr);
     s->setup_ms[0] = setup_phase_ms(phase);
     make_common(s);
+    verify_pipeline(s);
     return s;
 }
 }  // namespace
@@ -748,11 +822,13 @@ extern "C" SpmvAmdCgSlab* spmv_amd_cg_slab_create_stencil5(int n, SpmvAmdComm* c
     return create_stencil5_slab(n, comm->rank, comm->world, comm);
 }
 
-// Stand-in slab for measurements on one GPU: the slab rank `as_rank` of an `as_world`-GPU job would own (same
+#ifdef SPMV_AMD_LAB
+// (LAB build only.) Stand-in slab for measurements on one GPU: the slab rank `as_rank` of an `as_world`-GPU job would own (same
 // rows, same CSR bytes, same halo length, neighbours on the same sides), carried by a single-rank communicator
 // created under SPMV_AMD_SELF_NEIGHBOUR=1, which exchanges the halo rows with itself through the transport's own
-// send / recv path. The numbers it produces are those of a slab whose north / south neighbours are its own last /
-// first grid row (a periodic strip): a different linear system with the same work per iteration. Timing only.
+// send / recv path. The numbers it produces are those of a slab whose north / south neighbours are its own first / last grid
+// row (the slab mirrored at both cuts; tests/test_distributed.py, stand_in_system, writes that matrix out and checks the solve
+// against the oracle): a different linear system with the same work per iteration. Timing, and that test.
 extern "C" SpmvAmdCgSlab* spmv_amd_cg_slab_create_stencil5_as(int n, int as_rank, int as_world, SpmvAmdComm* comm) {
     if (comm == nullptr || comm->world != 1 || (as_world > 1 && !comm->self_neighbour)) {
         fprintf(stderr, "[cg-slab] a stand-in slab needs a single-rank self-neighbour communicator\n");
@@ -761,6 +837,7 @@ extern "C" SpmvAmdCgSlab* spmv_amd_cg_slab_create_stencil5_as(int n, int as_rank
     if (as_world < 1 || as_rank < 0 || as_rank >= as_world) return nullptr;
     return create_stencil5_slab(n, as_rank, as_world, comm);
 }
+#endif  // SPMV_AMD_LAB
 
 extern "C" int spmv_amd_cg_slab_set_vectors(SpmvAmdCgSlab* s, const double* b_full,
                                             const double* x0_full) {
@@ -769,22 +846,134 @@ extern "C" int spmv_amd_cg_slab_set_vectors(SpmvAmdCgSlab* s, const double* b_fu
     return 0;
 }
 
-extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* config,
-                                      CGStatsMultiGPU* stats) {
+// ---------------------------------------------------------------------------------------
+// One solve. The loop has TWO shapes, fixed per solve (LoopShape): the pipeline and the plain order; an iteration is the
+// same five stages in both -- SpMV (+ p.Ap sum) | all-reduce | r update | r.r sum (+ all-reduce) + scalar step | direction
+// update + halo exchange -- and each stage is one function below. What a stage enqueues depends on the shape only.
+// ---------------------------------------------------------------------------------------
+namespace {
+
+struct LoopShape {
+    bool multi = false;      // halo exchange needed
+    bool reduce = false;     // all-reduce of the dot products needed
+    bool separate = false;   // ... as a call of its own (RCCL / staged); false: inside the sums' last stage (peer mailbox) or not at all
+    const PeerMailbox* mailbox = nullptr;
+    bool detail = false;     // the reference's per-category timers: a host sync per stage, everything on the compute stream
+    bool overlap = false;    // PIPELINE: exchange on the side stream under the interior rows; false = PLAIN: on the compute stream
+    // pipeline only: the rows the neighbours wait for, the first piece of the rest and (RCCL path) the scalar step in ONE
+    // launch, the exchange released by that launch's device flag
+    bool fused_direction = false;
+    bool late = false;       // direction update as lead piece + rest (late bulk)
+    int slots = 1;           // direction ring length; 1 = the in-place x / p update
+    EdgeRows edges{0, 0, 0}; // fused_direction: [0, count_a) and [second, second + count_b)
+    size_t bulk_lo = 0, bulk_hi = 0;  // the rows of the direction update that are not edge rows
+};
+
+
+LoopShape loop_shape(const SpmvAmdCgSlab* s, const CGConfigMultiGPU* config) {
+    LoopShape L;
+    const SpmvAmdComm* comm = s->comm;
     const size_t nl = (size_t)s->n_local;
-    const size_t vbytes = nl * sizeof(double);
-    const bool detail = config->enable_detailed_timers != 0;
-    const int* skip = &s->d_s->converged;
-    SpmvAmdComm* comm = s->comm;
-    const bool multi = comm->exchanges_halos();  // halo exchange needed
-    const bool reduce = comm->collective();   // all-reduce of the dot products needed
-    // with a peer mailbox the all-reduce happens inside the reductions' last stage; `separate` = it needs a call of its own
-    const PeerMailbox* mailbox = (reduce && comm->mailbox_ready()) ? comm->d_mailbox : nullptr;
-    const bool separate = reduce && mailbox == nullptr;
+    L.multi = comm->exchanges_halos();
+    L.reduce = comm->collective();
+    L.mailbox = (L.reduce && comm->mailbox_ready()) ? comm->d_mailbox : nullptr;
+    L.separate = L.reduce && L.mailbox == nullptr;
+    L.detail = config->enable_detailed_timers != 0;
+    L.overlap = L.multi && !L.detail && !s->no_overlap;
+    L.slots = s->ring_slots;
+    // (ring mode only: with the in-place form the x update of the converging iteration rides in that very launch)
+    L.late = s->late_bulk && !L.detail && L.slots > 1;
+    // Early halo (round 3): the two edge ranges are rounded OUTWARDS to 4 KiB (512 doubles), so that the launch over the rest
+    // starts on a 4 KiB boundary like every whole-vector launch does: with the ranges cut exactly at the grid row, the rest of a
+    // 15 000-column slab started 64 bytes off a 128-byte line and its direction update ran 20-30 % slower (485 vs 386 us at
+    // 112.5 M rows; at 20 000 columns, 128-byte but not 4 KiB aligned, 8 %). A few rows beyond the grid row updated early is harmless.
+    constexpr size_t kAlign = 512;
+    const size_t head_rows = s->has_prev ? ((size_t)s->halo + kAlign - 1) / kAlign * kAlign : 0;
+    const size_t tail_start = s->has_next ? (nl - (size_t)s->halo) / kAlign * kAlign : nl;
+    L.fused_direction = L.overlap && L.slots > 1 && s->reduce_stage != nullptr && (nl % 2) == 0 &&
+                        nl >= 4 * (size_t)s->halo + 4 * kAlign && head_rows < tail_start;
+    if (L.fused_direction) {
+        L.edges = EdgeRows{head_rows, tail_start, nl - tail_start};
+        L.bulk_lo = head_rows, L.bulk_hi = tail_start;
+    } else {
+        L.bulk_lo = 0, L.bulk_hi = nl;
+    }
+    return L;
+}
+
+// State of one solve in flight: what the stages share.
+struct SolveRun {
+    SpmvAmdCgSlab* s;
+    const CGConfigMultiGPU* config;
+    CGStatsMultiGPU* stats;
+    const LoopShape L;
+    const TraceRanges trace;
+    EventTimer total, part;
+    const size_t nl;
+    const int* skip;
+    const bool timeline;
+    RingSlots ring_view;
+    int window_start = 0;       // first iteration whose alpha_k p_k is not in x yet (ring mode)
+    int tl_exchanges = 0;       // halo exchanges marked on the side stream (exchange j precedes the SpMV of iteration j)
+    bool halo_in_flight = false;
+    bool step_in_direction = false;  // this iteration's scalar step rides in the direction update's launch
+    bool status_known = false;
+    bool backward = false;      // sweep direction of this iteration's SpMV and direction update (the r update walks the other way)
+    int enqueued = 0, sampled = 0;
+    std::vector<int> sampled_iteration;  // 0-based loop index of each timed SpMV
+
+    SolveRun(SpmvAmdCgSlab* slab, const CGConfigMultiGPU* cfg, CGStatsMultiGPU* st)
+        : s(slab), config(cfg), stats(st), L(loop_shape(slab, cfg)), trace(L.detail || slab->roctx_always), nl((size_t)slab->n_local),
+          skip(&slab->d_s->converged), timeline(slab->timeline_on && !L.detail) {
+        for (int k = 0; k < kMaxRingSlots; ++k) ring_view.p[k] = s->ring[(size_t)k % s->ring.size()];
+    }
+
+    // detailed timers (the reference's, :770-800): a stage between two events and a host sync; otherwise just the stage
+    template <class Work>
+    void timed(double* bucket, double* bucket2, Work&& work) {
+        if (!L.detail) {
+            work();
+            return;
+        }
+        part.begin(s->compute);
+        work();
+        part.end(s->compute);
+        WatchdogScope guard("detailed timers: waiting for the stage just enqueued", s->comm->rank, s->enqueued_iteration, report_slab_state, s);
+        const double ms = part.elapsed_ms();
+        if (bucket) *bucket += ms;
+        if (bucket2) *bucket2 += ms;
+    }
+    static hipEvent_t tl_event(std::vector<hipEvent_t>& pool, size_t index) {
+        while (pool.size() <= index) {
+            hipEvent_t e;
+            HIP_CHECK(hipEventCreate(&e));
+            pool.push_back(e);
+        }
+        return pool[index];
+    }
+    // compute-stream marks: [0] solve start, [1] initial residual done, then kTimelineMarks per iteration, then the flush
+    size_t mark_index(int iteration, int k) const { return 2 + (size_t)iteration * kTimelineMarks + k; }
+    void mark(int iteration, int k) {
+        if (timeline) HIP_CHECK(hipEventRecord(tl_event(s->tl_compute, mark_index(iteration, k)), s->compute));
+    }
+
+    void begin();
+    void initial_residual();
+    void start_halo(double* v, bool released_by_flag);
+    void stage_spmv();
+    void stage_allreduce_pAp();
+    void stage_update_r();
+    void stage_sum_rr_and_step();
+    void stage_direction_and_halo();
+    bool read_status();
+    void finish();
+    void resolve_timeline(const CgScalars& fin, float total_ms);
+};
+
+void SolveRun::begin() {
     s->reduce_mailbox = nullptr;  // the initial SpMV has no dot product
     s->op_failed = false;
     memset(stats, 0, sizeof(*stats));
-
     // residual history: one slot per iteration, capped at 2^20 entries (later iterations go unrecorded)
     const int want_hist = config->max_iters < (1 << 20) ? config->max_iters + 1 : (1 << 20);
     if (s->hist_cap < want_hist) {
@@ -797,105 +986,78 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
     CgScalars init;
     memset(&init, 0, sizeof init);
     init.max_history = s->hist_cap;
+#ifdef SPMV_AMD_LAB
     init.stop_at = s->stop_at;
+#endif
     HIP_CHECK(hipMemcpyAsync(s->d_s, &init, sizeof init, hipMemcpyHostToDevice, s->compute));
-    // Every solve starts from the stored x0 (the reference benchmark wrapper restores x on the host
-    // before each run). x is not overwritten with x0 first: the initial SpMV reads x0 and the first
-    // x update computes x = x0 + alpha p.
+    // Every solve starts from the stored x0 (the reference benchmark wrapper restores x on the host before each run). x is not
+    // overwritten with x0 first: the initial SpMV reads x0 and the first x update computes x = x0 + alpha p.
     HIP_CHECK(hipStreamSynchronize(s->compute));
-
-    // the reference's NVTX ranges (:540-717) as roctx ranges, when detailed timers (or SPMV_AMD_ROCTX=1) ask for them
-    const TraceRanges trace(detail || s->roctx_always);
-    TraceScope solver_range(trace, "CG_Solver");
-    EventTimer total, part;
-    auto timed = [&](double* bucket, double* bucket2, auto&& work) {
-        if (!detail) {
-            work();
-            return;
-        }
-        part.begin(s->compute);
-        work();
-        part.end(s->compute);
-        WatchdogScope guard("detailed timers: waiting for the stage just enqueued", comm->rank, s->enqueued_iteration,
-                            report_slab_state, s);
-        const double ms = part.elapsed_ms();
-        if (bucket) *bucket += ms;
-        if (bucket2) *bucket2 += ms;
-    };
-
-    // timeline: stage-boundary events, no host sync (spmv_amd_cg_slab_set_timeline); `detail` has its own per-stage syncs
-    const bool timeline = s->timeline_on && !detail;
     s->timeline_us.clear();
-    auto tl_event = [](std::vector<hipEvent_t>& pool, size_t index) {
-        while (pool.size() <= index) {
-            hipEvent_t e;
-            HIP_CHECK(hipEventCreate(&e));
-            pool.push_back(e);
-        }
-        return pool[index];
-    };
-    // compute-stream marks: [0] solve start, [1] initial residual done, then kTimelineMarks per iteration, then the flush
-    auto mark = [&](int iteration, int k) {
-        if (timeline) HIP_CHECK(hipEventRecord(tl_event(s->tl_compute, 2 + (size_t)iteration * kTimelineMarks + k), s->compute));
-    };
-    int tl_exchanges = 0;  // halo exchanges marked on the side stream (exchange j precedes the SpMV of iteration j)
-
     s->p = s->ring[0];
-    const int slots = s->ring_slots;
-    RingSlots ring_view;
-    for (int k = 0; k < kMaxRingSlots; ++k) ring_view.p[k] = s->ring[(size_t)k % s->ring.size()];
-    int window_start = 0;  // first iteration whose alpha_k p_k is not in x yet (ring mode)
-
     s->enqueued_stage = "barrier before the timed region";
     s->enqueued_iteration = -1;
     {
-        WatchdogScope guard("barrier before the timed region", comm->rank, -1, report_slab_state, s);
-        comm->barrier(s->compute);
+        WatchdogScope guard("barrier before the timed region", s->comm->rank, -1, report_slab_state, s);
+        s->comm->barrier(s->compute);
     }
     total.begin(s->compute);
     if (timeline) HIP_CHECK(hipEventRecord(tl_event(s->tl_compute, 0), s->compute));
+}
 
-    // ---- r0 = b - A x0 ; p0 = r0 ; rr0 ----
-    // x0 is read where it lies: its allocation carries the halo rows the first / last grid row need
-    // (its halo rows travel like p's: on the side stream, under the interior rows, so that the point-to-point
-    // communicator is driven from one stream only; with detailed timers everything runs on the compute stream)
-    bool x0_halo_on_side = false;
-    if (multi) {
-        if (detail || s->no_overlap) {
-            timed(&stats->time_allgather_ms, nullptr, [&] { exchange_halo(s, s->x0, s->compute); });
-        } else {
-            HIP_CHECK(hipEventRecord(s->ev_p_ready, s->compute));
-            HIP_CHECK(hipStreamWaitEvent(s->side, s->ev_p_ready, 0));
-            exchange_halo(s, s->x0, s->side);
-            launch_halo_arrived(s->d_halo_flag, ++s->halo_sequence, s->side);
-            HIP_CHECK(hipEventRecord(s->ev_halo_done, s->side));
-            x0_halo_on_side = true;
-        }
+// Halo rows of the halo-carrying vector v to / from the neighbours. PIPELINE: on the side stream, behind the rows to send --
+// released by the direction launch's device flag (released_by_flag: the edge rows were written through by that launch's first
+// workgroups; no event on the compute stream, and not as late as the launch's end) or by an event (x0's rows at the start of
+// a solve) -- and followed by the arrival flag the boundary waves wait for and the event everything else waits for.
+// PLAIN: on the compute stream, in order.
+void SolveRun::start_halo(double* v, bool released_by_flag) {
+    if (!L.multi) return;
+    if (!L.overlap) {
+        timed(&stats->time_allgather_ms, nullptr, [&] { exchange_halo(s, v, s->compute); });
+        halo_in_flight = false;
+        return;
     }
+    if (released_by_flag) {
+        launch_edges_wait(s->scratch(), s->poll_sequence, (long long)(halo_wait_limit_s(s) * 1e8), &s->h_poll->halo_late, s->side);
+    } else {
+        HIP_CHECK(hipEventRecord(s->ev_p_ready, s->compute));
+        HIP_CHECK(hipStreamWaitEvent(s->side, s->ev_p_ready, 0));
+    }
+    const bool in_loop = v != s->x0;
+    if (timeline && in_loop) HIP_CHECK(hipEventRecord(tl_event(s->tl_side, 2 * (size_t)tl_exchanges), s->side));
+    exchange_halo(s, v, s->side);
+    ++s->halo_sequence;
+#ifdef SPMV_AMD_LAB
+    if (s->test_wedge_overlapped_exchange != 4)  // fault injection: an arrival flag that never comes
+#endif
+        launch_halo_arrived(s->d_halo_flag, s->halo_sequence, s->side);
+    if (timeline && in_loop) HIP_CHECK(hipEventRecord(tl_event(s->tl_side, 2 * (size_t)tl_exchanges++ + 1), s->side));
+    HIP_CHECK(hipEventRecord(s->ev_halo_done, s->side));
+    halo_in_flight = true;
+}
+
+// ---- r0 = b - A x0 ; p0 = r0 ; rr0 ----
+// x0 is read where it lies: its allocation carries the halo rows the first / last grid row need (its halo rows travel like
+// p's, so that the point-to-point communicator is driven from one stream only).
+void SolveRun::initial_residual() {
+    start_halo(s->x0, /*released_by_flag=*/false);
     if (s->fuse_init_residual) {
         // row-lds slabs: r0 = b - A x0, p0 = r0 and the r0.r0 partials come out of the SpMV launch itself (A x0 is
         // never written out and read back: 16 B/row less, once per solve)
         const ResidualOut init{s->b, s->r, s->p};
         int used = 0;
-        timed(&stats->time_initial_r_ms, nullptr, [&] {
-            used = slab_spmv(s, /*with_dot=*/false, /*overlap=*/x0_halo_on_side, nullptr, s->x0, nullptr, &init);
-        });
-        timed(&stats->time_dot_rs_initial_ms, nullptr, [&] {
-            reduce_spmv_partials(s, used, &s->d_s->rr_new, nullptr, nullptr, 0, mailbox);
-        });
+        timed(&stats->time_initial_r_ms, nullptr, [&] { used = slab_spmv(s, /*with_dot=*/false, halo_in_flight, nullptr, s->x0, nullptr, &init); });
+        timed(&stats->time_dot_rs_initial_ms, nullptr, [&] { reduce_spmv_partials(s, used, &s->d_s->rr_new, nullptr, nullptr, 0, L.mailbox); });
     } else {
-        slab_spmv(s, /*with_dot=*/false, /*overlap=*/x0_halo_on_side, nullptr, s->x0);
-        timed(&stats->time_initial_r_ms, nullptr, [&] {
-            launch_cg_init_residual(nl, s->b, s->Ap, s->r, s->p, s->partials_blas, s->compute);
-        });
+        slab_spmv(s, /*with_dot=*/false, halo_in_flight, nullptr, s->x0);
+        timed(&stats->time_initial_r_ms, nullptr, [&] { launch_cg_init_residual(nl, s->b, s->Ap, s->r, s->p, s->partials_blas, s->compute); });
         timed(&stats->time_dot_rs_initial_ms, nullptr, [&] {
-            launch_reduce_partials(s->partials_blas, cg_partial_count(nl), &s->d_s->rr_new, nullptr, s->compute, s->scratch(),
-                                   nullptr, 0, mailbox);
+            launch_reduce_partials(s->partials_blas, cg_partial_count(nl), &s->d_s->rr_new, nullptr, s->compute, s->scratch(), nullptr, 0, L.mailbox);
         });
     }
     s->enqueued_stage = "initial residual";
-    if (separate) allreduce_scalar(s, &s->d_s->rr_new, "all-reduce of the initial r.r");
-    s->reduce_mailbox = s->fused_dot ? mailbox : nullptr;  // the in-loop SpMVs' p.Ap reduction
+    if (L.separate) allreduce_scalar(s, &s->d_s->rr_new, "all-reduce of the initial r.r");
+    s->reduce_mailbox = s->fused_dot ? L.mailbox : nullptr;  // the in-loop SpMVs' p.Ap reduction
     launch_cg_scalars_init(s->d_s, s->d_hist, s->compute);
     if (timeline) HIP_CHECK(hipEventRecord(tl_event(s->tl_compute, 1), s->compute));
     if (s->label && config->verbose >= 1) {  // the reference prints ||r0|| before its loop (cg_solver.cu:529-531); verbose runs only
@@ -904,310 +1066,253 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
         HIP_CHECK(hipMemcpy(&now, s->d_s, sizeof now, hipMemcpyDeviceToHost));
         printf("[%s] Initial residual: %e\n", s->label, now.b_norm);
     }
-    bool halo_in_flight = false;
-    // edges_by_flag (round 5): the rows to send were written by the first workgroups of the direction update's launch, which raise
-    // a device flag once the rows have reached memory; the side stream waits for that flag with a one-thread launch instead of
-    // for an event recorded on the compute stream (a barrier packet per iteration, and too late: the launch's end).
-    bool edges_by_flag = false;
-    auto start_p_halo = [&] {  // halo rows of the new p: side stream, under the interior SpMV
-        if (!multi) return;
-        // SPMV_AMD_NO_OVERLAP=1: exchange on the compute stream, for A/B runs of the overlap
-        if (detail || s->no_overlap) {
-            timed(&stats->time_allgather_ms, nullptr, [&] { exchange_p_halo(s, s->compute); });
-            halo_in_flight = false;
-            return;
-        }
-        if (edges_by_flag) {
-            const double limit_s = watchdog_limit_seconds() > 0.0 && watchdog_limit_seconds() < 40.0 ? 0.5 * watchdog_limit_seconds() : 20.0;
-            launch_edges_wait(s->scratch(), s->poll_sequence, (long long)(limit_s * 1e8), &s->h_poll->halo_late, s->side);
-        } else {
-            HIP_CHECK(hipEventRecord(s->ev_p_ready, s->compute));
-            HIP_CHECK(hipStreamWaitEvent(s->side, s->ev_p_ready, 0));
-        }
-        if (timeline) HIP_CHECK(hipEventRecord(tl_event(s->tl_side, 2 * (size_t)tl_exchanges), s->side));
-        exchange_p_halo(s, s->side);
-        launch_halo_arrived(s->d_halo_flag, ++s->halo_sequence, s->side);
-        if (timeline) HIP_CHECK(hipEventRecord(tl_event(s->tl_side, 2 * (size_t)tl_exchanges + 1), s->side));
-        if (timeline) ++tl_exchanges;
-        HIP_CHECK(hipEventRecord(s->ev_halo_done, s->side));
-        halo_in_flight = true;
-    };
-    start_p_halo();
+    start_halo(s->p, /*released_by_flag=*/false);  // halo rows of p0: under the first interior SpMV
+}
 
-    // ---- iterations ----
-    double* const r_cur = s->r;
-    // (ring mode only: with the in-place form the x update of the converging iteration rides in that very launch)
-    const bool late = s->late_bulk && !detail && slots > 1;
-    int enqueued = 0, sampled = 0;
-    std::vector<int> sampled_iteration;  // 0-based loop index of each timed SpMV
-    bool done = false;
-    while (!done && !s->op_failed && enqueued < config->max_iters) {
-        // SpMV and x/p update of iteration k walk one way, the r update between them the other way; the
-        // direction flips every iteration, so every kernel starts where the previous one ended
-        const bool backward = s->pingpong && (enqueued & 1) == 0;  // iteration 0 follows the forward initial-residual pass
-        s->shape.reverse = backward;
-        TraceScope iteration_range(trace, "CG_Iteration");
-        s->enqueued_iteration = enqueued;
-        s->enqueued_stage = "SpMV";
-        trace.push("SpMV");
-        s->spmv_progress = &s->h_poll->progress;
-        s->spmv_progress_value = 4 * (s->poll_sequence + 1) + 1;
-        mark(enqueued, 0);
-        s->tl_after_interior = timeline ? tl_event(s->tl_compute, 2 + (size_t)enqueued * kTimelineMarks + 1) : nullptr;
-        if (timeline) {
-            // [1] is recorded inside slab_spmv behind the interior launch, [2] here behind the boundary rows;
-            // the reduction of the partials is issued by slab_spmv too, so [3] follows directly
-            slab_spmv(s, true, halo_in_flight, skip, nullptr, tl_event(s->tl_compute, 2 + (size_t)enqueued * kTimelineMarks + 2));
-            s->tl_after_interior = nullptr;
-        } else if (detail) {
-            timed(&stats->time_spmv_ms, nullptr, [&] { slab_spmv(s, true, halo_in_flight, skip); });
-        } else {
-            const bool sample = s->spmv_event_stride > 0 && (enqueued + s->spmv_event_phase) % s->spmv_event_stride == 0;
-            if (sample) {
-                while (s->spmv_ev.size() < 2 * (size_t)(sampled + 1)) {
-                    hipEvent_t e;
-                    HIP_CHECK(hipEventCreate(&e));
-                    s->spmv_ev.push_back(e);
-                }
-                HIP_CHECK(hipEventRecord(s->spmv_ev[2 * sampled], s->compute));
-                slab_spmv(s, true, halo_in_flight, skip, nullptr, s->spmv_ev[2 * sampled + 1]);
-                sampled_iteration.push_back(enqueued);
-                ++sampled;
-            } else {
-                slab_spmv(s, true, halo_in_flight, skip);
-            }
+// Stage 1: Ap = A p with the p.Ap partials and their sum (slab_spmv: interior rows | boundary rows + sum on a split slab).
+void SolveRun::stage_spmv() {
+    // SpMV and direction update of iteration k walk one way, the r update between them the other way; the direction flips
+    // every iteration, so every kernel starts where the previous one ended (iteration 0 follows the forward initial pass)
+    backward = (enqueued & 1) == 0;
+    s->shape.reverse = backward;
+    s->enqueued_iteration = enqueued;
+    s->enqueued_stage = "SpMV";
+    TraceScope range(trace, "SpMV");
+    s->spmv_progress = &s->h_poll->progress;
+    s->spmv_progress_value = 4 * (s->poll_sequence + 1) + 1;
+    mark(enqueued, 0);
+    if (timeline) {
+        // [1] is recorded inside slab_spmv behind the interior launch, [2] behind the boundary rows; the reduction of the
+        // partials is issued by slab_spmv too, so [3] follows directly
+        s->tl_after_interior = tl_event(s->tl_compute, mark_index(enqueued, 1));
+        slab_spmv(s, true, halo_in_flight, skip, nullptr, tl_event(s->tl_compute, mark_index(enqueued, 2)));
+        s->tl_after_interior = nullptr;
+    } else if (L.detail) {
+        timed(&stats->time_spmv_ms, nullptr, [&] { slab_spmv(s, true, halo_in_flight, skip); });
+    } else if (s->spmv_event_stride > 0 && (enqueued + s->spmv_event_phase) % s->spmv_event_stride == 0) {
+        while (s->spmv_ev.size() < 2 * (size_t)(sampled + 1)) {
+            hipEvent_t e;
+            HIP_CHECK(hipEventCreate(&e));
+            s->spmv_ev.push_back(e);
         }
-        trace.pop();
-        s->spmv_progress = nullptr;
-        if (s->op_failed) break;  // nothing of this iteration is awaited yet: the status record's sequence is advanced below
-        s->enqueued_stage = "all-reduce of p.Ap";
-        if (separate || (reduce && !s->fused_dot)) {
-            TraceScope r(trace, "AllReduce");
-            timed(&stats->time_allreduce_ms, nullptr, [&] { allreduce_scalar(s, &s->d_s->pAp, "all-reduce of p.Ap"); });
-        }
-        mark(enqueued, 3);
-        s->enqueued_stage = "r update";
-        trace.push("BLAS_AXPY");
-        timed(&stats->time_blas1_ms, &stats->time_axpy_update_r_ms, [&] {
-            launch_cg_update_r(nl, s->d_s, s->Ap, r_cur, s->partials_blas, s->compute, s->pingpong && !backward);
+        HIP_CHECK(hipEventRecord(s->spmv_ev[2 * sampled], s->compute));
+        slab_spmv(s, true, halo_in_flight, skip, nullptr, s->spmv_ev[2 * sampled + 1]);
+        sampled_iteration.push_back(enqueued);
+        ++sampled;
+    } else {
+        slab_spmv(s, true, halo_in_flight, skip);
+    }
+    s->spmv_progress = nullptr;
+}
+
+// Stage 2 (only where the sum is not completed across the ranks inside the reduction's launch).
+void SolveRun::stage_allreduce_pAp() {
+    s->enqueued_stage = "all-reduce of p.Ap";
+    if (L.separate || (L.reduce && !s->fused_dot)) {
+        TraceScope r(trace, "AllReduce");
+        timed(&stats->time_allreduce_ms, nullptr, [&] { allreduce_scalar(s, &s->d_s->pAp, "all-reduce of p.Ap"); });
+    }
+    mark(enqueued, 3);
+}
+
+// Stage 3: r -= alpha Ap with the r.r partials (alpha = rr_old / pAp in every thread).
+void SolveRun::stage_update_r() {
+    s->enqueued_stage = "r update";
+    TraceScope range(trace, "BLAS_AXPY");
+    timed(&stats->time_blas1_ms, &stats->time_axpy_update_r_ms,
+          [&] { launch_cg_update_r(nl, s->d_s, s->Ap, s->r, s->partials_blas, s->compute, !backward); });
+    mark(enqueued, 4);
+}
+
+// Stage 4: sum of the r.r partials, across the ranks, and the scalar step (residual, history, verdict, beta, alpha into the
+// ring's slot, status record into host-coherent memory). One launch without a separate all-reduce; with one (RCCL) the
+// step follows the all-reduce -- as a launch of its own, or inside the direction update's launch (fused_direction), except in
+// the iteration whose new direction re-uses a slot the pending x flush still has to read: the flush needs this step's alpha
+// and must run before the slot is overwritten.
+void SolveRun::stage_sum_rr_and_step() {
+    step_in_direction = L.fused_direction && L.separate && (enqueued + 1) - window_start < L.slots;
+    ++s->poll_sequence;
+    TraceScope range(trace, "Dot_Product");
+    if (L.separate) {
+        timed(&stats->time_reductions_ms, &stats->time_dot_rs_new_ms, [&] {
+            launch_reduce_partials(s->partials_blas, cg_partial_count(nl), &s->d_s->rr_new, skip, s->compute, s->scratch(), &s->h_poll->progress,
+                                   4 * s->poll_sequence + 2);
         });
-        trace.pop();
-        mark(enqueued, 4);
-        // the scalar step publishes {sequence, converged, iterations} straight into host-coherent pinned
-        // memory: no copy command sits between it and the p update on the stream. Without an all-reduce
-        // between the sum and the step, the step runs in the tail of the reduction's launch.
-        // p <- r + beta p, its halo exchange, and (when overlapping) nothing else before the host
-        // looks at the status: the GPU works on these while the host waits for the record.
-        // Early halo (round 3): the rows the neighbours need -- the slab's first / last grid row -- are updated by two
-        // small launches FIRST and the halo exchange starts behind them, so that it runs under the rest of the direction
-        // update as well as under the interior SpMV. Measured on the P = 8 middle slab (50 M rows) before this change: the
-        // RCCL send / recv kernel, started together with a SpMV that fills every CU, took as long as that SpMV (480 us) and
-        // the boundary rows waited ~25 us per iteration for it (profiles/r03_slab_timeline_*.txt). Same kernels, same
-        // per-element arithmetic, disjoint row ranges: results cannot change.
-        // The two early ranges are rounded OUTWARDS to 4 KiB (512 doubles), so that the launch over the rest starts on a 4 KiB
-        // boundary like every whole-vector launch does: with the ranges cut exactly at the grid row, the rest of a 15 000-column
-        // slab started 64 bytes off a 128-byte line and its direction update ran 20-30 % slower (485 vs 386 us at 112.5 M rows;
-        // at 20 000 columns, 128-byte but not 4 KiB aligned, 8 %). A few rows beyond the grid row being updated early is harmless.
-        constexpr size_t kAlign = 512;
-        const size_t head_rows = s->has_prev ? ((size_t)s->halo + kAlign - 1) / kAlign * kAlign : 0;
-        const size_t tail_start = s->has_next ? (nl - (size_t)s->halo) / kAlign * kAlign : nl;
-        const size_t tail_rows = nl - tail_start;
-        const bool early_halo = multi && !detail && !s->no_overlap && s->early_halo && (nl % 2) == 0 && nl >= 4 * (size_t)s->halo + 4 * kAlign &&
-                                head_rows < tail_start;
-        // Round 5: the rows the neighbours need, the first piece of the rest and -- on the RCCL path, where the scalar step is not
-        // part of the r.r sum's launch -- the step itself share ONE launch (kernels.hpp, DirectionLaunch): its first workgroups
-        // take the edge rows, write them through and raise the flag the side stream's exchange waits for; nobody waits for the
-        // step. Ring mode. The step stays a launch of its own in the iteration whose new direction re-uses a slot the pending
-        // x flush still has to read (the flush needs that step's alpha and must run before the slot is overwritten).
-        const int next_iteration = enqueued + 1;
-        const bool direction_fused = early_halo && s->edges_in_step && slots > 1 && s->scratch().base != nullptr;
-        bool step_in_direction = direction_fused && separate && next_iteration - window_start < slots;
-        const EdgeRows edge_rows{head_rows, tail_start, tail_rows};
-        ++s->poll_sequence;
-        trace.push("Dot_Product");
-        if (separate) {
-            timed(&stats->time_reductions_ms, &stats->time_dot_rs_new_ms, [&] {
-                launch_reduce_partials(s->partials_blas, cg_partial_count(nl), &s->d_s->rr_new, skip, s->compute, s->scratch(),
-                                       &s->h_poll->progress, 4 * s->poll_sequence + 2);
-            });
-            s->enqueued_stage = "all-reduce of r.r";
-            {
-                TraceScope r(trace, "AllReduce");
-                timed(&stats->time_allreduce_ms, nullptr, [&] { allreduce_scalar(s, &s->d_s->rr_new, "all-reduce of r.r"); });
-            }
-            if (!step_in_direction)  // else: inside the direction update's first launch, further down
-                launch_cg_scalars_step(s->d_s, config->tolerance, s->d_hist, &s->h_poll->sequence, s->poll_sequence,
-                                       s->compute, s->d_alpha_ring, slots);
-        } else {
-            timed(&stats->time_reductions_ms, &stats->time_dot_rs_new_ms, [&] {
-                // single rank, or mailbox: sum (completed across the ranks in place) and scalar step in one launch
-                launch_reduce_partials_and_step(s->partials_blas, cg_partial_count(nl), &s->d_s->rr_new, skip, s->compute,
-                                                s->scratch(), s->d_s, config->tolerance, s->d_hist,
-                                                &s->h_poll->sequence, s->poll_sequence, s->d_alpha_ring, slots, mailbox,
-                                                &s->h_poll->progress, 4 * s->poll_sequence + 2);
-            });
+        s->enqueued_stage = "all-reduce of r.r";
+        {
+            TraceScope r(trace, "AllReduce");
+            timed(&stats->time_allreduce_ms, nullptr, [&] { allreduce_scalar(s, &s->d_s->rr_new, "all-reduce of r.r"); });
         }
-        trace.pop();
-        mark(enqueued, 5);
-        ++enqueued;
-        trace.push("BLAS_AXPBY");
+        if (!step_in_direction)
+            launch_cg_scalars_step(s->d_s, config->tolerance, s->d_hist, &s->h_poll->sequence, s->poll_sequence, s->compute, s->d_alpha_ring, L.slots);
+    } else {
+        timed(&stats->time_reductions_ms, &stats->time_dot_rs_new_ms, [&] {
+            launch_reduce_partials_and_step(s->partials_blas, cg_partial_count(nl), &s->d_s->rr_new, skip, s->compute, s->scratch(), s->d_s,
+                                            config->tolerance, s->d_hist, &s->h_poll->sequence, s->poll_sequence, s->d_alpha_ring, L.slots, L.mailbox,
+                                            &s->h_poll->progress, 4 * s->poll_sequence + 2);
+        });
+    }
+    mark(enqueued, 5);
+    ++enqueued;  // from here on `enqueued` is the number of the iteration just stepped (1-based), as the kernels count
+}
 
-        // The bulk of the update over rows [lo, hi), lo on a 4 KiB boundary. Late bulk: the piece the sweep walks first, then
-        // the status record, then -- unless the iteration converged -- the rest; the lead piece keeps the GPU busy while
-        // the host reads the record and launches.
-        bool status_known = false;
-        auto bulk = [&](auto&& update, size_t lo, size_t hi) {
-            if (!late || hi - lo < 4 * s->lead_rows) {
-                update(lo, hi - lo, backward);
-                return;
-            }
-            const size_t cut = backward ? (hi - s->lead_rows) / kAlign * kAlign : lo + s->lead_rows;
-            if (backward)
-                update(cut, hi - cut, true);
-            else
-                update(lo, cut - lo, false);
+// Stage 5: p <- r + beta p and its halo exchange; nothing else before the host looks at the status: the GPU works on these
+// while the host waits for the record. Late bulk: the piece the sweep walks first, then the status record, then -- unless the
+// iteration converged -- the rest; the lead piece keeps the GPU busy while the host reads the record and launches.
+void SolveRun::stage_direction_and_halo() {
+    trace.push("BLAS_AXPBY");
+    status_known = false;
+    const size_t lo = L.bulk_lo, hi = L.bulk_hi;
+    const bool two_pieces = L.late && hi - lo >= 4 * s->lead_rows;
+    const size_t cut = !two_pieces ? (backward ? lo : hi) : backward ? (hi - s->lead_rows) / 512 * 512 : lo + s->lead_rows;
+    // first piece: [cut, hi) walking backward, [lo, cut) walking forward; the rest is the other side of the cut
+    const size_t first_lo = backward ? cut : lo, first_rows = backward ? hi - cut : cut - lo;
+    const size_t rest_lo = backward ? lo : cut, rest_rows = backward ? cut - lo : hi - cut;
+    auto pieces = [&](auto&& first, auto&& rest) {
+        timed(&stats->time_blas1_ms, &stats->time_axpby_update_p_ms, [&] {
+            first(first_lo, first_rows);
+            if (!two_pieces) return;
             s->enqueued_stage = "direction update (lead piece)";
             wait_for_status(s);
             status_known = true;
-            if (s->h_poll->converged) return;  // the loop ends here: nothing reads the rest of this direction
-            if (backward)
-                update(lo, cut - lo, true);
-            else
-                update(cut, hi - cut, false);
+            if (!s->h_poll->converged) rest(rest_lo, rest_rows);  // else the loop ends here: nothing reads the rest of this direction
+        });
+    };
+    if (L.slots == 1) {  // in-place form: x += alpha p rides with the direction update
+        const double* x_in = enqueued == 1 ? s->x0 : s->x;
+        auto px = [&](size_t off, size_t count) {
+            if (count > 0) launch_cg_update_px(count, s->d_s, s->r + off, s->p + off, x_in + off, s->x + off, enqueued, s->compute, backward, s->device_form);
         };
-        if (slots == 1) {
-            const double* x_in = enqueued == 1 ? s->x0 : s->x;
-            auto px = [&](size_t off, size_t count, bool reverse) {
-                if (count > 0)
-                    launch_cg_update_px(count, s->d_s, r_cur + off, s->p + off, x_in + off, s->x + off, enqueued, s->compute, reverse, s->device_form);
-            };
-            timed(&stats->time_blas1_ms, &stats->time_axpby_update_p_ms, [&] {
-                if (early_halo) {
-                    if (head_rows > 0 && tail_rows > 0)  // a rank with two neighbours: both grid rows in one launch
-                        launch_cg_update_px_two_ranges(head_rows, tail_start, tail_rows, s->d_s, r_cur, s->p, x_in, s->x, enqueued, s->compute, s->device_form);
-                    else
-                        px(0, head_rows, false), px(tail_start, tail_rows, false);
-                    trace.pop();
-                    {
-                        TraceScope r(trace, "Halo_Exchange");
-                        start_p_halo();
-                    }
-                    trace.push("BLAS_AXPBY");
-                    bulk(px, head_rows, tail_start);
-                } else {
-                    bulk(px, 0, nl);
-                }
+        pieces(px, px);
+    } else {
+        // the slot the new direction goes to still holds p of iteration enqueued - slots: fold the whole window into x first
+        // (alpha of this iteration is already on the stream: the step above wrote it)
+        if (enqueued - window_start == L.slots) {
+            timed(&stats->time_blas1_ms, nullptr, [&] {
+                launch_cg_flush_x(nl, s->d_alpha_ring, ring_view, L.slots, window_start % L.slots, L.slots, window_start == 0 ? s->x0 : s->x, s->x, s->compute);
             });
-        } else {
-            // the slot the new direction goes to still holds p of iteration enqueued - slots: fold the whole
-            // window into x first (alpha of this iteration is already on the stream: the step above wrote it)
-            if (enqueued - window_start == slots) {
-                timed(&stats->time_blas1_ms, nullptr, [&] {
-                    launch_cg_flush_x(nl, s->d_alpha_ring, ring_view, slots, window_start % slots, slots,
-                                      window_start == 0 ? s->x0 : s->x, s->x, s->compute);
-                });
-                window_start = enqueued;
+            window_start = enqueued;
+        }
+        double* p_next = s->ring[(size_t)(enqueued % L.slots)];
+        const double* p_in = s->p;
+        auto plain = [&](size_t off, size_t count) {
+            if (count > 0) launch_cg_update_p_ring(count, s->d_s, s->r + off, p_in + off, p_next + off, enqueued, s->compute, backward, s->device_form);
+        };
+        auto fused = [&](size_t off, size_t count) {
+            // the edge rows first (they raise the flag the exchange waits for), then this piece; the step too where it is due
+            launch_cg_direction(DirectionLaunch{s->d_s, config->tolerance, enqueued, s->d_hist, step_in_direction ? &s->h_poll->sequence : nullptr,
+                                                s->poll_sequence, s->d_alpha_ring, L.slots, s->r, p_in, p_next, off, count, backward, s->device_form},
+                                &L.edges, s->scratch(), s->compute);
+            s->p = p_next;  // the exchange sends from / receives into the new direction buffer
+            trace.pop();
+            {
+                TraceScope r(trace, "Halo_Exchange");
+                start_halo(s->p, /*released_by_flag=*/true);
             }
-            double* p_next = s->ring[(size_t)(enqueued % slots)];
-            const double* p_in = s->p;
-            bool first_piece = direction_fused;
-            auto ring_update = [&](size_t off, size_t count, bool reverse) {
-                if (first_piece) {
-                    // the edge rows first (they raise the flag the exchange waits for), then this piece; the step too where it is due
-                    first_piece = false;
-                    launch_cg_direction(DirectionLaunch{s->d_s, config->tolerance, enqueued, s->d_hist, step_in_direction ? &s->h_poll->sequence : nullptr,
-                                                        s->poll_sequence, s->d_alpha_ring, slots, r_cur, p_in, p_next, off, count, reverse, s->device_form},
-                                        &edge_rows, s->scratch(), s->compute);
-                    step_in_direction = false;
-                    s->p = p_next;
-                    edges_by_flag = true;
-                    trace.pop();
-                    {
-                        TraceScope r(trace, "Halo_Exchange");
-                        start_p_halo();
-                    }
-                    edges_by_flag = false;
-                    trace.push("BLAS_AXPBY");
-                } else if (count > 0) {
-                    launch_cg_update_p_ring(count, s->d_s, r_cur + off, p_in + off, p_next + off, enqueued, s->compute, reverse, s->device_form);
-                }
-            };
-            timed(&stats->time_blas1_ms, &stats->time_axpby_update_p_ms, [&] {
-                if (direction_fused) {
-                    bulk(ring_update, head_rows, tail_start);  // its first piece carries the edge rows (and the step) and starts the exchange
-                } else if (early_halo) {
-                    if (head_rows > 0 && tail_rows > 0)  // a rank with two neighbours: both grid rows in one launch
-                        launch_cg_update_p_ring_two_ranges(head_rows, tail_start, tail_rows, s->d_s, r_cur, p_in, p_next, enqueued, s->compute, s->device_form);
-                    else
-                        ring_update(0, head_rows, false), ring_update(tail_start, tail_rows, false);
-                    s->p = p_next;  // the exchange sends from / receives into the new direction buffer
-                    trace.pop();
-                    {
-                        TraceScope r(trace, "Halo_Exchange");
-                        start_p_halo();
-                    }
-                    trace.push("BLAS_AXPBY");
-                    bulk(ring_update, head_rows, tail_start);
-                } else {
-                    bulk(ring_update, 0, nl);
-                }
-            });
-            s->p = p_next;
-        }
-        trace.pop();
-        mark(enqueued - 1, 6);
-        s->enqueued_stage = "direction update and halo exchange";
-        if (!early_halo) {
-            TraceScope r(trace, "Halo_Exchange");
-            start_p_halo();
-        }
-        if (!status_known) wait_for_status(s);
-        mailbox_check(comm);
-        if (const int gave_up = __atomic_load_n(&s->h_poll->halo_late, __ATOMIC_ACQUIRE)) {
-            // worded like the host watchdog's report: bench.py's supervisors read that sentence and restart the ranks once without the overlap
-            fprintf(stderr, "\n[spmv_amd watchdog] rank %d: no progress for %.1f s in stage '%s' (CG iteration %d)\n", comm->rank,
-                    watchdog_limit_seconds() > 0.0 && watchdog_limit_seconds() < 40.0 ? 0.5 * watchdog_limit_seconds() : 20.0,
-                    gave_up == 3 ? "edge rows' ready flag (side-stream wait in front of the halo exchange)"
-                                 : "halo arrival flag (in-kernel wait of the boundary rows)",
-                    enqueued - 1);
-            report_slab_state(s, stderr);
-            exit(EXIT_FAILURE);
-        }
-        if (s->h_poll->converged) done = true;
-        if (config->verbose >= 2 && comm->rank == 0) {
-            CgScalars now;
-            HIP_CHECK(hipMemcpy(&now, s->d_s, sizeof now, hipMemcpyDeviceToHost));
-            if (s->label)  // cg_solve_device's line (reference cg_solver.cu:604-607)
-                printf("[%s] Iter %3d: residual = %e (rel = %e)\n", s->label, now.iterations, now.residual, now.residual / now.b_norm);
-            else
-                printf("[Iter %3d] Residual: %.6e (rel: %.6e, alpha: %.4e)\n", now.iterations, now.residual,
-                       now.residual / now.b_norm, now.alpha);
-        }
+            trace.push("BLAS_AXPBY");
+        };
+        if (L.fused_direction) pieces(fused, plain);
+        else pieces(plain, plain);
+        s->p = p_next;
     }
+    trace.pop();
+    mark(enqueued - 1, 6);
+    s->enqueued_stage = "direction update and halo exchange";
+    if (!L.fused_direction) {
+        TraceScope r(trace, "Halo_Exchange");
+        start_halo(s->p, /*released_by_flag=*/false);
+    }
+}
+
+// The host reads the iteration's status record (the GPU is already busy with the direction update, the exchange and -- in the
+// next turn of the loop -- the SpMV). Returns true when the loop is over.
+bool SolveRun::read_status() {
+    if (!status_known) wait_for_status(s);
+    mailbox_check(s->comm);
+    if (const int gave_up = __atomic_load_n(&s->h_poll->halo_late, __ATOMIC_ACQUIRE)) {
+        if (s->selfcheck) {  // creation check: a hand-over that never came is a verdict, not the end of the process
+            s->selfcheck_late = true;
+            __atomic_store_n(&s->h_poll->halo_late, 0, __ATOMIC_RELEASE);
+            return true;
+        }
+        // worded like the host watchdog's report: bench.py's supervisors read that sentence and restart the ranks once without the overlap
+        fprintf(stderr, "\n[spmv_amd watchdog] rank %d: no progress for %.1f s in stage '%s' (CG iteration %d)\n", s->comm->rank, halo_wait_limit_s(s),
+                gave_up == 3 ? "edge rows' ready flag (side-stream wait in front of the halo exchange)"
+                             : "halo arrival flag (in-kernel wait of the boundary rows)",
+                enqueued - 1);
+        report_slab_state(s, stderr);
+        exit(EXIT_FAILURE);
+    }
+    if (config->verbose >= 2 && s->comm->rank == 0) {
+        CgScalars now;
+        HIP_CHECK(hipMemcpy(&now, s->d_s, sizeof now, hipMemcpyDeviceToHost));
+        if (s->label)  // cg_solve_device's line (reference cg_solver.cu:604-607)
+            printf("[%s] Iter %3d: residual = %e (rel = %e)\n", s->label, now.iterations, now.residual, now.residual / now.b_norm);
+        else
+            printf("[Iter %3d] Residual: %.6e (rel: %.6e, alpha: %.4e)\n", now.iterations, now.residual, now.residual / now.b_norm, now.alpha);
+    }
+    return s->h_poll->converged != 0;
+}
+
+// Averages over the counted iterations of a timeline solve; order = kTimelineNames.
+void SolveRun::resolve_timeline(const CgScalars& fin, float total_ms) {
+    auto us = [&](hipEvent_t a, hipEvent_t b) {
+        float ms = 0.f;
+        HIP_CHECK(hipEventElapsedTime(&ms, a, b));
+        return (double)ms * 1e3;
+    };
+    const std::vector<hipEvent_t>& E = s->tl_compute;
+    const size_t tl_flush = mark_index(enqueued, 0);  // [+0] before, [+1] after the final flush
+    const int its = fin.iterations < enqueued ? fin.iterations : enqueued;
+    // The direction update of the converging iteration does no work (its launch reads the flag and returns; with late
+    // bulk only a lead piece is launched at all): it is left out of that stage's average, as the reference divides each
+    // timer by the iterations that ran it (cg_solver_mgpu_partitioned.cu:770-800) and tests convergence before its p
+    // update (:652-676). iteration_us stays the average over all counted iterations, the shorter last one included.
+    const int direction_updates = fin.converged && its > 0 ? its - 1 : its;
+    double stage[kTimelineMarks] = {0, 0, 0, 0, 0, 0, 0};  // [k] = mark k -> mark k+1; [6] = mark 6 -> next iteration's mark 0
+    double iteration_us = 0.0;
+    for (int it = 0; it < its; ++it) {
+        const size_t base = mark_index(it, 0);
+        for (int k = 0; k < kTimelineMarks - 1; ++k)
+            if (k != 5 || it < direction_updates) stage[k] += us(E[base + k], E[base + k + 1]);
+        const hipEvent_t next = it + 1 < enqueued ? E[base + kTimelineMarks] : E[tl_flush];  // the last counted iteration ends at the flush mark
+        stage[6] += us(E[base + 6], next);
+        iteration_us += us(E[base], next);
+    }
+    double side_us = 0.0;
+    const int exchanges = tl_exchanges < its ? tl_exchanges : its;  // exchange j feeds the SpMV of iteration j
+    for (int j = 0; j < exchanges; ++j) side_us += us(s->tl_side[2 * (size_t)j], s->tl_side[2 * (size_t)j + 1]);
+    const double per = its > 0 ? 1.0 / its : 0.0;
+    s->timeline_us = {(double)its, (double)total_ms, us(E[0], E[1]), stage[0] * per, stage[1] * per, stage[2] * per, stage[3] * per,
+                      stage[4] * per, direction_updates > 0 ? stage[5] / direction_updates : 0.0, stage[6] * per, iteration_us * per,
+                      exchanges > 0 ? side_us / exchanges : 0.0, us(E[tl_flush], E[tl_flush + 1]), (double)direction_updates};
+    stats->time_spmv_ms = (s->timeline_us[3] + s->timeline_us[4]) * s->timeline_us[0] / 1e3;
+}
+
+// The last flush of x, the end of the timed region, and the outcome from what the scalar kernels left in host-coherent memory.
+void SolveRun::finish() {
     s->shape.reverse = false;
     s->reduce_mailbox = nullptr;
-    const size_t tl_flush = 2 + (size_t)enqueued * kTimelineMarks;  // [+0] before, [+1] after the final flush
+    const size_t tl_flush = mark_index(enqueued, 0);
     if (timeline) HIP_CHECK(hipEventRecord(tl_event(s->tl_compute, tl_flush), s->compute));
-    if (slots > 1 && enqueued > window_start)  // x <- x + the directions of the last window
+    if (L.slots > 1 && enqueued > window_start)  // x <- x + the directions of the last window
         timed(&stats->time_blas1_ms, nullptr, [&] {
-            launch_cg_flush_x(nl, s->d_alpha_ring, ring_view, slots, window_start % slots, enqueued - window_start,
-                              window_start == 0 ? s->x0 : s->x, s->x, s->compute);
+            launch_cg_flush_x(nl, s->d_alpha_ring, ring_view, L.slots, window_start % L.slots, enqueued - window_start, window_start == 0 ? s->x0 : s->x,
+                              s->x, s->compute);
         });
     s->p = s->ring[0];
     if (enqueued == 0)  // no iteration ran (max_iters == 0): the solution is the initial guess
-        HIP_CHECK(hipMemcpyAsync(s->x, s->x0, vbytes, hipMemcpyDeviceToDevice, s->compute));
+        HIP_CHECK(hipMemcpyAsync(s->x, s->x0, nl * sizeof(double), hipMemcpyDeviceToDevice, s->compute));
     if (timeline) HIP_CHECK(hipEventRecord(tl_event(s->tl_compute, tl_flush + 1), s->compute));
     total.end(s->compute);
     float total_ms = 0.f;
     {
-        WatchdogScope guard("draining the streams after the loop", comm->rank, enqueued, report_slab_state, s);
+        WatchdogScope guard("draining the streams after the loop", s->comm->rank, enqueued, report_slab_state, s);
         total_ms = total.elapsed_ms();
-        HIP_CHECK(hipStreamSynchronize(s->side));
+        if (s->side) HIP_CHECK(hipStreamSynchronize(s->side));
     }
     HIP_CHECK(hipGetLastError());
-
-    // The outcome, from what the scalar kernels left in host-coherent memory (the stop event above has been waited for):
-    // iteration count and flag from the last status record, ||r|| of the last counted iteration from the history -- which is
+    // Iteration count and flag from the last status record, ||r|| of the last counted iteration from the history -- which is
     // fin.residual when converged and sqrt(fin.rr_old) when not (the step moves rr_new into rr_old exactly then). Only a solve
     // longer than the history (2^20 iterations) has to fetch the device scalars.
     CgScalars fin;
@@ -1223,53 +1328,18 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
         HIP_CHECK(hipMemcpy(&fin, s->d_s, sizeof fin, hipMemcpyDeviceToHost));
     }
     if (timeline) {
-        // averages over the counted iterations; order = kTimelineNames
-        auto us = [&](hipEvent_t a, hipEvent_t b) {
-            float ms = 0.f;
-            HIP_CHECK(hipEventElapsedTime(&ms, a, b));
-            return (double)ms * 1e3;
-        };
-        const std::vector<hipEvent_t>& E = s->tl_compute;
-        const int its = fin.iterations < enqueued ? fin.iterations : enqueued;
-        // The direction update of the converging iteration does no work (its launch reads the flag and returns; with late
-        // bulk only a lead piece is launched at all): it is left out of that stage's average, as the reference divides each
-        // timer by the iterations that ran it (cg_solver_mgpu_partitioned.cu:770-800) and tests convergence before its p
-        // update (:652-676). iteration_us stays the average over all counted iterations, the shorter last one included.
-        const int direction_updates = fin.converged && its > 0 ? its - 1 : its;
-        double stage[kTimelineMarks] = {0, 0, 0, 0, 0, 0, 0};  // [k] = mark k -> mark k+1; [6] = mark 6 -> next iteration's mark 0
-        double iteration_us = 0.0;
-        for (int it = 0; it < its; ++it) {
-            const size_t base = 2 + (size_t)it * kTimelineMarks;
-            for (int k = 0; k < kTimelineMarks - 1; ++k)
-                if (k != 5 || it < direction_updates) stage[k] += us(E[base + k], E[base + k + 1]);
-            // the last counted iteration ends at the flush mark
-            const hipEvent_t next = it + 1 < enqueued ? E[base + kTimelineMarks] : E[tl_flush];
-            stage[6] += us(E[base + 6], next);
-            iteration_us += us(E[base], next);
-        }
-        double side_us = 0.0;
-        const int exchanges = tl_exchanges < its ? tl_exchanges : its;  // exchange j feeds the SpMV of iteration j
-        for (int j = 0; j < exchanges; ++j) side_us += us(s->tl_side[2 * (size_t)j], s->tl_side[2 * (size_t)j + 1]);
-        const double per = its > 0 ? 1.0 / its : 0.0;
-        s->timeline_us = {(double)its, (double)total_ms, us(E[0], E[1]), stage[0] * per, stage[1] * per, stage[2] * per, stage[3] * per,
-                          stage[4] * per, direction_updates > 0 ? stage[5] / direction_updates : 0.0, stage[6] * per, iteration_us * per,
-                          exchanges > 0 ? side_us / exchanges : 0.0, us(E[tl_flush], E[tl_flush + 1]), (double)direction_updates};
-    }
-    if (timeline) {
-        stats->time_spmv_ms = (s->timeline_us[3] + s->timeline_us[4]) * s->timeline_us[0] / 1e3;
-    } else if (!detail) {  // timed SpMV launches that did real work (one per counted iteration), scaled to all of them
+        resolve_timeline(fin, total_ms);
+    } else if (!L.detail) {  // timed SpMV launches that did real work (one per counted iteration), scaled to all of them
         double ms_sum = 0.0;
-        int used = 0;
         s->last_spmv_each.clear();
         for (int k = 0; k < sampled; ++k) {
             if (sampled_iteration[k] >= fin.iterations) continue;
             float ms = 0.f;
             HIP_CHECK(hipEventElapsedTime(&ms, s->spmv_ev[2 * k], s->spmv_ev[2 * k + 1]));
             ms_sum += ms;
-            ++used;
             s->last_spmv_each.push_back(ms);
         }
-        stats->time_spmv_ms = used > 0 ? ms_sum / used * fin.iterations : 0.0;
+        stats->time_spmv_ms = s->last_spmv_each.empty() ? 0.0 : ms_sum / (double)s->last_spmv_each.size() * fin.iterations;
     }
     ++s->spmv_event_phase;
     s->last_spmv_ms = stats->time_spmv_ms;
@@ -1279,8 +1349,8 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
     // not converged: the reference reports sqrt(rs_old) of the last completed iteration (:720-725)
     stats->residual_norm = (fin.converged || fin.iterations < s->hist_cap) ? fin.residual : sqrt(fin.rr_old);
     stats->time_total_ms = total_ms;
-    if (!fin.converged && comm->rank == 0 && s->label == nullptr) printf("\nMax iterations reached without convergence\n");
-    if (detail && stats->iterations > 0) {
+    if (!fin.converged && s->comm->rank == 0 && s->label == nullptr) printf("\nMax iterations reached without convergence\n");
+    if (L.detail && stats->iterations > 0) {
         stats->time_dot_rs_new_ms /= stats->iterations;
         stats->time_axpy_update_r_ms /= stats->iterations;
         stats->time_axpby_update_p_ms /= stats->iterations;
@@ -1288,6 +1358,28 @@ extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* 
     const int count = fin.iterations + 1 < s->hist_cap ? fin.iterations + 1 : s->hist_cap;
     s->history.assign(s->d_hist, s->d_hist + count);
     last_cg_history() = s->history;
+}
+
+}  // namespace
+
+extern "C" int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* config, CGStatsMultiGPU* stats) {
+    SolveRun run(s, config, stats);
+    // the reference's NVTX ranges (:540-717) as roctx ranges, when detailed timers (or SPMV_AMD_ROCTX=1) ask for them
+    TraceScope solver_range(run.trace, "CG_Solver");
+    run.begin();
+    run.initial_residual();
+    bool done = false;
+    while (!done && !s->op_failed && run.enqueued < config->max_iters) {
+        TraceScope iteration_range(run.trace, "CG_Iteration");
+        run.stage_spmv();
+        if (s->op_failed) break;  // nothing of this iteration is awaited yet
+        run.stage_allreduce_pAp();
+        run.stage_update_r();
+        run.stage_sum_rr_and_step();
+        run.stage_direction_and_halo();
+        done = run.read_status();
+    }
+    run.finish();
     return s->op_failed ? 1 : 0;
 }
 
@@ -1362,23 +1454,21 @@ extern "C" int spmv_amd_cg_slab_spmv_launch_ms(const SpmvAmdCgSlab* s, float* ou
 
 extern "C" void spmv_amd_cg_slab_set_timeline(SpmvAmdCgSlab* s, int on) { s->timeline_on = on != 0; }
 
-// Loop options of an existing slab, for A/B measurements on the SAME allocations (two slabs of one process differ by up to
-// +-1.3 % through their placement alone, profiles/r03_placement.txt). Every option leaves the results bit-identical.
+#ifdef SPMV_AMD_LAB
+// (LAB build only.) Options of an existing slab, for A/B measurements on the SAME allocations (two slabs of one process differ
+// by up to +-1.3 % through their placement alone, profiles/r03_placement.txt): "no_overlap" (the PLAIN loop shape), "late_bulk",
+// "lead_rows" -- none of which changes a bit of the results -- "spmv_event_stride", and the timing aid "stop_at".
 // Returns 0, or -1 for an unknown name.
 extern "C" int spmv_amd_cg_slab_set_option(SpmvAmdCgSlab* s, const char* name, long long value) {
     if (strcmp(name, "late_bulk") == 0) s->late_bulk = value != 0;
     else if (strcmp(name, "lead_rows") == 0) s->lead_rows = value < 512 ? 512 : (size_t)value / 512 * 512;
-    else if (strcmp(name, "early_halo") == 0) s->early_halo = value != 0;
-    else if (strcmp(name, "pingpong") == 0) s->pingpong = value != 0;
-    else if (strcmp(name, "reduce_one_launch") == 0) s->reduce_one_launch = value != 0;
-    else if (strcmp(name, "no_overlap") == 0) s->no_overlap = value != 0;
-    else if (strcmp(name, "halo_flag") == 0) s->halo_flag = value != 0;
-    else if (strcmp(name, "edges_in_step") == 0) s->edges_in_step = value != 0;
+    else if (strcmp(name, "no_overlap") == 0) s->no_overlap = value != 0 || s->comm->pipeline_verdict < 0;  // a refused pipeline stays refused
     else if (strcmp(name, "stop_at") == 0) s->stop_at = value > 0 ? (int)value : 0;
     else if (strcmp(name, "spmv_event_stride") == 0) s->spmv_event_stride = (int)value;
     else return -1;
     return 0;
 }
+#endif  // SPMV_AMD_LAB
 extern "C" const char* spmv_amd_cg_slab_timeline_names(void) { return kTimelineNames; }
 extern "C" int spmv_amd_cg_slab_timeline(const SpmvAmdCgSlab* s, double* out, int cap) {
     const int count = (int)s->timeline_us.size();
@@ -1446,8 +1536,8 @@ std::mutex g_workspace_lock;
 // A release asked for BY THAT THREAD -- a caller's run_device that calls spmv_amd_cg_release_workspace() or an operator's
 // free() -- cannot take the lock again and must not pull the vectors from under the running loop: it is noted and carried
 // out when the solve returns.
-std::thread::id g_workspace_owner;
-bool g_release_pending = false;
+std::atomic<std::thread::id> g_workspace_owner{std::thread::id()};  // read without the lock by release_cg_workspace() on any thread
+bool g_release_pending = false;  // only ever touched by the owner thread (which holds the lock)
 void release_cg_workspace_locked() {
     if (g_workspace == nullptr) return;
     spmv_amd_cg_slab_destroy(g_workspace);
@@ -1458,7 +1548,7 @@ void release_cg_workspace_locked() {
 namespace spmv_amd {
 
 void release_cg_workspace() {
-    if (g_workspace_owner == std::this_thread::get_id()) {  // only ever equal on the thread that set it: no lock needed to compare
+    if (g_workspace_owner.load(std::memory_order_acquire) == std::this_thread::get_id()) {  // only ever equal on the thread that set it
         g_release_pending = true;
         return;
     }
@@ -1477,9 +1567,9 @@ int cg_solve_on_operator(SpmvOperator* op, int n, const double* b, double* x, co
                          std::vector<double>* history) {
     std::lock_guard<std::mutex> guard(g_workspace_lock);
     struct Owner {  // marks this thread as the one inside the solve; a release it asked for meanwhile is carried out on the way out
-        Owner() { g_workspace_owner = std::this_thread::get_id(), g_release_pending = false; }
+        Owner() { g_release_pending = false, g_workspace_owner.store(std::this_thread::get_id(), std::memory_order_release); }
         ~Owner() {
-            g_workspace_owner = std::thread::id();
+            g_workspace_owner.store(std::thread::id(), std::memory_order_release);
             if (g_release_pending) release_cg_workspace_locked();
             g_release_pending = false;
         }

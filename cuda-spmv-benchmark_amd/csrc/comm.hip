@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "device_runtime.hpp"
+#include "mpi_bootstrap.hpp"
 #include "watchdog.hpp"
 
 #define RCCL_CHECK(call)                                                                         \
@@ -216,7 +217,43 @@ SpmvAmdComm* g_world = nullptr;
 
 namespace spmv_amd {
 SpmvAmdComm* self_comm() { return &g_self; }
-SpmvAmdComm* world_comm() { return g_world ? g_world : &g_self; }
+
+// The communicator cg_solve_mgpu_partitioned runs on: the one the caller handed over (spmv_amd_comm_set_world); else, in a
+// process that has MPI initialised with more than one rank -- the reference's own main, src/main/cg_solver_mgpu_stencil.cu:23-27,
+// which calls the solver with nothing but MPI around it -- RCCL communicators created HERE, once, the way the reference finds its
+// rank (src/solvers/cg_solver_mgpu_partitioned.cu:240-259): rank and size from MPI_COMM_WORLD, device = rank, the 256-byte id
+// drawn by rank 0 and carried by MPI_Bcast (mpi_bootstrap.hpp: the MPI library is the process's own, looked up at run time);
+// else the single rank. Errors exit, as the reference's CUDA_CHECK does (include/spmv.h:46-53).
+SpmvAmdComm* world_comm() {
+    if (g_world) return g_world;
+    MpiWorld mpi;
+    if (!mpi_world(&mpi) || mpi.size < 2) return &g_self;
+    int devices = 0;
+    if (hipGetDeviceCount(&devices) != hipSuccess) devices = 0;
+    (void)hipGetLastError();
+    if (devices < mpi.size) {
+        fprintf(stderr, "[cg-mgpu] rank %d of %d (MPI: %s): %d HIP device(s) visible, one per rank is required (the reference: cudaSetDevice(rank))\n",
+                mpi.rank, mpi.size, mpi.flavour, devices);
+        exit(EXIT_FAILURE);
+    }
+    HIP_CHECK(hipSetDevice(mpi.rank));
+    char id[2 * NCCL_UNIQUE_ID_BYTES];
+    memset(id, 0, sizeof id);
+    if (mpi.rank == 0) spmv_amd_comm_unique_id(id);
+    if (!mpi_bcast_bytes(id, (int)sizeof id, 0)) {
+        fprintf(stderr, "[cg-mgpu] rank %d of %d: MPI_Bcast of the communicator id failed\n", mpi.rank, mpi.size);
+        exit(EXIT_FAILURE);
+    }
+    SpmvAmdComm* c = spmv_amd_comm_create_rccl(mpi.rank, mpi.size, id);
+    if (c == nullptr || spmv_amd_comm_selftest(c) != 0) {
+        fprintf(stderr, "[cg-mgpu] rank %d of %d: RCCL communicator %s\n", mpi.rank, mpi.size, c ? "failed its self-test" : "could not be created");
+        exit(EXIT_FAILURE);
+    }
+    if (mpi.rank == 0)
+        printf("[cg-mgpu] %d ranks from MPI_COMM_WORLD (%s), one GPU each; halo rows and dot products over RCCL\n", mpi.size, mpi.flavour);
+    g_world = c;  // kept for the later solves of the process (the harness runs 14: 3 warm-ups + 1 + 10)
+    return g_world;
+}
 }  // namespace spmv_amd
 
 // The id handed around is two RCCL unique ids back to back (p2p + collective communicator).
@@ -235,10 +272,12 @@ extern "C" SpmvAmdComm* spmv_amd_comm_create_rccl(int rank, int world, const voi
     RcclComm* c = new RcclComm();
     c->rank = rank;
     c->world = world;
+#ifdef SPMV_AMD_LAB  // test hooks of the lab build (comm.hpp): the product library's communicator is what its ranks make it
     const char* force = getenv("SPMV_AMD_FORCE_COLLECTIVES");
     c->force_collectives = force != nullptr && force[0] == '1';
     const char* self_nb = getenv("SPMV_AMD_SELF_NEIGHBOUR");
     c->self_neighbour = world == 1 && self_nb != nullptr && self_nb[0] == '1';
+#endif
     {
         // Creation failures are reported to the caller (NULL), who may choose another transport;
         // failures later, inside a solve, end the process like every HIP error does.

@@ -49,17 +49,22 @@ struct SpmvAmdComm {
     PeerMailbox* d_mailbox = nullptr;
     struct MailboxHost* mailbox_host = nullptr;  // owner of the allocations behind d_mailbox
     bool mailbox_ready() const { return d_mailbox != nullptr; }
-    // Test hook (SPMV_AMD_FORCE_COLLECTIVES=1): issue the all-reduces even with one rank, so that a
+    // Test hook, LAB build only (SPMV_AMD_FORCE_COLLECTIVES=1): issue the all-reduces even with one rank, so that a
     // 1-GPU box drives the RCCL calls of the CG loop; a 1-rank all-reduce is the identity.
     bool force_collectives = false;
     bool collective() const { return world > 1 || force_collectives; }
-    // Test hook (SPMV_AMD_SELF_NEIGHBOUR=1, one RCCL rank): the rank is its own previous and next neighbour.
-    // The solver then runs the whole multi-rank pipeline -- halo-carrying buffers, send / recv on the side
-    // stream under the interior SpMV, event waits, split SpMV launches -- on one GPU. The rows that would
-    // read the halos are the first and last grid row of the GLOBAL grid, which have no north / south entry,
-    // so the received values are never used and the solve must reproduce the plain single-rank result.
+    // Test hook, LAB build only (SPMV_AMD_SELF_NEIGHBOUR=1, one RCCL rank): the rank is its own previous and next
+    // neighbour. The solver then runs the whole multi-rank pipeline -- halo-carrying buffers, send / recv on the side
+    // stream under the interior SpMV, the arrival flag, split SpMV launches -- on one GPU. On the WHOLE grid the rows that
+    // would read the halos are the first and last grid row of the global grid, which have no north / south entry: the
+    // received values are never used and the solve must reproduce the plain single-rank result. On a stand-in slab
+    // (spmv_amd_cg_slab_create_stencil5_as) they ARE used: the slab mirrored at its cuts, checked against the oracle.
     bool self_neighbour = false;
     bool exchanges_halos() const { return world > 1 || self_neighbour; }
+    // What the first slab created on this communicator found when it solved a few iterations in both loop shapes
+    // (cg_slab.hip, verify_pipeline): 0 = not checked yet, 1 = the overlapped pipeline reproduced the plain order's residual
+    // history bit for bit on every rank, -1 = it did not on some rank: every slab on this communicator runs the plain order.
+    int pipeline_verdict = 0;
     virtual ~SpmvAmdComm() {}
     // Exchanges `count` doubles with rank-1 (send_prev/recv_prev) and rank+1 (send_next/recv_next);
     // pointers are device pointers, NULL where the slab has no neighbour on that side (the pointers, not the

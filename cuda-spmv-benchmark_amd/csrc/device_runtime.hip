@@ -21,7 +21,13 @@ int placement_candidates() {
     const int k = env_int("SPMV_AMD_PLACEMENT_CANDIDATES", 3);
     return k < 1 ? 1 : (k > 16 ? 16 : k);
 }
-int placement_fail_after() { return env_int("SPMV_AMD_PLACEMENT_FAIL_AFTER", 0); }
+int placement_fail_after() {
+#ifdef SPMV_AMD_LAB  // test hook of the lab build: the k-th further candidate "does not fit"
+    return env_int("SPMV_AMD_PLACEMENT_FAIL_AFTER", 0);
+#else
+    return 0;
+#endif
+}
 
 LaunchShape current_launch_shape() {
     // the launch switches (kernels.hpp, Tunables), out-of-range values replaced by the defaults: read when an operator is

@@ -73,7 +73,7 @@ int placement_candidates();
 // optional copy must never abort a solve that fits without it -- and so does free memory below
 // bytes + spacer + 4 GiB. cost_ms(candidate) is evaluated on each; the cheapest is returned, the others are freed -- `first`
 // too if it lost and release_first is set. *tried / *gain (optional): candidates timed, cost of the first over the one kept.
-// SPMV_AMD_PLACEMENT_FAIL_AFTER=<k> (test hook): the k-th further candidate "does not fit".
+// SPMV_AMD_PLACEMENT_FAIL_AFTER=<k> (test hook, LAB build only): the k-th further candidate "does not fit".
 int placement_fail_after();
 template <class T, class Cost>
 inline T* device_alloc_best_of(size_t count, size_t min_count, Cost&& cost_ms, int* tried = nullptr, double* gain = nullptr,

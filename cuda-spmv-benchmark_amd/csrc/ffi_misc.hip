@@ -143,7 +143,7 @@ extern "C" int spmv_amd_cg_fused_step(int which, size_t n, const double* scalars
         return 1;
     }
     if (has_dot) {
-        launch_reduce_partials(partials, cg_partial_count(n), d_out, nullptr, nullptr, ReduceScratch{stage, true});
+        launch_reduce_partials(partials, cg_partial_count(n), d_out, nullptr, nullptr, ReduceScratch{stage});
         HIP_CHECK(hipDeviceSynchronize());
         if (dot_out) download(dot_out, d_out, 1);
     }
@@ -157,5 +157,9 @@ extern "C" int spmv_amd_cg_fused_step(int which, size_t n, const double* scalars
 }
 
 extern "C" const char* spmv_amd_version(void) {
+#ifdef SPMV_AMD_LAB
+    return "libspmv_amd_lab 0.1 (gfx950, HIP " __DATE__ "; LAB build: test and measurement hooks compiled in)";
+#else
     return "libspmv_amd 0.1 (gfx950, HIP " __DATE__ ")";
+#endif
 }

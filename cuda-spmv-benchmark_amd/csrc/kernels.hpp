@@ -146,8 +146,9 @@ struct CgScalars {
     int converged;
     int iterations;
     int max_history;
-    int stop_at;  // measurement hook (set_option "stop_at"): the scalar step of this iteration declares convergence whatever the
-                  // residual, so that a stand-in slab (whose periodic system never converges) does a converging solve's work: 0 = off
+    int stop_at;  // LAB build only (read through cg_stop_at(), reduce_device.hpp; the product library ignores the field): the scalar
+                  // step of this iteration declares convergence whatever the residual, so that a stand-in slab (whose mirrored
+                  // system does not converge in 14 iterations) does a converging solve's work: 0 = off
     // r.r after step k in slot k & 1 (slot 0: the initial r.r): a launch that holds step k AND work that needs beta_k reads
     // beta_k = rr_new / rr_ring[(k - 1) & 1] in every workgroup without waiting for the step -- the step writes the OTHER slot
     // (and rr_old, which only later launches read)
@@ -182,7 +183,6 @@ void launch_check_convergence(const double* d_rr_new, double b_norm, double tol,
 // doubles, zero before the first use (every reduction leaves it ready for the next).
 struct ReduceScratch {
     double* base = nullptr;  // null: a single workgroup sums everything (short lists only)
-    bool one_launch = true;  // false: slices and final sum as two launches, the form of rounds 2-4 (the slab option reduce_one_launch = 0)
 };
 int reduce_scratch_doubles();
 double* reduce_scratch_alloc();  // uncached device memory where the runtime offers it, zeroed; hipFree releases it
@@ -202,7 +202,7 @@ void launch_halo_arrived(unsigned* d_flag, unsigned sequence, hipStream_t stream
 // The first and / or last grid row of a solver slab (the rows that wait for the halos) AND the reduction of the SpMV's p.Ap
 // partials -- the interior launch's d_interior_partials plus these rows' own -- into *d_out, in ONE launch (spmv_kernels.hip).
 // `interior` = the plan of the launch over the other rows. Returns false, having launched nothing, where the fused form does
-// not apply (not a row-lds slab, two-launch reductions asked for, a slab of fewer than three grid rows): the caller then
+// not apply (not a row-lds slab, a slab of fewer than three grid rows): the caller then
 // launches the rows and the reduction separately.
 bool launch_stencil5_edges_and_reduce(const SlabCsr& m, const Stencil5Plan& interior, bool first_gridrow, bool last_gridrow, const double* x,
                                       double* y, double alpha, const double* d_interior_partials, double* d_out, const int* d_skip_flag,
@@ -231,12 +231,6 @@ void launch_cg_update_p_ring(size_t n, const CgScalars* s, const double* r, cons
                              int iteration, hipStream_t stream, bool reverse = false, bool fma_form = false);
 // x = x_in + sum_j alpha[slot_j] * p[slot_j], slot_j = (first_slot + j) % slots for j = 0..count-1, added in that
 // order with one fma each: element for element the x the per-iteration updates x += alpha_j p_j produce.
-// Both direction updates over two row ranges, [0, count_a) and [second, second + count_b) (all even), in ONE launch: the first
-// and last grid row of a slab, ahead of the rest (early halo exchange, cg_slab.hip).
-void launch_cg_update_px_two_ranges(size_t count_a, size_t second, size_t count_b, const CgScalars* s, const double* r, double* p,
-                                    const double* x_in, double* x, int iteration, hipStream_t stream, bool fma_form = false);
-void launch_cg_update_p_ring_two_ranges(size_t count_a, size_t second, size_t count_b, const CgScalars* s, const double* r,
-                                        const double* p_in, double* p_out, int iteration, hipStream_t stream, bool fma_form = false);
 constexpr int kMaxRingSlots = 16;
 struct RingSlots {
     const double* p[kMaxRingSlots];

@@ -40,6 +40,15 @@ constexpr int kReduceStageBlocks = 256;
 __device__ __forceinline__ bool cg_converging(double rr_new, double b_norm, double tol, int stop_at, int k) {
     return sqrt(rr_new) / b_norm < tol || (stop_at > 0 && k == stop_at);
 }
+// stop_at: measurement hook of the LAB build only (kernels.hpp, CgScalars); the product library's test is the reference's alone
+__device__ __forceinline__ int cg_stop_at(const CgScalars* s) {
+#ifdef SPMV_AMD_LAB
+    return s->stop_at;
+#else
+    (void)s;
+    return 0;
+#endif
+}
 
 __device__ __forceinline__ void cg_scalars_step(CgScalars* s, double tol, double* history, int* host_record,
                                                 int sequence, double* alpha_ring, int ring_slots) {
@@ -51,7 +60,7 @@ __device__ __forceinline__ void cg_scalars_step(CgScalars* s, double tol, double
         s->rr_ring[s->iterations & 1] = s->rr_new;
         if (alpha_ring != nullptr) alpha_ring[(s->iterations - 1) % ring_slots] = s->alpha;
         if (history != nullptr && s->iterations < s->max_history) history[s->iterations] = res;
-        if (cg_converging(s->rr_new, s->b_norm, tol, s->stop_at, s->iterations)) {
+        if (cg_converging(s->rr_new, s->b_norm, tol, cg_stop_at(s), s->iterations)) {
             s->converged = 1;
         } else {
             s->beta = s->rr_new / s->rr_old;
@@ -185,6 +194,11 @@ __device__ __forceinline__ void publish(unsigned long long* slot, double value) 
 }
 __device__ __forceinline__ double published(const unsigned long long* slot) {
     return __longlong_as_double((long long)__hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+// A value ANOTHER AGENT may have written (a peer GPU's store over xGMI, a DMA engine, the RCCL receive kernel on behalf of a
+// peer): system scope, so that no cache level of this device may answer from a line it held before the writer's data arrived.
+__device__ __forceinline__ double published_by_any_agent(const unsigned long long* slot) {
+    return __longlong_as_double((long long)__hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
 }
 
 // Called by ALL threads of a workgroup once everything it contributes has been published (by any of its threads, each

@@ -169,7 +169,9 @@ constexpr int kLdsTileCols = 128;
 // sit on a scalar-load round trip before its first vector load; such a launch only reads). *dot: the tile's partial.
 // kFreshHalo (boundary tiles evaluated behind a device-side arrival flag instead of a kernel boundary, see
 // stencil5_rowlds_edges_reduce_kernel): the north / south values -- the halo rows another GPU's data was received into -- are
-// read with agent-scope loads, which this XCD's L2 cannot serve from a line it cached before the rows arrived.
+// read with SYSTEM-scope loads: the writer is another agent (a peer GPU's stores over xGMI, or the RCCL receive kernel acting
+// for it), and no cache of this device may answer from a line it held before those rows arrived (2 x grid_size
+// values per iteration, nothing on the clock).
 template <int kMode, bool kFreshHalo = false>
 __device__ __forceinline__ bool rowlds_tile(const SlabCsr& m, const double* __restrict__ x, double* __restrict__ y, double alpha,
                                             int li, int gi, int j0, int lane, int skip, double* __restrict__ strip,
@@ -208,8 +210,8 @@ __device__ __forceinline__ bool rowlds_tile(const SlabCsr& m, const double* __re
                 const double* __restrict__ xl = x + ((long long)li * n + j);
                 xc[h] = xl[0];
                 if (kFreshHalo) {
-                    xn[h] = published(reinterpret_cast<const unsigned long long*>(xl - n));
-                    xs[h] = published(reinterpret_cast<const unsigned long long*>(xl + n));
+                    xn[h] = published_by_any_agent(reinterpret_cast<const unsigned long long*>(xl - n));
+                    xs[h] = published_by_any_agent(reinterpret_cast<const unsigned long long*>(xl + n));
                 } else {
                     xn[h] = xl[-n], xs[h] = xl[n];
                 }
@@ -368,6 +370,11 @@ __global__ __launch_bounds__(kReduceBlock) void stencil5_rowlds_edges_reduce_ker
                         __builtin_amdgcn_s_sleep(4);
                     }
                 }
+                // Ordering point for the whole wave (lanes 1-63 never ran the loop): no load of the tile below may be moved above
+                // the wait by the compiler. Wavefront scope: no cache operation is emitted, the halo values are read past the
+                // caches by their own system-scope loads.
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 live = rowlds_tile<1, true>(m, x, y, alpha, li, gfirst + li, (tile - row_group * col_tiles) * kLdsTileCols, lane, skip, strip[wave],
                                             xrow[wave], none, &dot);
             } else {
@@ -976,7 +983,7 @@ bool launch_stencil5_edges_and_reduce(const SlabCsr& m, const Stencil5Plan& inte
                                       const ReduceScratch& scratch, int* host_progress, int progress_value, const PeerMailbox* mailbox,
                                       hipStream_t stream, const HaloArrival& halo) {
     const int n = m.grid_size;
-    if (interior.variant != Stencil5Variant::RowLds || scratch.base == nullptr || !scratch.one_launch || (!first_gridrow && !last_gridrow) ||
+    if (interior.variant != Stencil5Variant::RowLds || scratch.base == nullptr || (!first_gridrow && !last_gridrow) ||
         interior.partials <= 0 || n <= 0 || m.n_local % n != 0)
         return false;
     const int local_gridrows = m.n_local / n;

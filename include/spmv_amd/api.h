@@ -312,18 +312,29 @@ typedef struct SpmvAmdCgSlab SpmvAmdCgSlab;
 SpmvAmdCgSlab* spmv_amd_cg_slab_create(MatrixData* mat, SpmvAmdComm* comm);
 /* Slab of the synthetic n x n stencil, generated in HBM; b = 1, x0 = 0. */
 SpmvAmdCgSlab* spmv_amd_cg_slab_create_stencil5(int n, SpmvAmdComm* comm);
-/* Measurement aid: the slab rank `as_rank` of an `as_world`-GPU run would own (same rows, CSR bytes, halo
- * length and neighbour sides; reference partition, cg_solver_mgpu_partitioned.cu:259-268,306-331), carried by ONE
- * rank whose communicator was created with SPMV_AMD_SELF_NEIGHBOUR=1 and exchanges the halo rows with itself
- * through the transport's own send / recv path. Solves a periodic strip, not the global system: timing only. */
-SpmvAmdCgSlab* spmv_amd_cg_slab_create_stencil5_as(int n, int as_rank, int as_world, SpmvAmdComm* comm);
 /* Full-length host vectors as in the reference (each rank uploads its slab);
  * NULL keeps b = 1 / x0 = 0. */
 int spmv_amd_cg_slab_set_vectors(SpmvAmdCgSlab* s, const double* b_full, const double* x0_full);
 /* One solve from the stored x0; the timed region is the reference's
- * (cg_solver_mgpu_partitioned.cu:405-413 -> 728-731). */
+ * (cg_solver_mgpu_partitioned.cu:405-413 -> 728-731).
+ * The loop has two shapes (csrc/cg_slab.hip, LoopShape), bit-identical in their results. PIPELINE (default on a slab with
+ * neighbours): the halo exchange runs on a side stream under the interior rows' SpMV; the boundary rows wait inside their
+ * launch for a device flag the side stream raises behind the receive, and the side stream's exchange waits for a device
+ * flag the direction update's first workgroups raise. CONCURRENCY REQUIREMENT: those two waits spin (bounded: 20 s, or half of
+ * SPMV_AMD_WATCHDOG_S) for a kernel on the OTHER stream, so the two streams' kernels must be able to run at the same time --
+ * true on the hardware queues of a normal process, NOT under a tool that serialises dispatches (rocprofv3 --pmc): run such
+ * passes with SPMV_AMD_NO_OVERLAP=1. PLAIN (SPMV_AMD_NO_OVERLAP=1 read at creation, detailed timers, the in-place form, slabs too
+ * thin to split): everything on the compute stream, the exchange behind the whole direction update, the reference's own order
+ * (:680-703); no device flag, no spin. A wait that gives up ends the process with the watchdog's sentence on stderr. */
 int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* config,
                            CGStatsMultiGPU* stats);
+/* Which shape this slab's loop takes and who decided (a static string): "single rank"; "pipeline (verified against the plain
+ * order at creation)"; "plain: SPMV_AMD_NO_OVERLAP=1"; "plain: the pipeline's residual history differed from the plain order's in
+ * the creation check". The creation check: the first slab created on a communicator that exchanges halos solves four iterations
+ * in each shape (default b = 1, x0 = 0); the shapes are bit-identical by construction, so a difference on any rank -- lost or stale
+ * halo rows, a device flag that never comes -- makes every slab on that communicator run the plain order, with a line on
+ * stderr. Set-up work, once per communicator, outside every timed region. */
+const char* spmv_amd_cg_slab_loop_shape(const SpmvAmdCgSlab* s);
 /* Gathers the solution into x_full on rank 0 (other ranks get their own slab). */
 int spmv_amd_cg_slab_gather(SpmvAmdCgSlab* s, double* x_full);
 int spmv_amd_cg_slab_history(SpmvAmdCgSlab* s, double* out, int cap);
@@ -363,16 +374,6 @@ int spmv_amd_cg_slab_tile_runs(const SpmvAmdCgSlab* s, double* out, int cap);
 int spmv_amd_cg_slab_setup_ms(const SpmvAmdCgSlab* s, double* out, int cap);
 /* The timed in-loop SpMV launches of the last solve, one by one (ms, iteration order). Returns their number. */
 int spmv_amd_cg_slab_spmv_launch_ms(const SpmvAmdCgSlab* s, float* out, int cap);
-/* Loop options of an existing slab (A/B runs on the same allocations; results are bit-identical under every option):
- * "late_bulk" 0/1, "lead_rows" N, "early_halo" 0/1, "pingpong" 0/1, "reduce_one_launch" 0/1 (0 = the two-launch reductions of
- * rounds 2-4 and a separate boundary-row launch), "no_overlap" 0/1 (1 = halo exchange on the compute stream),
- * "halo_flag" 0/1 (0 = a cross-stream event wait in front of the boundary rows instead of their own wait for the arrival flag),
- * "edges_in_step" 0/1 (slabs with neighbours; 1 = the rows they wait for, the first piece of the rest of the direction update and, on the
- * RCCL path, the scalar step in ONE launch whose device flag releases the halo exchange; 0 = rounds 3-4's step | edge rows | event | rest),
- * "spmv_event_stride" N (time every N-th in-loop SpMV launch -- default 7, phase advancing with every solve --, 0 = none). The one option that is NOT result-neutral, a timing
- * aid for stand-in slabs: "stop_at" K (iteration K counts as the converging one whatever its residual; 0 = off).
- * 0, or -1 = unknown name. */
-int spmv_amd_cg_slab_set_option(SpmvAmdCgSlab* s, const char* name, long long value);
 const char* spmv_amd_cg_slab_timeline_names(void);
 int spmv_amd_cg_slab_timeline(const SpmvAmdCgSlab* s, double* out, int cap);
 void spmv_amd_cg_slab_destroy(SpmvAmdCgSlab* s);

@@ -36,6 +36,17 @@ def B():
 
 
 @pytest.fixture(scope="session")
+def Blab(B):
+    """The binding on the LAB build of the library (lib/libspmv_amd_lab.so: the product's sources compiled with -DSPMV_AMD_LAB,
+    which adds the test and measurement hooks the product library does not have: stand-in slabs, self-neighbour communicators,
+    loop options, fault injection). Everything else in the suite runs on the product library (`B`)."""
+    mod = B.use_lab()
+    mod.lib()
+    assert mod.is_lab() and not B.is_lab()
+    return mod
+
+
+@pytest.fixture(scope="session")
 def O():
     """The CPU oracle (test infrastructure)."""
     from oracle import oracle

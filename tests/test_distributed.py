@@ -152,7 +152,7 @@ def test_bench_distributed_path_with_one_rank():
     unique-id broadcast, RCCL communicator creation and the all-reduces inside the CG loop all run
     (a 1-rank all-reduce is the identity), and the result must equal the plain single-rank run."""
     import json
-    env = dict(os.environ, SPMV_AMD_BENCH_FORCE_DIST="1", SPMV_AMD_FORCE_COLLECTIVES="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, SPMV_AMD_BENCH_FORCE_DIST="1", SPMV_AMD_FORCE_COLLECTIVES="1", SPMV_AMD_LIB="lab", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
            "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
            "--grid", "1024", "--no-cpu-baseline", "--no-spmv"]
@@ -177,7 +177,7 @@ def test_multi_rank_pipeline_over_rccl_with_the_rank_as_its_own_neighbour(grid):
     the first and last grid row of the global grid have no north / south entry, must reproduce the plain solve
     (the split launches change the order of the dot partials, hence 1e-10 rather than bit equality)."""
     import json
-    env = dict(os.environ, SPMV_AMD_BENCH_FORCE_DIST="1", SPMV_AMD_FORCE_COLLECTIVES="1", SPMV_AMD_SELF_NEIGHBOUR="1",
+    env = dict(os.environ, SPMV_AMD_BENCH_FORCE_DIST="1", SPMV_AMD_FORCE_COLLECTIVES="1", SPMV_AMD_SELF_NEIGHBOUR="1", SPMV_AMD_LIB="lab",
                HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
            "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
@@ -235,7 +235,10 @@ def read_process_log(path):
     return [json.loads(l) for l in open(path).read().splitlines() if l.strip()] if os.path.exists(path) else []
 
 
-FORCED_MULTI_ENV = dict(SPMV_AMD_BENCH_FORCE_DIST="1", SPMV_AMD_FORCE_COLLECTIVES="1", SPMV_AMD_SELF_NEIGHBOUR="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+# the complete multi-rank pipeline on one GPU needs the LAB build's hooks (self-neighbour communicator, forced collectives, fault
+# injection): SPMV_AMD_LIB=lab makes binding.py -- and with it bench.py -- load lib/libspmv_amd_lab.so
+FORCED_MULTI_ENV = dict(SPMV_AMD_BENCH_FORCE_DIST="1", SPMV_AMD_FORCE_COLLECTIVES="1", SPMV_AMD_SELF_NEIGHBOUR="1", SPMV_AMD_LIB="lab",
+                        HSA_ENABLE_IPC_MODE_LEGACY="0")
 
 
 @pytest.mark.gpu
@@ -618,13 +621,14 @@ def test_bench_two_ranks_under_an_external_launcher_on_one_gpu():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("n,as_rank,as_world", [(640, 0, 2), (640, 1, 4), (640, 3, 4), (1024, 3, 8)])
-def test_stand_in_slab_is_the_real_slab_of_that_rank(B, O, fresh_host_matrices, monkeypatch, n, as_rank, as_world):
+def test_stand_in_slab_is_the_real_slab_of_that_rank(Blab, O, monkeypatch, n, as_rank, as_world):
     """spmv_amd_cg_slab_create_stencil5_as (the scaling probe's slab): rank r-of-P's rows, CSR bytes and halo sides on a
     single self-neighbour RCCL rank. Its slab SpMV on caller data (halos filled from the full vector, no exchange) must
     be bit-identical to the oracle's halo kernel for that rank; a solve with tolerance 0 runs exactly max_iters
     iterations through the send/recv + all-reduce pipeline."""
     monkeypatch.setenv("SPMV_AMD_SELF_NEIGHBOUR", "1")
     monkeypatch.setenv("SPMV_AMD_FORCE_COLLECTIVES", "1")
+    B = Blab
     comm = B.Comm.rccl(0, 1, B.Comm.unique_id())
     assert comm is not None and comm.transport() == "rccl" and comm.transport_ranks() == 1
     slab = B.CgSlab.stencil5_as(n, as_rank, as_world, comm)
@@ -643,3 +647,131 @@ def test_stand_in_slab_is_the_real_slab_of_that_rank(B, O, fresh_host_matrices, 
     assert slab.history()[-1] < slab.history()[0]  # the periodic strip is SPD too: CG makes progress
     slab.destroy()
     comm.destroy()
+
+
+def stand_in_system(O, n, as_rank, as_world):
+    """The linear system a stand-in slab solves, as a general CSR matrix of the slab's own rows. The slab is rank r of P of the
+    n x n stencil carried by ONE self-neighbour RCCL rank: the halo exchange sends the first grid row "to the previous rank" and the
+    last grid row "to the next rank", both of which are this rank, and same-peer send / recv pairs match in the order they were
+    issued (csrc/comm.hip, halo_exchange) -- so the previous-rank halo receives the slab's own FIRST grid row and the next-rank
+    halo its own LAST one. A north entry of the first grid row (global column c in [off - n, off)) therefore multiplies the row's
+    own element (local column c - off + n), a south entry of the last grid row local column c - off - n: the slab mirrored at both
+    cuts (diagonal 4 instead of 5 there: still symmetric positive definite). Rows and values are the global stencil's
+    (reference slab: cg_solver_mgpu_partitioned.cu:306-329); the column map is the halo kernel's (spmv_stencil_partitioned_halo_kernel.cu:44-68)
+    with the halos' contents written out."""
+    off, nl = O.partition_rows(n * n, as_world, as_rank)
+    rp, ci, va = O.stencil5_csr(n)
+    base, end = int(rp[off]), int(rp[off + nl])
+    lrp = (rp[off:off + nl + 1] - base).astype(np.int32)
+    local = ci[base:end].astype(np.int64) - off
+    if as_rank == 0:
+        assert local.min() >= 0  # the global first grid row has no north entry
+    if as_rank == as_world - 1:
+        assert local.max() < nl
+    local = np.where(local < 0, local + n, local)
+    local = np.where(local >= nl, local - n, local)
+    assert local.min() >= 0 and local.max() < nl
+    return lrp, local.astype(np.int32), va[base:end].copy(), nl
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ring", [16, 4])
+@pytest.mark.parametrize("n,as_rank,as_world", [(1024, 0, 2), (1024, 1, 2), (1024, 1, 4), (2048, 3, 8)])
+def test_stand_in_slab_over_rccl_solves_its_system_like_the_oracle(Blab, O, monkeypatch, n, as_rank, as_world, ring):
+    """The RCCL transport's multi-rank shapes against the ORACLE: a stand-in slab under self-neighbour RCCL
+    with DEFAULT options -- halo rows by ncclSend / ncclRecv on the side stream, the boundary waves' in-kernel wait on the arrival
+    flag, the direction update's edge rows written through + the side stream's wait kernel, both ncclAllReduce -- is the one
+    configuration on a one-GPU box in which the RECEIVED halo values enter the result over RCCL (a whole-grid self-neighbour
+    solve cannot notice stale or lost halo rows: its first / last grid row have no north / south entry). The system it solves,
+    written out as a general CSR (stand_in_system), goes through oracle_cg's CSR loop with the partitioned solver's BLAS1 forms
+    (device_form = False: p = r + beta p as axpby, cg_solver_mgpu_partitioned.cu:680-703); every ||r_k|| must agree to 1e-10.
+    Ring 16 (no flush inside 12 iterations: the scalar step rides in the direction update's launch every time) and ring 4 (every
+    fourth iteration flushes x first: the step is a launch of its own there)."""
+    monkeypatch.setenv("SPMV_AMD_SELF_NEIGHBOUR", "1")
+    monkeypatch.setenv("SPMV_AMD_FORCE_COLLECTIVES", "1")
+    monkeypatch.setenv("SPMV_AMD_P_RING", str(ring))
+    B = Blab
+    iterations = 12
+    lrp, lci, lva, nl = stand_in_system(O, n, as_rank, as_world)
+    _, want, res = O.cg(lrp, lci, lva, -1, np.ones(nl), np.zeros(nl), max_iters=iterations, tol=0.0, device_form=False)
+    assert res.iterations == iterations and len(want) == iterations + 1 and want[-1] < 1e-3 * want[0]
+    comm = B.Comm.rccl(0, 1, B.Comm.unique_id())
+    assert comm is not None and comm.transport() == "rccl"
+    slab = B.CgSlab.stencil5_as(n, as_rank, as_world, comm)
+    try:
+        assert slab.n_local == nl and slab.variant() == "stencil5/row-lds"
+        for _ in range(3):  # back to back: flags and sequence numbers carry over from solve to solve
+            st = slab.solve(max_iters=iterations, tol=0.0)
+            got = slab.history()
+            assert st.iterations == iterations and st.converged == 0 and len(got) == iterations + 1
+            assert hist_err(got, want) < 1e-10, (got, want)
+    finally:
+        slab.destroy()
+        comm.destroy()
+
+
+@pytest.mark.gpu
+def test_a_ranks_set_up_fits_the_leg_timeout_many_times_over(Blab, monkeypatch):
+    """What one rank of the default `bench.py --gpus 8` run does before its first timed solve, on the real P = 8 slab of the headline
+    grid (rank 3 of 8: 5e7 rows, two neighbours; a stand-in on this one GPU): two RCCL communicators + the self-test, the slab
+    generated in HBM, the placement and tile-run trials of creation, 3 warm-up solves + 10 steps. bench.py ends an attempt at the
+    headline leg after --leg-timeout = 170 s (two attempts fit the 420 s launch limit): the whole of it must take a small
+    fraction of that, or a slow box would turn a healthy run into an UNMEASURED line."""
+    monkeypatch.setenv("SPMV_AMD_SELF_NEIGHBOUR", "1")
+    monkeypatch.setenv("SPMV_AMD_FORCE_COLLECTIVES", "1")
+    B = Blab
+    t0 = time.monotonic()
+    comm = B.Comm.rccl(0, 1, B.Comm.unique_id())
+    assert comm is not None and comm.selftest() == 0
+    t_comm = time.monotonic() - t0
+    slab = B.CgSlab.stencil5_as(20000, 3, 8, comm)
+    t_slab = time.monotonic() - t0 - t_comm
+    phases = slab.setup_ms()
+    for _ in range(13):
+        st = slab.solve(max_iters=14, tol=0.0)
+    total = time.monotonic() - t0
+    slab.destroy()
+    comm.destroy()
+    assert st.iterations == 14 and slab is not None
+    assert t_comm < 30 and t_slab < 30 and total < 60, (t_comm, t_slab, total, phases)
+    assert sum(phases.values()) / 1e3 <= t_slab + 0.5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fault", ["0", "3", "4"])
+def test_creation_check_refuses_a_pipeline_that_loses_halo_rows(Blab, O, monkeypatch, capfd, fault):
+    """The library's own guard for the constructions no one-GPU box can prove between devices: the first slab created
+    on a communicator that exchanges halos solves four iterations in the plain order and four in the pipeline; the shapes are
+    bit-identical by construction, so a difference refuses the pipeline for that communicator. Healthy (fault 0): the pipeline
+    is kept and says it was verified. Fault injection of the LAB build: 3 = the rows of a side-stream exchange never travel,
+    4 = the exchange's arrival flag never comes (the boundary waves give up after 2 s in the check, not 20 s, and the check --
+    not the process -- ends): the slab says so on stderr, runs the plain order (no side-stream exchange in the timeline) and its
+    solve still matches the oracle on the stand-in's system, where the received rows matter."""
+    monkeypatch.setenv("SPMV_AMD_SELF_NEIGHBOUR", "1")
+    monkeypatch.setenv("SPMV_AMD_FORCE_COLLECTIVES", "1")
+    monkeypatch.setenv("SPMV_AMD_TEST_WEDGE_OVERLAPPED_EXCHANGE", fault)
+    B = Blab
+    n, r, P, iterations = 1024, 1, 4, 10
+    lrp, lci, lva, nl = stand_in_system(O, n, r, P)
+    _, want, _ = O.cg(lrp, lci, lva, -1, np.ones(nl), np.zeros(nl), max_iters=iterations, tol=0.0, device_form=False)
+    comm = B.Comm.rccl(0, 1, B.Comm.unique_id())
+    t0 = time.monotonic()
+    slab = B.CgSlab.stencil5_as(n, r, P, comm)
+    assert time.monotonic() - t0 < 60
+    err = capfd.readouterr().err
+    try:
+        shape = slab.loop_shape()
+        if fault == "0":
+            assert shape == "pipeline (verified against the plain order at creation)" and "refused" not in err
+        else:
+            assert shape.startswith("plain: the pipeline's residual history differed"), shape
+            assert "did NOT reproduce the plain order's residual history" in err and "refused the overlapped pipeline" in err
+        st, tl = slab.timeline_solve(max_iters=iterations, tol=0.0)
+        assert st.iterations == iterations and hist_err(slab.history(), want) < 1e-10
+        assert (tl["halo_exchange_on_side_stream_us"] > 0) == (fault == "0")
+        second = B.CgSlab.stencil5_as(n, 0, 2, comm)  # the verdict belongs to the communicator: a later slab does not check again
+        assert second.loop_shape() == shape
+        second.destroy()
+    finally:
+        slab.destroy()
+        comm.destroy()

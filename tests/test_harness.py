@@ -194,3 +194,24 @@ def test_bench_line_carries_every_baseline_number_as_a_flat_scalar():
     assert abs(roof["spmv20k_frac"] - 0.7692) < 1e-4 and roof["bound"] == "hbm" and roof["unit"] == "GB/s"
     assert conf["spmv_effective_gbs"] == roof["spmv20k_effective_gbs"] and conf["spmv_median_ms"] == 3.64
     assert json.dumps(line)  # one JSON line
+
+
+def test_reference_mpi_main_finds_its_ranks_and_fails_loudly_without_gpus():
+    """The reference's MPI main (oracle/_ref/ref_cg_solver_mgpu: src/main/cg_solver_mgpu_stencil.cu minus its nsys capture window)
+    under `mpiexec -np 2` with no GPU in sight: every rank loads the matrix, calls cg_solve_mgpu_partitioned with nothing but
+    MPI_Init around it, and the LIBRARY finds rank and size through the process's own MPI library (csrc/mpi_bootstrap.cpp: dlsym,
+    no link-time MPI dependency) -- as the reference's solver does (cg_solver_mgpu_partitioned.cu:240-259) -- then stops the way
+    the reference's cudaSetDevice(rank) would: a message naming rank, size and the devices it found, non-zero exit."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_cg_solver_mgpu")
+    mpiexec = "/opt/conda/bin/mpiexec"
+    if not os.path.exists(exe) or not os.path.exists(mpiexec):
+        pytest.skip("oracle/_ref/ref_cg_solver_mgpu not built, or no mpiexec (reference sources / MPI absent)")
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
+    out = subprocess.run([mpiexec, "-np", "2", exe, os.path.join(GOLDEN, "example81x81.mtx")], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0, out.stdout + out.stderr
+    assert "Matrix loaded: 6561" in out.stdout and "Calling partitioned multi-GPU CG solver" in out.stdout
+    # (the launcher ends the other rank as soon as the first one has exited: at least one of them got its sentence out)
+    assert any(f"[cg-mgpu] rank {rank} of 2 (MPI: MPICH ABI): 0 HIP device(s) visible, one per rank is required" in out.stderr for rank in (0, 1)), out.stderr
+    # the library itself has no MPI dependency
+    ldd = subprocess.run(["ldd", os.path.join(ROOT, "cuda-spmv-benchmark_amd", "lib", "libspmv_amd.so")], capture_output=True, text=True).stdout
+    assert "libmpi" not in ldd

@@ -193,6 +193,35 @@ def test_only_the_declared_api_leaves_the_library(B):
     assert listed == declared
 
 
+def test_hooks_live_in_the_lab_build_only(B):
+    """The test and measurement hooks (stand-in slabs, slab options incl. stop_at; the self-neighbour / forced-collective /
+    fault-injection / placement-failure environment switches) are compiled into lib/libspmv_amd_lab.so (-DSPMV_AMD_LAB) and
+    NOT into the product library: the product exports none of the lab's entry points, its binary does not even contain the
+    names of the lab's environment switches or options, api.h does not declare them; the lab build = the product's exports
+    + include/spmv_amd/lab.h's. The reference has no such switches (include/spmv.h:46-64)."""
+    import subprocess
+
+    def exports(path):
+        out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+        return {line.split()[-1] for line in out.splitlines() if line.strip()}
+
+    product, lab = exports(B.LIB_PATH), exports(B.LAB_LIB_PATH)
+    assert os.path.basename(B.LIB_PATH) == "libspmv_amd.so"
+    assert lab - product == set(B.LAB_ONLY_SYMBOLS) and product - lab == set()
+    api = open(os.path.join(ROOT, "include", "spmv_amd", "api.h")).read()
+    lab_h = open(os.path.join(ROOT, "include", "spmv_amd", "lab.h")).read()
+    for name in B.LAB_ONLY_SYMBOLS:
+        assert name not in api and name in lab_h
+    blob, lab_blob = open(B.LIB_PATH, "rb").read(), open(B.LAB_LIB_PATH, "rb").read()
+    for word in (b"SPMV_AMD_TEST_WEDGE_OVERLAPPED_EXCHANGE", b"SPMV_AMD_SELF_NEIGHBOUR", b"SPMV_AMD_FORCE_COLLECTIVES", b"SPMV_AMD_PLACEMENT_FAIL_AFTER",
+                 b"stop_at", b"spmv_event_stride", b"lead_rows"):
+        assert word not in blob, word
+        assert word in lab_blob, word
+    for word in (b"SPMV_AMD_NO_OVERLAP", b"SPMV_AMD_P_RING", b"SPMV_AMD_WATCHDOG_S"):  # the product's documented switches
+        assert word in blob, word
+    assert b"LAB build" in B.use_lab().lib().spmv_amd_version() and b"LAB" not in B.lib().spmv_amd_version()
+
+
 @pytest.mark.parametrize("case", ["stencil81_old", "stencil40", "random", "unbalanced", "upper", "long_rows_with_duplicate_columns"])
 def test_build_csr_struct_bit_exact(B, O, fresh_host_matrices, case):
     if case == "long_rows_with_duplicate_columns":

@@ -18,7 +18,7 @@ if sys.argv[1] == "--child":
     if P > 1:
         os.environ["SPMV_AMD_SELF_NEIGHBOUR"] = os.environ["SPMV_AMD_FORCE_COLLECTIVES"] = "1"
     os.dup2(2, 1)
-    B = load_binding()
+    B = load_binding().use_lab()  # stand-in slabs and slab options: the LAB build (include/spmv_amd/lab.h)
     B.lib()
     B.require_gpu()
     comm = B.Comm.rccl(0, 1, B.Comm.unique_id()) if P > 1 else None

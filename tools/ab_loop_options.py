@@ -4,8 +4,8 @@ with spmv_amd_cg_slab_set_option -- so that placement (worth up to +-1.3 % betwe
 profiles/r03_placement.txt) cannot enter. Solves run to the tolerance (14 iterations on the 20000 grid), alternating A B B A.
 
    python tools/ab_loop_options.py <option> [grid=20000] [as_world=1 as_rank=0] [rounds=8] [collectives=1]
-   options: late_bulk, early_halo, pingpong, reduce_one_launch, no_overlap, halo_flag, edges_in_step
-A slab of a larger job (as_world > 1) is a stand-in slab on a self-neighbour RCCL rank (see tools/ab_early_halo_rigorous.py)."""
+   options: no_overlap (pipeline against the plain loop shape), late_bulk
+A slab of a larger job (as_world > 1) is a stand-in slab on a self-neighbour RCCL rank (LAB build, include/spmv_amd/lab.h)."""
 import os
 import sys
 
@@ -26,7 +26,7 @@ comm = None
 if P > 1:
     os.environ["SPMV_AMD_SELF_NEIGHBOUR"] = "1"
     os.environ["SPMV_AMD_FORCE_COLLECTIVES"] = collectives
-B = load_binding()
+B = load_binding().use_lab()  # stand-in slabs and slab options: the LAB build (include/spmv_amd/lab.h)
 B.lib()
 B.require_gpu()
 if P > 1:

@@ -15,7 +15,11 @@ for ROLE in 1:0 2:1 4:1; do
   rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_$N" -- python3 tools/slab_attribution.py --child 20000 3 $ROLE > "$OUT/trace_$N.json" 2>"$OUT/trace_$N.err"
   for C in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do
     CN=$(echo "$C" | tr ' ' '_')
-    rocprofv3 --pmc $C --output-format csv -d "$OUT/pmc_${N}_$CN" -- python3 tools/slab_attribution.py --child 20000 2 $ROLE > "$OUT/pmc_${N}_$CN.json" 2>"$OUT/pmc_${N}_$CN.err"
+    # Counter passes SERIALISE dispatches: a kernel that spins for a flag another stream's kernel raises (the boundary waves'
+    # wait for the halo's arrival flag, the side stream's wait for the edge rows) would spin alone until its bound and end the
+    # run. The PLAIN loop shape has no such wait and gives the same bits and the same SpMV kernel: SLAB_OPTIONS=no_overlap=1
+    # (the concurrency requirement of the pipeline is stated in include/spmv_amd/api.h).
+    SLAB_OPTIONS=no_overlap=1 rocprofv3 --pmc $C --output-format csv -d "$OUT/pmc_${N}_$CN" -- python3 tools/slab_attribution.py --child 20000 2 $ROLE > "$OUT/pmc_${N}_$CN.json" 2>"$OUT/pmc_${N}_$CN.err"
   done
 done
 python3 - "$OUT" <<'PY'

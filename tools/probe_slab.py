@@ -16,7 +16,7 @@ solves = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 allreduce = sys.argv[4] if len(sys.argv) > 4 else "mailbox"
 grid = int(sys.argv[5]) if len(sys.argv) > 5 else 20000
 os.environ["SPMV_AMD_SELF_NEIGHBOUR"] = os.environ["SPMV_AMD_FORCE_COLLECTIVES"] = "1"
-B = load_binding()
+B = load_binding().use_lab()  # stand-in slabs and slab options: the LAB build (include/spmv_amd/lab.h)
 B.lib()
 B.require_gpu()
 if P == 1:

@@ -25,7 +25,7 @@ def child(grid, solves, roles):
     os.environ["SPMV_AMD_SELF_NEIGHBOUR"] = os.environ["SPMV_AMD_FORCE_COLLECTIVES"] = "1"
     json_fd = os.dup(1)
     os.dup2(2, 1)
-    B = load_binding()
+    B = load_binding().use_lab()  # stand-in slabs and slab options: the LAB build (include/spmv_amd/lab.h)
     B.lib()
     B.require_gpu()
     comm = B.Comm.rccl(0, 1, B.Comm.unique_id())
@@ -35,7 +35,7 @@ def child(grid, solves, roles):
         slab.set_option("spmv_event_stride", 1)  # every in-loop launch timed, small slabs too
         if P > 1:
             slab.set_option("stop_at", 14)  # the last iteration counts as the converging one, as on the rank of a real job
-        for opt in os.environ.get("SLAB_OPTIONS", "").split(","):  # e.g. SLAB_OPTIONS=reduce_one_launch=0
+        for opt in os.environ.get("SLAB_OPTIONS", "").split(","):  # e.g. SLAB_OPTIONS=no_overlap=1 (counter passes: tools/collect_slab_attribution.sh)
             if "=" in opt:
                 slab.set_option(opt.split("=")[0], int(opt.split("=")[1]))
         for _ in range(3):

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Soak of the loop's device-flag hand-overs (halo arrival flag, edge rows' ready flag) on stand-in slabs: many solves in a row per
-slab shape, both all-reduce shapes, every history compared bit for bit with the one the event-ordered form (edges_in_step = 0,
-halo_flag = 0) produced on the same slab. A lost or late hand-over would show as a different history, a watchdog exit or a hang.
+slab shape, both all-reduce shapes, every history compared bit for bit with the one the PLAIN loop shape (no_overlap: everything
+on the compute stream, no flag anywhere) produced on the same slab. A lost or late hand-over would show as a different history,
+a watchdog exit or a hang. (Rounds 5's reference form, the event-ordered pipeline, left with its switches in round 6.)
    python tools/soak_flags.py [solves=300]
 Small grids make the iterations short (tens of microseconds), which is where a race between the streams would have room."""
 import os
@@ -20,18 +21,16 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from conftest import load_binding
     os.dup2(2, 1)
-    B = load_binding()
+    B = load_binding().use_lab()  # stand-in slabs and slab options: the LAB build (include/spmv_amd/lab.h)
     B.lib()
     B.require_gpu()
     comm = B.Comm.rccl(0, 1, B.Comm.unique_id())
     slab = B.CgSlab.stencil5_as(n, r, P, comm)
     kw = dict(max_iters=14, tol=0.0)
-    slab.set_option("edges_in_step", 0)
-    slab.set_option("halo_flag", 0)
+    slab.set_option("no_overlap", 1)
     slab.solve(**kw)
     want = slab.history().copy()
-    slab.set_option("edges_in_step", 1)
-    slab.set_option("halo_flag", 1)
+    slab.set_option("no_overlap", 0)
     t0 = time.perf_counter()
     bad = 0
     for k in range(solves):
@@ -44,7 +43,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
             bad += 1
     dt = time.perf_counter() - t0
     print(f"grid {n:6d} slab {r} of {P} ({slab.n_local:9d} rows) collectives {collectives}: {solves} solves in {dt:6.2f} s, "
-          f"{bad} histories differ from the event-ordered form", file=sys.stderr)
+          f"{bad} histories differ from the plain shape's", file=sys.stderr)
     slab.destroy()
     comm.destroy()
     sys.exit(1 if bad else 0)
