@@ -707,10 +707,25 @@ namespace {
 // kernel -- constructions that were proven on ONE device (with the rank as its own neighbour) and cannot be proven between
 // devices on a one-GPU box. So the FIRST slab created on a communicator that exchanges halos checks them where it runs:
 // four iterations in the plain order (everything on the compute stream, no flag), four in the pipeline; the two shapes give
-// the same bits by construction, so any difference in the residual history on any rank -- lost or stale halo rows, a flag
-// that never comes (the waits give up after 2 s here) -- refuses the pipeline for every slab on that communicator: they run
+// the same bits by construction, so any difference in the residual history on any rank -- lost or stale halo rows (the halos
+// are set to NaN before each of the two solves), a flag that never comes (the waits give up after 2 s here) -- refuses the
+// pipeline for every slab on that communicator: they run
 // the plain order, say so on stderr and in spmv_amd_cg_slab_loop_shape(). ~10 iterations' worth of set-up, once per
 // communicator, outside every timed region (the library needed the check bench.py had).
+// Every halo row of every halo-carrying buffer (x0's, the direction ring's) set to NaN (all bits one). A correct loop receives
+// each of them before it reads it. Repeated solves of one system write the SAME values into the same slots every time: rows
+// that were lost, or read before they arrived, would otherwise be indistinguishable from rows that travelled.
+void poison_halos(SpmvAmdCgSlab* s) {
+    if (s->halo == 0 || s->op != nullptr) return;
+    const size_t bytes = (size_t)s->halo * sizeof(double);
+    auto both_sides = [&](double* local) {
+        if (s->has_prev) HIP_CHECK(hipMemsetAsync(local - s->halo, 0xFF, bytes, s->compute));
+        if (s->has_next) HIP_CHECK(hipMemsetAsync(local + s->n_local, 0xFF, bytes, s->compute));
+    };
+    both_sides(s->x0);
+    for (double* local : s->ring) both_sides(local);
+}
+
 void verify_pipeline(SpmvAmdCgSlab* s) {
     SpmvAmdComm* comm = s->comm;
     if (s->op != nullptr || !comm->exchanges_halos()) return;
@@ -720,10 +735,14 @@ void verify_pipeline(SpmvAmdCgSlab* s) {
         CGStatsMultiGPU st;
         s->selfcheck = true, s->selfcheck_late = false, s->wait_limit_s = 2.0;
         s->no_overlap = true;
+        poison_halos(s);
         spmv_amd_cg_slab_solve(s, &few, &st);
         const std::vector<double> plain = s->history;
         s->no_overlap = false;
+        poison_halos(s);  // what the plain solve left in the halos is exactly what the pipeline should receive: wipe it
         spmv_amd_cg_slab_solve(s, &few, &st);
+        poison_halos(s);
+        HIP_CHECK(hipStreamSynchronize(s->compute));
         const bool same = !s->selfcheck_late && plain.size() == s->history.size() && plain.size() == 5 &&
                           memcmp(plain.data(), s->history.data(), plain.size() * sizeof(double)) == 0;
         s->selfcheck = false, s->selfcheck_late = false, s->wait_limit_s = 0.0;
@@ -990,6 +1009,9 @@ void SolveRun::begin() {
     init.stop_at = s->stop_at;
 #endif
     HIP_CHECK(hipMemcpyAsync(s->d_s, &init, sizeof init, hipMemcpyHostToDevice, s->compute));
+#ifdef SPMV_AMD_LAB
+    poison_halos(s);  // the lab's tests solve one system again and again: a row that did not travel must not find last solve's copy
+#endif
     // Every solve starts from the stored x0 (the reference benchmark wrapper restores x on the host before each run). x is not
     // overwritten with x0 first: the initial SpMV reads x0 and the first x update computes x = x0 + alpha p.
     HIP_CHECK(hipStreamSynchronize(s->compute));

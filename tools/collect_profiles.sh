@@ -3,7 +3,7 @@
 #   1. rocprofv3 --kernel-trace --stats of the default command minus its scaling-probe leg,
 #      `python3 bench.py --no-scaling-probe` (the probe launches the same kernels on smaller grids and would mix
 #      their durations into the per-kernel averages)
-#   2. PMC passes (FETCH_SIZE, WRITE_SIZE, TCC hit/miss, SQ) of `bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-scaling-probe --no-spmv --no-ceiling`, --pmc only (separate passes, no trace domains)
+#   2. PMC passes (FETCH_SIZE, WRITE_SIZE, TCC hit/miss, SQ) of `bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-scaling-probe --no-spmv --no-compare --no-ceiling`, --pmc only (separate passes, no trace domains)
 #   3. the streaming probe (practical HBM ceilings of the box)
 # usage: tools/collect_profiles.sh <tag>
 set -u
@@ -11,9 +11,9 @@ TAG=${1:-r01}
 OUT=gpurun_out/profiles_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
 export TMPDIR=/tmp
-BENCH="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-scaling-probe --no-spmv --no-ceiling"
+BENCH="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-scaling-probe --no-spmv --no-compare --no-ceiling"
 # the exact default command for the per-kernel stats; the counter passes use a shorter run of the same workload
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 bench.py --no-scaling-probe > "$OUT/bench_stats_run.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 bench.py --no-scaling-probe --no-compare --cpu-sample-grid 10000 > "$OUT/bench_stats_run.log" 2>&1
 for C in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_RD"; do
   N=$(echo "$C" | tr ' ' '_' | cut -c1-30)
   rocprofv3 --pmc $C --output-format csv -d "$OUT/pmc_$N" -- $BENCH > "$OUT/pmc_$N.log" 2>&1
