@@ -367,7 +367,7 @@ def probe_role(B, grid, P, r, full_iterations, mailbox, steps=5):
     """ONE stand-in slab (rank r of P of this grid) in THIS process, which was started for it: the complete multi-rank pipeline
     over RCCL with the rank as its own neighbour (halo ncclSend / ncclRecv on the side stream under the interior SpMV, split SpMV
     launches, both all-reduces issued with one rank), `full_iterations` iterations per solve (tolerance 0: the slab's neighbours
-    being its own grid rows, the system solved is a periodic strip, not the global one -- only the time is used), the last
+    being its own grid rows, the system solved is the slab mirrored at its cuts, not the global one -- only the time is used), the last
     of which counts as the converging one, as in the real solve."""
     os.environ["SPMV_AMD_SELF_NEIGHBOUR"] = os.environ["SPMV_AMD_FORCE_COLLECTIVES"] = "1"
     comm = B.Comm.rccl(0, 1, B.Comm.unique_id())
@@ -378,7 +378,7 @@ def probe_role(B, grid, P, r, full_iterations, mailbox, steps=5):
         return {"error": "peer mailbox could not be set up"}
     slab = B.CgSlab.stencil5_as(grid, r, P, comm)
     # the rank of a real job converges in its last iteration: no direction update, no halo exchange behind it. The stand-in's
-    # periodic system would not: its last iteration is declared the converging one (timing aid, csrc/cg_slab.hip "stop_at")
+    # mirrored system would not: its last iteration is declared the converging one (timing aid, csrc/cg_slab.hip "stop_at")
     slab.set_option("stop_at", full_iterations)
     for _ in range(2):
         st = slab.solve(max_iters=full_iterations, tol=0.0)

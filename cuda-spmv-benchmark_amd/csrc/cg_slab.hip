@@ -201,7 +201,6 @@ struct SpmvAmdCgSlab {
     // stores / consumers' loads plain instead of nontemporal did not raise the hit share.
     bool roctx_always = false;  // SPMV_AMD_ROCTX=1: roctx ranges even without detailed timers
     bool no_overlap = false;  // SPMV_AMD_NO_OVERLAP=1: the PLAIN loop shape (halo exchange on the compute stream: the reference's; bench.py's fallback)
-    const char* no_overlap_why = "";  // who chose the plain shape: the environment switch, or the creation check (verify_pipeline)
     // verify_pipeline's two short solves: waits on the other stream's flags give up after wait_limit_s instead of 20 s, and a
     // wait that gave up ends that solve (selfcheck_late) instead of the process
     bool selfcheck = false, selfcheck_late = false;
@@ -349,7 +348,6 @@ void make_common(SpmvAmdCgSlab* s) {
     }
     s->shape = current_launch_shape();
     if (const char* v = getenv("SPMV_AMD_NO_OVERLAP")) s->no_overlap = v[0] == '1';
-    if (s->no_overlap) s->no_overlap_why = "SPMV_AMD_NO_OVERLAP=1";
 #ifdef SPMV_AMD_LAB
     if (const char* v = getenv("SPMV_AMD_TEST_WEDGE_OVERLAPPED_EXCHANGE")) s->test_wedge_overlapped_exchange = atoi(v);
 #endif
@@ -703,15 +701,6 @@ void allreduce_scalar(SpmvAmdCgSlab* s, double* d_value, const char* stage) {
 }  // namespace
 
 namespace {
-// The pipeline hands rows between its two streams through device flags and reads the received halo rows inside a running
-// kernel -- constructions that were proven on ONE device (with the rank as its own neighbour) and cannot be proven between
-// devices on a one-GPU box. So the FIRST slab created on a communicator that exchanges halos checks them where it runs:
-// four iterations in the plain order (everything on the compute stream, no flag), four in the pipeline; the two shapes give
-// the same bits by construction, so any difference in the residual history on any rank -- lost or stale halo rows (the halos
-// are set to NaN before each of the two solves), a flag that never comes (the waits give up after 2 s here) -- refuses the
-// pipeline for every slab on that communicator: they run
-// the plain order, say so on stderr and in spmv_amd_cg_slab_loop_shape(). ~10 iterations' worth of set-up, once per
-// communicator, outside every timed region (ADVICE r05: the library needed the check bench.py had).
 // Every halo row of every halo-carrying buffer (x0's, the direction ring's) set to NaN (all bits one). A correct loop receives
 // each of them before it reads it. Repeated solves of one system write the SAME values into the same slots every time: rows
 // that were lost, or read before they arrived, would otherwise be indistinguishable from rows that travelled.
@@ -726,6 +715,14 @@ void poison_halos(SpmvAmdCgSlab* s) {
     for (double* local : s->ring) both_sides(local);
 }
 
+// The pipeline hands rows between its two streams through device flags and reads the received halo rows inside a running
+// kernel -- constructions that were proven on ONE device (with the rank as its own neighbour) and cannot be proven between
+// devices on a one-GPU box. So the FIRST slab created on a communicator that exchanges halos checks them where it runs:
+// four iterations in the plain order (everything on the compute stream, no flag), four in the pipeline; the two shapes give
+// the same bits by construction, so any difference in the residual history on any rank -- lost or stale halo rows (the halos
+// are set to NaN before each of the two solves), a flag that never comes (the waits give up after 2 s here) -- refuses the
+// pipeline for every slab on that communicator: they run the plain order, say so on stderr and in spmv_amd_cg_slab_loop_shape(). ~10 iterations' worth of set-up, once per
+// communicator, outside every timed region (ADVICE r05: the library needed the check bench.py had).
 void verify_pipeline(SpmvAmdCgSlab* s) {
     SpmvAmdComm* comm = s->comm;
     if (s->op != nullptr || !comm->exchanges_halos()) return;
@@ -743,7 +740,12 @@ void verify_pipeline(SpmvAmdCgSlab* s) {
         spmv_amd_cg_slab_solve(s, &few, &st);
         poison_halos(s);
         HIP_CHECK(hipStreamSynchronize(s->compute));
-        const bool same = !s->selfcheck_late && plain.size() == s->history.size() && plain.size() == 5 &&
+        bool finite = true;  // NaN from a poisoned halo in the PLAIN order: the transport itself does not deliver the rows
+        for (double v : plain) finite = finite && std::isfinite(v);
+        if (!finite)
+            fprintf(stderr, "[cg-slab] rank %d: the plain order's residual history is not finite in the creation check: the communicator's halo "
+                            "exchange does not deliver this rank's neighbour rows (transport: %s)\n", comm->rank, comm->transport());
+        const bool same = finite && !s->selfcheck_late && plain.size() == s->history.size() && plain.size() == 5 &&
                           memcmp(plain.data(), s->history.data(), plain.size() * sizeof(double)) == 0;
         s->selfcheck = false, s->selfcheck_late = false, s->wait_limit_s = 0.0;
         double bad = same ? 0.0 : 1.0;
@@ -763,10 +765,7 @@ void verify_pipeline(SpmvAmdCgSlab* s) {
             fprintf(stderr, "[cg-slab] %g rank(s) refused the overlapped pipeline: every solve on this communicator runs the plain order "
                             "(halo exchange on the compute stream, the reference's own)\n", bad);
     }
-    if (comm->pipeline_verdict < 0) {
-        s->no_overlap = true;
-        s->no_overlap_why = "creation check";
-    }
+    if (comm->pipeline_verdict < 0) s->no_overlap = true;
 }
 
 SpmvAmdCgSlab* create_from_matrix(MatrixData* mat, SpmvAmdComm* comm, bool setup_trials) {

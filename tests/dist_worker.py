@@ -158,6 +158,9 @@ def run_gpu_rccl(n, rank, world, mailbox):
     N = n * n
     slab = B.CgSlab.stencil5(n, comm)
     assert (slab.row_offset, slab.n_local) == O.partition_rows(N, world, rank)
+    # the library's creation check just solved four iterations in the plain order and four in the pipeline BETWEEN THESE DEVICES
+    # (halos NaN-poisoned): the flag hand-overs and the in-kernel halo reads must have reproduced the plain order bit for bit
+    assert slab.loop_shape() == "pipeline (verified against the plain order at creation)", slab.loop_shape()
     rp, ci, va = O.stencil5_csr(n)
     xo, ho, ro = O.cg_partitioned(rp, ci, va, n, np.ones(N), np.zeros(N), world=world) if rank == 0 else (None, None, None)
     hists = []

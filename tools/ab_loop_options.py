@@ -32,7 +32,7 @@ B.require_gpu()
 if P > 1:
     comm = B.Comm.rccl(0, 1, B.Comm.unique_id())
     slab = B.CgSlab.stencil5_as(n, r, P, comm)
-    kw = dict(max_iters=14, tol=0.0)  # the periodic strip is another system: fixed iteration count, never converges
+    kw = dict(max_iters=14, tol=0.0)  # the slab mirrored at its cuts is another system: fixed iteration count
 else:
     slab = B.CgSlab.stencil5(n)
     kw = {}

@@ -17,9 +17,11 @@ for ROLE in 1:0 2:1 4:1; do
     CN=$(echo "$C" | tr ' ' '_')
     # Counter passes SERIALISE dispatches: a kernel that spins for a flag another stream's kernel raises (the boundary waves'
     # wait for the halo's arrival flag, the side stream's wait for the edge rows) would spin alone until its bound and end the
-    # run. The PLAIN loop shape has no such wait and gives the same bits and the same SpMV kernel: SLAB_OPTIONS=no_overlap=1
-    # (the concurrency requirement of the pipeline is stated in include/spmv_amd/api.h).
-    SLAB_OPTIONS=no_overlap=1 rocprofv3 --pmc $C --output-format csv -d "$OUT/pmc_${N}_$CN" -- python3 tools/slab_attribution.py --child 20000 2 $ROLE > "$OUT/pmc_${N}_$CN.json" 2>"$OUT/pmc_${N}_$CN.err"
+    # run. The PLAIN loop shape has no such wait and gives the same bits and the same SpMV kernel: SPMV_AMD_NO_OVERLAP=1, read at
+    # creation (the concurrency requirement of the pipeline is stated in include/spmv_amd/api.h). Without the
+    # switch the library's creation check would notice by itself -- its pipeline solve's waits give up after 2 s under a
+    # serialising tool -- and fall back to the plain order with a line on stderr.
+    SPMV_AMD_NO_OVERLAP=1 rocprofv3 --pmc $C --output-format csv -d "$OUT/pmc_${N}_$CN" -- python3 tools/slab_attribution.py --child 20000 2 $ROLE > "$OUT/pmc_${N}_$CN.json" 2>"$OUT/pmc_${N}_$CN.err"
   done
 done
 python3 - "$OUT" <<'PY'
