@@ -701,6 +701,55 @@ void allreduce_scalar(SpmvAmdCgSlab* s, double* d_value, const char* stage) {
 }  // namespace
 
 namespace {
+struct LoopShape {
+    bool multi = false;      // halo exchange needed
+    bool reduce = false;     // all-reduce of the dot products needed
+    bool separate = false;   // ... as a call of its own (RCCL / staged); false: inside the sums' last stage (peer mailbox) or not at all
+    const PeerMailbox* mailbox = nullptr;
+    bool detail = false;     // the reference's per-category timers: a host sync per stage, everything on the compute stream
+    // PIPELINE: the exchange on the side stream under the interior rows, the boundary rows behind its arrival flag, and the rows
+    // the neighbours wait for + the first piece of the rest + (RCCL path) the scalar step in ONE direction launch whose device
+    // flag releases the exchange. false = PLAIN: everything on the compute stream, the exchange behind the whole direction update.
+    bool pipeline = false;
+    bool late = false;       // direction update as lead piece + rest (late bulk)
+    int slots = 1;           // direction ring length; 1 = the in-place x / p update
+    EdgeRows edges{0, 0, 0}; // pipeline: [0, count_a) and [second, second + count_b)
+    size_t bulk_lo = 0, bulk_hi = 0;  // the rows of the direction update that are not edge rows
+};
+
+
+LoopShape loop_shape(const SpmvAmdCgSlab* s, const CGConfigMultiGPU* config) {
+    LoopShape L;
+    const SpmvAmdComm* comm = s->comm;
+    const size_t nl = (size_t)s->n_local;
+    L.multi = comm->exchanges_halos();
+    L.reduce = comm->collective();
+    L.mailbox = (L.reduce && comm->mailbox_ready()) ? comm->d_mailbox : nullptr;
+    L.separate = L.reduce && L.mailbox == nullptr;
+    L.detail = config->enable_detailed_timers != 0;
+    L.slots = s->ring_slots;
+    // (ring mode only: with the in-place form the x update of the converging iteration rides in that very launch)
+    L.late = s->late_bulk && !L.detail && L.slots > 1;
+    // Early halo (round 3): the two edge ranges are rounded OUTWARDS to 4 KiB (512 doubles), so that the launch over the rest
+    // starts on a 4 KiB boundary like every whole-vector launch does: with the ranges cut exactly at the grid row, the rest of a
+    // 15 000-column slab started 64 bytes off a 128-byte line and its direction update ran 20-30 % slower (485 vs 386 us at
+    // 112.5 M rows; at 20 000 columns, 128-byte but not 4 KiB aligned, 8 %). A few rows beyond the grid row updated early is harmless.
+    constexpr size_t kAlign = 512;
+    const size_t head_rows = s->has_prev ? ((size_t)s->halo + kAlign - 1) / kAlign * kAlign : 0;
+    const size_t tail_start = s->has_next ? (nl - (size_t)s->halo) / kAlign * kAlign : nl;
+    // the pipeline needs the direction ring (its one-launch direction update writes out of place) and a slab thick enough to
+    // have rows between its edge ranges; the in-place form and thinner slabs take the plain order
+    L.pipeline = L.multi && !L.detail && !s->no_overlap && L.slots > 1 && s->reduce_stage != nullptr && (nl % 2) == 0 &&
+                 nl >= 4 * (size_t)s->halo + 4 * kAlign && head_rows < tail_start;
+    if (L.pipeline) {
+        L.edges = EdgeRows{head_rows, tail_start, nl - tail_start};
+        L.bulk_lo = head_rows, L.bulk_hi = tail_start;
+    } else {
+        L.bulk_lo = 0, L.bulk_hi = nl;
+    }
+    return L;
+}
+
 // Every halo row of every halo-carrying buffer (x0's, the direction ring's) set to NaN (all bits one). A correct loop receives
 // each of them before it reads it. Repeated solves of one system write the SAME values into the same slots every time: rows
 // that were lost, or read before they arrived, would otherwise be indistinguishable from rows that travelled.
@@ -727,8 +776,13 @@ void verify_pipeline(SpmvAmdCgSlab* s) {
     SpmvAmdComm* comm = s->comm;
     if (s->op != nullptr || !comm->exchanges_halos()) return;
     if (s->no_overlap) return;  // the caller asked for the plain order: nothing to verify, nothing recorded
+    const CGConfigMultiGPU few = {4, 0.0, 0, 0};
+    // Whether THIS rank's slab takes the pipeline is a local fact (an odd row count, a thin last slab, the in-place form make it
+    // plain) while the check is collective: every rank of the communicator runs the two solves -- a plain-shaped rank solves
+    // the plain order twice -- and the verdict counts only if at least one rank really ran the pipeline.
+    const bool mine = loop_shape(s, &few).pipeline;
+    if (comm->world == 1 && !mine) return;
     if (comm->pipeline_verdict == 0) {
-        const CGConfigMultiGPU few = {4, 0.0, 0, 0};
         CGStatsMultiGPU st;
         s->selfcheck = true, s->selfcheck_late = false, s->wait_limit_s = 2.0;
         s->no_overlap = true;
@@ -748,22 +802,23 @@ void verify_pipeline(SpmvAmdCgSlab* s) {
         const bool same = finite && !s->selfcheck_late && plain.size() == s->history.size() && plain.size() == 5 &&
                           memcmp(plain.data(), s->history.data(), plain.size() * sizeof(double)) == 0;
         s->selfcheck = false, s->selfcheck_late = false, s->wait_limit_s = 0.0;
-        double bad = same ? 0.0 : 1.0;
+        double votes[2] = {same ? 0.0 : 1.0, mine ? 1.0 : 0.0};  // {ranks whose histories differ, ranks that ran the pipeline}
         if (!same)
             fprintf(stderr, "[cg-slab] rank %d: the overlapped pipeline did NOT reproduce the plain order's residual history in the creation check\n", comm->rank);
-        if (comm->world > 1) {  // every rank learns whether every rank agrees
-            double* d = device_alloc<double>(1);
-            upload(d, &bad, 1);
+        if (comm->world > 1) {  // every rank learns what every rank found
+            double* d = device_alloc<double>(2);
+            upload(d, votes, 2);
             WatchdogScope guard("creation check: all-reduce of the ranks' verdicts", comm->rank, -1, report_slab_state, s);
-            comm->allreduce_sum(d, 1, s->compute);
+            comm->allreduce_sum(d, 2, s->compute);
             HIP_CHECK(hipStreamSynchronize(s->compute));
-            download(&bad, d, 1);
+            download(votes, d, 2);
             device_release(d);
         }
-        comm->pipeline_verdict = bad == 0.0 ? 1 : -1;
+        // no rank ran the pipeline (every slab thin or in place): nothing was verified, a later slab on this communicator checks again
+        if (votes[0] != 0.0 || votes[1] != 0.0) comm->pipeline_verdict = votes[0] == 0.0 ? 1 : -1;
         if (comm->pipeline_verdict < 0 && comm->rank == 0)
             fprintf(stderr, "[cg-slab] %g rank(s) refused the overlapped pipeline: every solve on this communicator runs the plain order "
-                            "(halo exchange on the compute stream, the reference's own)\n", bad);
+                            "(halo exchange on the compute stream, the reference's own)\n", votes[0]);
     }
     if (comm->pipeline_verdict < 0) s->no_overlap = true;
 }
@@ -803,7 +858,11 @@ extern "C" SpmvAmdCgSlab* spmv_amd_cg_slab_create(MatrixData* mat, SpmvAmdComm* 
 // Which shape this slab's loop takes and who decided: "single rank", "pipeline", "plain: <why>". A static string.
 extern "C" const char* spmv_amd_cg_slab_loop_shape(const SpmvAmdCgSlab* s) {
     if (!s->comm->exchanges_halos()) return "single rank";
-    if (!s->no_overlap) return s->comm->pipeline_verdict > 0 ? "pipeline (verified against the plain order at creation)" : "pipeline";
+    if (!s->no_overlap) {
+        const CGConfigMultiGPU any = {1, 0.0, 0, 0};
+        if (!loop_shape(s, &any).pipeline) return "plain: the in-place form (ring 1) or a slab too thin to split";
+        return s->comm->pipeline_verdict > 0 ? "pipeline (verified against the plain order at creation)" : "pipeline";
+    }
     return s->comm->pipeline_verdict < 0 ? "plain: the pipeline's residual history differed from the plain order's in the creation check"
                                          : "plain: SPMV_AMD_NO_OVERLAP=1";
 }
@@ -870,54 +929,6 @@ extern "C" int spmv_amd_cg_slab_set_vectors(SpmvAmdCgSlab* s, const double* b_fu
 // update + halo exchange -- and each stage is one function below. What a stage enqueues depends on the shape only.
 // ---------------------------------------------------------------------------------------
 namespace {
-
-struct LoopShape {
-    bool multi = false;      // halo exchange needed
-    bool reduce = false;     // all-reduce of the dot products needed
-    bool separate = false;   // ... as a call of its own (RCCL / staged); false: inside the sums' last stage (peer mailbox) or not at all
-    const PeerMailbox* mailbox = nullptr;
-    bool detail = false;     // the reference's per-category timers: a host sync per stage, everything on the compute stream
-    bool overlap = false;    // PIPELINE: exchange on the side stream under the interior rows; false = PLAIN: on the compute stream
-    // pipeline only: the rows the neighbours wait for, the first piece of the rest and (RCCL path) the scalar step in ONE
-    // launch, the exchange released by that launch's device flag
-    bool fused_direction = false;
-    bool late = false;       // direction update as lead piece + rest (late bulk)
-    int slots = 1;           // direction ring length; 1 = the in-place x / p update
-    EdgeRows edges{0, 0, 0}; // fused_direction: [0, count_a) and [second, second + count_b)
-    size_t bulk_lo = 0, bulk_hi = 0;  // the rows of the direction update that are not edge rows
-};
-
-
-LoopShape loop_shape(const SpmvAmdCgSlab* s, const CGConfigMultiGPU* config) {
-    LoopShape L;
-    const SpmvAmdComm* comm = s->comm;
-    const size_t nl = (size_t)s->n_local;
-    L.multi = comm->exchanges_halos();
-    L.reduce = comm->collective();
-    L.mailbox = (L.reduce && comm->mailbox_ready()) ? comm->d_mailbox : nullptr;
-    L.separate = L.reduce && L.mailbox == nullptr;
-    L.detail = config->enable_detailed_timers != 0;
-    L.overlap = L.multi && !L.detail && !s->no_overlap;
-    L.slots = s->ring_slots;
-    // (ring mode only: with the in-place form the x update of the converging iteration rides in that very launch)
-    L.late = s->late_bulk && !L.detail && L.slots > 1;
-    // Early halo (round 3): the two edge ranges are rounded OUTWARDS to 4 KiB (512 doubles), so that the launch over the rest
-    // starts on a 4 KiB boundary like every whole-vector launch does: with the ranges cut exactly at the grid row, the rest of a
-    // 15 000-column slab started 64 bytes off a 128-byte line and its direction update ran 20-30 % slower (485 vs 386 us at
-    // 112.5 M rows; at 20 000 columns, 128-byte but not 4 KiB aligned, 8 %). A few rows beyond the grid row updated early is harmless.
-    constexpr size_t kAlign = 512;
-    const size_t head_rows = s->has_prev ? ((size_t)s->halo + kAlign - 1) / kAlign * kAlign : 0;
-    const size_t tail_start = s->has_next ? (nl - (size_t)s->halo) / kAlign * kAlign : nl;
-    L.fused_direction = L.overlap && L.slots > 1 && s->reduce_stage != nullptr && (nl % 2) == 0 &&
-                        nl >= 4 * (size_t)s->halo + 4 * kAlign && head_rows < tail_start;
-    if (L.fused_direction) {
-        L.edges = EdgeRows{head_rows, tail_start, nl - tail_start};
-        L.bulk_lo = head_rows, L.bulk_hi = tail_start;
-    } else {
-        L.bulk_lo = 0, L.bulk_hi = nl;
-    }
-    return L;
-}
 
 // State of one solve in flight: what the stages share.
 struct SolveRun {
@@ -1033,7 +1044,7 @@ void SolveRun::begin() {
 // PLAIN: on the compute stream, in order.
 void SolveRun::start_halo(double* v, bool released_by_flag) {
     if (!L.multi) return;
-    if (!L.overlap) {
+    if (!L.pipeline) {
         timed(&stats->time_allgather_ms, nullptr, [&] { exchange_halo(s, v, s->compute); });
         halo_in_flight = false;
         return;
@@ -1147,11 +1158,11 @@ void SolveRun::stage_update_r() {
 
 // Stage 4: sum of the r.r partials, across the ranks, and the scalar step (residual, history, verdict, beta, alpha into the
 // ring's slot, status record into host-coherent memory). One launch without a separate all-reduce; with one (RCCL) the
-// step follows the all-reduce -- as a launch of its own, or inside the direction update's launch (fused_direction), except in
+// step follows the all-reduce -- as a launch of its own, or inside the direction update's launch (pipeline), except in
 // the iteration whose new direction re-uses a slot the pending x flush still has to read: the flush needs this step's alpha
 // and must run before the slot is overwritten.
 void SolveRun::stage_sum_rr_and_step() {
-    step_in_direction = L.fused_direction && L.separate && (enqueued + 1) - window_start < L.slots;
+    step_in_direction = L.pipeline && L.separate && (enqueued + 1) - window_start < L.slots;
     ++s->poll_sequence;
     TraceScope range(trace, "Dot_Product");
     if (L.separate) {
@@ -1232,14 +1243,14 @@ void SolveRun::stage_direction_and_halo() {
             }
             trace.push("BLAS_AXPBY");
         };
-        if (L.fused_direction) pieces(fused, plain);
+        if (L.pipeline) pieces(fused, plain);
         else pieces(plain, plain);
         s->p = p_next;
     }
     trace.pop();
     mark(enqueued - 1, 6);
     s->enqueued_stage = "direction update and halo exchange";
-    if (!L.fused_direction) {
+    if (!L.pipeline) {
         TraceScope r(trace, "Halo_Exchange");
         start_halo(s->p, /*released_by_flag=*/false);
     }

@@ -329,8 +329,8 @@ int spmv_amd_cg_slab_set_vectors(SpmvAmdCgSlab* s, const double* b_full, const d
 int spmv_amd_cg_slab_solve(SpmvAmdCgSlab* s, const CGConfigMultiGPU* config,
                            CGStatsMultiGPU* stats);
 /* Which shape this slab's loop takes and who decided (a static string): "single rank"; "pipeline (verified against the plain
- * order at creation)"; "plain: SPMV_AMD_NO_OVERLAP=1"; "plain: the pipeline's residual history differed from the plain order's in
- * the creation check". The creation check: the first slab created on a communicator that exchanges halos solves four iterations
+ * order at creation)"; "plain: SPMV_AMD_NO_OVERLAP=1"; "plain: the in-place form (ring 1) or a slab too thin to split"; "plain: the
+ * pipeline's residual history differed from the plain order's in the creation check". The creation check: the first slab created on a communicator that exchanges halos solves four iterations
  * in each shape (default b = 1, x0 = 0); the shapes are bit-identical by construction, so a difference on any rank -- lost or stale
  * halo rows, a device flag that never comes -- makes every slab on that communicator run the plain order, with a line on
  * stderr. Set-up work, once per communicator, outside every timed region. */
