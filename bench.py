@@ -97,6 +97,14 @@ than ranks, or if RCCL spans fewer ranks than asked, every rank stops, rank 0 pr
 exchange -> H2D scheme) is taken only when SPMV_AMD_BENCH_ALLOW_STAGED=1 asks for it (tests on a 1-GPU box),
 and then the line says "degraded" and carries no vs_baseline.
 """
+import os as _os
+
+# Thread pools sized by the host's core count (256 on the GPU boxes) inside a container with a 16-CPU quota get the whole
+# cgroup CPU-throttled, the solver's host thread included (tools/throttle_probe.sh): keep the numeric libraries' pools small
+# unless the caller decided otherwise. Must happen before numpy / torch are imported. The CPU baseline sets its own thread count.
+for _k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS", "NUMEXPR_NUM_THREADS"):
+    _os.environ.setdefault(_k, "8")
+
 import argparse
 import hashlib
 import importlib.util
@@ -528,6 +536,17 @@ def self_launch(args):
     return worst
 
 
+def cgroup_throttle_counters():
+    """(periods in which this container was CPU-throttled, microseconds throttled) from cgroup v2's cpu.stat, or None. A throttled
+    container stalls the solver's host thread, which sits on the critical path once per iteration (status record -> next launches):
+    the difference over the timed steps tells a slow number caused by the host from one caused by the GPU."""
+    try:
+        rec = dict(line.split() for line in open("/sys/fs/cgroup/cpu.stat"))
+        return int(rec["nr_throttled"]), int(rec["throttled_usec"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def parity_vs_golden(n, hist, iterations):
     """The residual history of the timed solves against the committed oracle fixture (tests/golden/known_answers.json, written
     by tests/golden/make_golden.py from oracle/spmv_oracle.c on a CPU: data, not code). north_star's bar: 1e-10 relative on
@@ -697,6 +716,7 @@ def measure_leg(c, allreduce_kind):
             os.kill(os.getpid(), signal.SIGKILL)
         barrier()
         torch.cuda.synchronize()
+        throttle0 = cgroup_throttle_counters()
         t0 = time.perf_counter()
         # in-loop SpMV launches are event-timed on their own stream inside the solver: every 7th launch, the phase moving on by
         # one with every solve, so the timed steps cover every iteration of the loop (each pair of events costs two barrier
@@ -710,6 +730,8 @@ def measure_leg(c, allreduce_kind):
         torch.cuda.synchronize()
         barrier()
         dt = time.perf_counter() - t0
+        throttle1 = cgroup_throttle_counters()
+        host_throttled = None if throttle0 is None or throttle1 is None else {"periods": throttle1[0] - throttle0[0], "usec": throttle1[1] - throttle0[1]}
         rank_ms = [float(v) for v in gather(c, dt / args.steps * 1e3)]  # every rank's own wall time per step: the spread is load imbalance
         if multi:
             t = torch.tensor([dt], dtype=torch.float64)
@@ -735,7 +757,8 @@ def measure_leg(c, allreduce_kind):
                "local_rows": slab.n_local, "local_nnz": slab.local_nnz, "spmv_ms": spmv_ms, "spmv_launches": spmv_launches,
                "event_ms_per_solve": float(np.median(event_ms)),
                "rccl_ranks": comm.transport_ranks() if (comm is not None and transport == "rccl") else 0,
-               "placement": placement, "tile_runs": tile_runs, "setup_ms": setup_ms, "loop_shape": loop_shape}
+               "placement": placement, "tile_runs": tile_runs, "setup_ms": setup_ms, "loop_shape": loop_shape,
+               "host_throttled": host_throttled}
     finally:
         slab.destroy()
         if comm is not None:
@@ -995,6 +1018,10 @@ def build_line(args, base, leg, spmv, extras, world, n, rows, nnz, compare=None)
                            "spmv_median_ms": None if spmv is None or "median_ms" not in spmv else spmv["median_ms"],
                            "grid": n, "unknowns": rows, "nnz": nnz, "partition": f"{world} row slab(s)", "transport": transport,
                            "loop_shape": leg.get("loop_shape"),
+                           # CPU throttling of this container during the timed steps (cgroup cpu.stat; rank 0's view): a stalled host
+                           # thread leaves the GPU idle once per iteration -- non-zero values explain a slow `value`, zero rules the host out
+                           "host_throttled_periods_in_timed_steps": None if not leg.get("host_throttled") else leg["host_throttled"]["periods"],
+                           "host_throttled_usec_in_timed_steps": None if not leg.get("host_throttled") else leg["host_throttled"]["usec"],
                            "iterations_per_solve": iterations, "converged": leg["converged"], "final_residual": leg["final_residual"],
                            # the solver's own clock (HIP events around the reference's timed region, median over the timed steps, rank 0):
                            # `value` is the wall clock around the K steps, which also holds the host's work between two solves

@@ -213,7 +213,11 @@ struct SpmvAmdCgSlab {
     // same bits. Measured at 4e8 rows on one slab, settings alternated between solves: 108.04 -> 107.34 ms per solve, -0.65 %
     // (profiles/r04_ab_late_bulk.txt). Small slabs (a whole update is ~0.2 ms at 5e7 rows) keep the single launch. Ring mode only.
     bool late_bulk = false;
-    size_t lead_rows = (size_t)1 << 24;
+    // 2^25 rows = ~125 us of streaming: the host's read + launch take ~20 us on a quiet box, but a container that is being CPU-
+    // throttled answers later (tools/throttle_probe.sh: the direction stage is where the host sits on the critical path). On one
+    // slab, settings alternated (profiles/r06_ab_lead_rows.txt): 2^22 ... 2^26 rows all within 0.1 % (104.08-104.19 ms per solve
+    // at 4e8 rows), late bulk off 104.67, 2^27 104.69.
+    size_t lead_rows = (size_t)1 << 25;
     int poll_sequence = 0;
     double last_spmv_ms = 0.0;
     int last_spmv_launches = 0;

@@ -17,7 +17,7 @@ settings = [("default", {})] + ([(" ".join(sys.argv[3:]), other)] if other else 
 res = {name: [] for name, _ in settings}
 for k in range(runs):
     for name, extra in (settings if k % 2 == 0 else settings[::-1]):
-        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-scaling-probe", "--steps", steps],
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-scaling-probe", "--no-compare", "--steps", steps],
                              env=dict(os.environ, **extra), capture_output=True, text=True, timeout=600)
         lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
         if out.returncode != 0 or not lines:
