@@ -213,6 +213,13 @@ struct SpmvAmdCgSlab {
     // same bits. Measured at 4e8 rows on one slab, settings alternated between solves: 108.04 -> 107.34 ms per solve, -0.65 %
     // (profiles/r04_ab_late_bulk.txt). Small slabs (a whole update is ~0.2 ms at 5e7 rows) keep the single launch. Ring mode only.
     bool late_bulk = false;
+    // The lead / status / rest protocol puts the host on the critical path with only the lead piece to hide behind, so it is
+    // used only where it can pay: in iterations that MAY converge, judged by the residual the host already knows (the previous
+    // iteration's, in the host-coherent history): still more than 16 x the tolerance away -> this iteration will not converge
+    // (a drop of 16 x in one iteration would be needed) and the whole update is enqueued at once, as on small slabs. A wrong
+    // guess costs the empty dispatch once, never a result: the kernels test the flag themselves. On the 20 000^2 solve the
+    // protocol runs in iterations 11-14 of 14. (LAB build: set_option("late_bulk", 1) forces the protocol in every iteration.)
+    bool late_predict = true;
     // 2^25 rows = ~125 us of streaming: the host's read + launch take ~20 us on a quiet box, but a container that is being CPU-
     // throttled answers later (tools/throttle_probe.sh: the direction stage is where the host sits on the critical path). On one
     // slab, settings alternated (profiles/r06_ab_lead_rows.txt): 2^22 ... 2^26 rows all within 0.1 % (104.08-104.19 ms per solve
@@ -998,6 +1005,7 @@ struct SolveRun {
     void stage_update_r();
     void stage_sum_rr_and_step();
     void stage_direction_and_halo();
+    bool may_converge_now() const;
     bool read_status();
     void finish();
     void resolve_timeline(const CgScalars& fin, float total_ms);
@@ -1192,6 +1200,20 @@ void SolveRun::stage_sum_rr_and_step() {
     ++enqueued;  // from here on `enqueued` is the number of the iteration just stepped (1-based), as the kernels count
 }
 
+// Could the iteration whose step is on the stream right now (number `enqueued`, 1-based) be the converging one? The host knows
+// the residuals up to iteration enqueued - 1 (it has read that iteration's status record; the history lies in host-coherent
+// memory, written before the record): far from the tolerance -> no.
+bool SolveRun::may_converge_now() const {
+    if (!s->late_predict) return true;
+#ifdef SPMV_AMD_LAB
+    if (s->stop_at > 0) return true;  // a stand-in's iteration count is declared, not predicted
+#endif
+    const int known = enqueued - 1;
+    if (known < 0 || known >= s->hist_cap) return true;
+    const double r0 = s->d_hist[0], rk = s->d_hist[known];
+    return !(rk > 16.0 * config->tolerance * r0);  // (a NaN compares false: "may converge", the careful path)
+}
+
 // Stage 5: p <- r + beta p and its halo exchange; nothing else before the host looks at the status: the GPU works on these
 // while the host waits for the record. Late bulk: the piece the sweep walks first, then the status record, then -- unless the
 // iteration converged -- the rest; the lead piece keeps the GPU busy while the host reads the record and launches.
@@ -1199,7 +1221,7 @@ void SolveRun::stage_direction_and_halo() {
     trace.push("BLAS_AXPBY");
     status_known = false;
     const size_t lo = L.bulk_lo, hi = L.bulk_hi;
-    const bool two_pieces = L.late && hi - lo >= 4 * s->lead_rows;
+    const bool two_pieces = L.late && hi - lo >= 4 * s->lead_rows && may_converge_now();
     const size_t cut = !two_pieces ? (backward ? lo : hi) : backward ? (hi - s->lead_rows) / 512 * 512 : lo + s->lead_rows;
     // first piece: [cut, hi) walking backward, [lo, cut) walking forward; the rest is the other side of the cut
     const size_t first_lo = backward ? cut : lo, first_rows = backward ? hi - cut : cut - lo;
@@ -1496,7 +1518,7 @@ extern "C" void spmv_amd_cg_slab_set_timeline(SpmvAmdCgSlab* s, int on) { s->tim
 // "lead_rows" -- none of which changes a bit of the results -- "spmv_event_stride", and the timing aid "stop_at".
 // Returns 0, or -1 for an unknown name.
 extern "C" int spmv_amd_cg_slab_set_option(SpmvAmdCgSlab* s, const char* name, long long value) {
-    if (strcmp(name, "late_bulk") == 0) s->late_bulk = value != 0;
+    if (strcmp(name, "late_bulk") == 0) s->late_bulk = value != 0, s->late_predict = value == 2;  // 1: the protocol in every iteration, 2: where convergence is near (the default rule)
     else if (strcmp(name, "lead_rows") == 0) s->lead_rows = value < 512 ? 512 : (size_t)value / 512 * 512;
     else if (strcmp(name, "no_overlap") == 0) s->no_overlap = value != 0 || s->comm->pipeline_verdict < 0;  // a refused pipeline stays refused
     else if (strcmp(name, "stop_at") == 0) s->stop_at = value > 0 ? (int)value : 0;

@@ -2,7 +2,8 @@
 """Late bulk (csrc/cg_slab.hip): the direction update of an iteration is enqueued as a LEAD piece, then the host reads the status
 record and enqueues the rest only if the loop goes on. The lead piece must outlast the host's read + launch; a slow host (a
 throttled container, a noisy neighbour) leaves the GPU idle behind a short one. One slab (LAB build), settings switched between
-solves: late bulk off, and on with lead pieces of 2^24 ... 2^27 rows.
+solves: late bulk off, the default rule (the protocol only in iterations that may converge, judged by the known residual), and
+the protocol in every iteration with lead pieces of 2^22 ... 2^27 rows.
    python tools/ab_lead_rows.py [grid=20000] [rounds=6]"""
 import os
 import sys
@@ -19,7 +20,8 @@ B = load_binding().use_lab()
 B.lib()
 B.require_gpu()
 slab = B.CgSlab.stencil5(n)
-settings = [("late bulk off", 0, 1 << 24)] + [(f"lead 2^{k} rows", 1, 1 << k) for k in (22, 23, 24, 25, 26, 27)]
+settings = ([("late bulk off", 0, 1 << 25), ("default rule, 2^25", 2, 1 << 25)] +
+            [(f"every iteration, 2^{k}", 1, 1 << k) for k in (22, 23, 24, 25, 26, 27)])
 ms = {name: [] for name, _, _ in settings}
 tl = {}
 for _ in range(2):
@@ -42,6 +44,6 @@ print(f"grid {n} ({slab.n_local} rows), one slab, {rounds} rounds, settings alte
 for name, _, _ in settings:
     v = np.array(ms[name])
     t = tl[name]
-    print(f"   {name:18s} solve ms median {np.median(v):8.3f}  min {v.min():8.3f}  max {v.max():8.3f}   timeline: direction update {t['direction_update_us']:7.1f} us, "
+    print(f"   {name:26s} solve ms median {np.median(v):8.3f}  min {v.min():8.3f}  max {v.max():8.3f}   timeline: direction update {t['direction_update_us']:7.1f} us, "
           f"gap {t['gap_before_next_iteration_us']:5.1f} us, iteration {t['iteration_us']:7.1f} us")
 slab.destroy()
