@@ -721,11 +721,12 @@ def measure_leg(c, allreduce_kind):
         # in-loop SpMV launches are event-timed on their own stream inside the solver: every 7th launch, the phase moving on by
         # one with every solve, so the timed steps cover every iteration of the loop (each pair of events costs two barrier
         # packets next to the launch; csrc/cg_slab.hip, spmv_event_stride)
-        spmv_each, event_ms = [], []
+        spmv_each, event_ms, outcomes = [], [], []
         for _ in range(args.steps):
             st = slab.solve()
             spmv_each.extend(float(v) for v in slab.spmv_launch_ms())
             event_ms.append(st.time_total_ms)
+            outcomes.append((int(st.iterations), int(st.converged), float(st.residual_norm).hex()))
         spmv_ms, spmv_launches = float(np.sum(spmv_each)), len(spmv_each)
         torch.cuda.synchronize()
         barrier()
@@ -737,6 +738,10 @@ def measure_leg(c, allreduce_kind):
             t = torch.tensor([dt], dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t[0])
+        # every timed solve is the same solve: same iteration count, same verdict, the same final residual to the bit (the parity
+        # gate below looks at the LAST solve's history; a solve that ended early would be a fast solve, not a right one)
+        if len(set(outcomes)) != 1:
+            raise Unmeasured(f"the {args.steps} timed solves disagree on (iterations, converged, final residual): {sorted(set(outcomes))}")
         hist = slab.history()
         # every rank computes its scalars from the same all-reduced values: the histories must agree bit for bit
         hexes = gather(c, [float(v).hex() for v in hist])

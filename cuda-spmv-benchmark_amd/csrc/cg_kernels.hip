@@ -443,7 +443,14 @@ __device__ __forceinline__ void flush_chunk(d2& xv, const RingSlots& ring, const
 // 8.56-8.59 ms against 8.03-8.36 ms at 4e8 rows, same bits).
 __global__ __launch_bounds__(kStream) void cg_flush_x_kernel(size_t n, const double* __restrict__ alphas, RingSlots ring,
                                                              int slots, int first_slot, int count,
-                                                             const double* x_in, double* x) {
+                                                             const double* x_in, double* x, const CgScalars* __restrict__ s, int window_start) {
+    // Only directions of iterations that were COUNTED enter x: the host may have enqueued one iteration more than the solve needed
+    // (it runs one iteration ahead of the status records while convergence looks far, cg_slab.hip), and that iteration's kernels
+    // -- the step included -- did nothing: its alpha slot holds an old value. The terms are iterations window_start + 1 ...
+    if (s != nullptr) {
+        const int counted = s->iterations - window_start;
+        if (count > counted) count = counted > 0 ? counted : 0;
+    }
     const size_t pairs = n >> 1;
     const size_t i = (size_t)blockIdx.x * kStream + threadIdx.x;
     if (i < pairs) {
@@ -631,10 +638,10 @@ void launch_cg_update_p_ring(size_t n, const CgScalars* s, const double* r, cons
 }
 
 void launch_cg_flush_x(size_t n, const double* alphas, const RingSlots& ring, int slots, int first_slot, int count,
-                       const double* x_in, double* x, hipStream_t stream) {
+                       const double* x_in, double* x, hipStream_t stream, const CgScalars* s, int window_start) {
     if (n == 0 || count <= 0) return;
     hipLaunchKernelGGL(cg_flush_x_kernel, dim3(stream_grid(n)), dim3(kStream), 0, stream, n, alphas, ring, slots,
-                       first_slot, count, x_in, x);
+                       first_slot, count, x_in, x, s, window_start);
 }
 
 }  // namespace spmv_amd

@@ -52,6 +52,10 @@
 //    sweep alternation) are gone with their code; both shapes give the same bits (tests/test_cg_gpu.py). Test and measurement
 //    hooks (stand-in slabs, stop_at, loop options, fault injection) exist in the LAB build only (-DSPMV_AMD_LAB,
 //    lib/libspmv_amd_lab.so): the product library has no switch that can change a result.
+//  * (round 6) the host off the critical path where the residual allows: while the known residual is more than 16 x the tolerance
+//    away the host neither uses the late bulk's lead / status / rest protocol nor waits for the iteration's status record before
+//    it enqueues the next iteration (it runs ONE iteration ahead; the rule reads the residual history only, so every rank takes
+//    the same decision). A container that is being CPU-throttled answers late (profiles/r06_throttle_probe.txt).
 //
 // The same loop also serves the reference's SINGLE-GPU entry point, cg_solve_device (cg_solver.cu:436-706): a slab that
 // borrows the caller's SpmvOperator instead of owning a CSR (cg_solve_on_operator, near the end of this file), and it can
@@ -220,6 +224,9 @@ struct SpmvAmdCgSlab {
     // guess costs the empty dispatch once, never a result: the kernels test the flag themselves. On the 20 000^2 solve the
     // protocol runs in iterations 11-14 of 14. (LAB build: set_option("late_bulk", 1) forces the protocol in every iteration.)
     bool late_predict = true;
+    // The host runs one iteration ahead of the status records while convergence is far (SolveRun::read_status): an iteration's
+    // worth of work is always queued, so a host that answers late does not idle the GPU. (LAB build: set_option("run_ahead", 0).)
+    bool run_ahead = true;
     // 2^25 rows = ~125 us of streaming: the host's read + launch take ~20 us on a quiet box, but a container that is being CPU-
     // throttled answers later (tools/throttle_probe.sh: the direction stage is where the host sits on the critical path). On one
     // slab, settings alternated (profiles/r06_ab_lead_rows.txt): 2^22 ... 2^26 rows all within 0.1 % (104.08-104.19 ms per solve
@@ -653,20 +660,26 @@ void report_slab_state(void* user, FILE* out) {
     s->comm->describe(out);
 }
 
-// Blocks the host until the scalar step of the iteration just enqueued has published its record. Bounded by
-// the watchdog (SPMV_AMD_WATCHDOG_S): a rank whose peers never answer ends with a report, not a hang.
-void wait_for_status(SpmvAmdCgSlab* s) {
+// Has the scalar step that publishes record `sequence` run? (Records carry increasing sequence numbers, one per iteration, over
+// the life of the slab; a later record implies the earlier ones.)
+bool record_arrived(const SpmvAmdCgSlab* s, int sequence) {
+    return (int)(__atomic_load_n(&s->h_poll->sequence, __ATOMIC_ACQUIRE) - sequence) >= 0;
+}
+
+// Blocks the host until record `sequence` has been published. Bounded by the watchdog (SPMV_AMD_WATCHDOG_S): a rank whose
+// peers never answer ends with a report, not a hang.
+void wait_for_record(SpmvAmdCgSlab* s, int sequence) {
+    if (record_arrived(s, sequence)) return;
     WatchdogScope guard("waiting for the iteration's status record", s->comm->rank, s->enqueued_iteration,
                         report_slab_state, s);
-    volatile int* seq = &s->h_poll->sequence;
     long spins = 0;
-    while (__atomic_load_n(seq, __ATOMIC_ACQUIRE) != s->poll_sequence) {
+    while (!record_arrived(s, sequence)) {
         __builtin_ia32_pause();  // the record arrives within one iteration; the spinning core at least yields its pipeline
         if (++spins % (1L << 20) == 0) {
             // surface a faulted stream at once instead of waiting for the watchdog
             const hipError_t e = hipStreamQuery(s->compute);
             if (e != hipSuccess && e != hipErrorNotReady) HIP_CHECK(e);
-            if (e == hipSuccess && __atomic_load_n(seq, __ATOMIC_ACQUIRE) != s->poll_sequence) {
+            if (e == hipSuccess && !record_arrived(s, sequence)) {
                 fprintf(stderr, "[cg-slab] status record missing after the stream drained\n");
                 exit(EXIT_FAILURE);
             }
@@ -805,6 +818,10 @@ void verify_pipeline(SpmvAmdCgSlab* s) {
         spmv_amd_cg_slab_solve(s, &few, &st);
         poison_halos(s);
         HIP_CHECK(hipStreamSynchronize(s->compute));
+        if (s->side) HIP_CHECK(hipStreamSynchronize(s->side));
+        // everything the check enqueued has run: a wait that gave up in an iteration the host had already enqueued ahead may have
+        // raised the flag again after read_status cleared it
+        __atomic_store_n(&s->h_poll->halo_late, 0, __ATOMIC_RELEASE);
         bool finite = true;  // NaN from a poisoned halo in the PLAIN order: the transport itself does not deliver the rows
         for (double v : plain) finite = finite && std::isfinite(v);
         if (!finite)
@@ -957,7 +974,9 @@ struct SolveRun {
     int tl_exchanges = 0;       // halo exchanges marked on the side stream (exchange j precedes the SpMV of iteration j)
     bool halo_in_flight = false;
     bool step_in_direction = false;  // this iteration's scalar step rides in the direction update's launch
-    bool status_known = false;
+    // Status records: the record of iteration j (1-based) of this solve carries sequence0 + j. records_read = the latest
+    // iteration whose record the host has seen; the host runs at most ONE iteration ahead of it (read_status).
+    int sequence0 = 0, records_read = 0;
     bool backward = false;      // sweep direction of this iteration's SpMV and direction update (the r update walks the other way)
     int enqueued = 0, sampled = 0;
     std::vector<int> sampled_iteration;  // 0-based loop index of each timed SpMV
@@ -1005,7 +1024,9 @@ struct SolveRun {
     void stage_update_r();
     void stage_sum_rr_and_step();
     void stage_direction_and_halo();
-    bool may_converge_now() const;
+    bool far_from_convergence(int iteration, int basis) const;
+    bool converged_at(int k) const;
+    void await_record(int iteration);
     bool read_status();
     void finish();
     void resolve_timeline(const CgScalars& fin, float total_ms);
@@ -1039,6 +1060,9 @@ void SolveRun::begin() {
     HIP_CHECK(hipStreamSynchronize(s->compute));
     s->timeline_us.clear();
     s->p = s->ring[0];
+    sequence0 = s->poll_sequence;
+    records_read = 0;
+    s->h_poll->converged = 0, s->h_poll->iterations = 0;  // (the stream is idle: nothing of the previous solve can still write here)
     s->enqueued_stage = "barrier before the timed region";
     s->enqueued_iteration = -1;
     {
@@ -1200,18 +1224,34 @@ void SolveRun::stage_sum_rr_and_step() {
     ++enqueued;  // from here on `enqueued` is the number of the iteration just stepped (1-based), as the kernels count
 }
 
-// Could the iteration whose step is on the stream right now (number `enqueued`, 1-based) be the converging one? The host knows
-// the residuals up to iteration enqueued - 1 (it has read that iteration's status record; the history lies in host-coherent
-// memory, written before the record): far from the tolerance -> no.
-bool SolveRun::may_converge_now() const {
-    if (!s->late_predict) return true;
+// Is iteration `iteration` (1-based) too far from the tolerance to be the converging one? Judged by the residual of iteration
+// `basis`, which the host has SEEN (basis <= records_read; the history lies in host-coherent memory and is written before the record): CG on
+// these systems halves the residual per iteration; a drop of 16 x per iteration between the known residual and `iteration` is
+// the margin. A wrong guess costs empty dispatches, never a result: every kernel tests the flag itself.
+bool SolveRun::far_from_convergence(int iteration, int basis) const {
 #ifdef SPMV_AMD_LAB
-    if (s->stop_at > 0) return true;  // a stand-in's iteration count is declared, not predicted
+    if (s->stop_at > 0) return iteration + 3 < s->stop_at;  // a stand-in's last iteration is declared: behave like a solve that converges there
 #endif
-    const int known = enqueued - 1;
-    if (known < 0 || known >= s->hist_cap) return true;
-    const double r0 = s->d_hist[0], rk = s->d_hist[known];
-    return !(rk > 16.0 * config->tolerance * r0);  // (a NaN compares false: "may converge", the careful path)
+    if (basis < 0 || basis > records_read || basis >= s->hist_cap || iteration <= basis) return false;
+    const double ratio = basis == 0 ? 1.0 : s->d_hist[basis] / s->d_hist[0];  // ||r0|| itself may not have been written yet
+    double bar = config->tolerance;
+    for (int k = basis; k < iteration; ++k) bar *= 16.0;
+    return ratio > bar;  // (a NaN compares false: "may converge", the careful path)
+}
+
+// The verdict on iteration k (1-based, k <= records_read) from the host-coherent history: the GPU's own test (reduce_device.hpp,
+// cg_converging: sqrt(rr_new) / b_norm < tol, strict) on the same two doubles -- history[k] is that sqrt, history[0] is b_norm.
+bool SolveRun::converged_at(int k) const {
+    if (k < 1 || k >= s->hist_cap) return s->h_poll->converged != 0;
+#ifdef SPMV_AMD_LAB
+    if (s->stop_at > 0 && k == s->stop_at) return true;
+#endif
+    return s->d_hist[k] / s->d_hist[0] < config->tolerance;
+}
+
+void SolveRun::await_record(int iteration) {
+    wait_for_record(s, sequence0 + iteration);
+    if (iteration > records_read) records_read = iteration;
 }
 
 // Stage 5: p <- r + beta p and its halo exchange; nothing else before the host looks at the status: the GPU works on these
@@ -1219,9 +1259,8 @@ bool SolveRun::may_converge_now() const {
 // iteration converged -- the rest; the lead piece keeps the GPU busy while the host reads the record and launches.
 void SolveRun::stage_direction_and_halo() {
     trace.push("BLAS_AXPBY");
-    status_known = false;
     const size_t lo = L.bulk_lo, hi = L.bulk_hi;
-    const bool two_pieces = L.late && hi - lo >= 4 * s->lead_rows && may_converge_now();
+    const bool two_pieces = L.late && hi - lo >= 4 * s->lead_rows && !(s->late_predict && far_from_convergence(enqueued, records_read));  // a local choice: any basis the host has will do
     const size_t cut = !two_pieces ? (backward ? lo : hi) : backward ? (hi - s->lead_rows) / 512 * 512 : lo + s->lead_rows;
     // first piece: [cut, hi) walking backward, [lo, cut) walking forward; the rest is the other side of the cut
     const size_t first_lo = backward ? cut : lo, first_rows = backward ? hi - cut : cut - lo;
@@ -1231,8 +1270,7 @@ void SolveRun::stage_direction_and_halo() {
             first(first_lo, first_rows);
             if (!two_pieces) return;
             s->enqueued_stage = "direction update (lead piece)";
-            wait_for_status(s);
-            status_known = true;
+            await_record(enqueued);
             if (!s->h_poll->converged) rest(rest_lo, rest_rows);  // else the loop ends here: nothing reads the rest of this direction
         });
     };
@@ -1247,7 +1285,8 @@ void SolveRun::stage_direction_and_halo() {
         // (alpha of this iteration is already on the stream: the step above wrote it)
         if (enqueued - window_start == L.slots) {
             timed(&stats->time_blas1_ms, nullptr, [&] {
-                launch_cg_flush_x(nl, s->d_alpha_ring, ring_view, L.slots, window_start % L.slots, L.slots, window_start == 0 ? s->x0 : s->x, s->x, s->compute);
+                launch_cg_flush_x(nl, s->d_alpha_ring, ring_view, L.slots, window_start % L.slots, L.slots, window_start == 0 ? s->x0 : s->x, s->x, s->compute,
+                                  s->d_s, window_start);
             });
             window_start = enqueued;
         }
@@ -1285,7 +1324,28 @@ void SolveRun::stage_direction_and_halo() {
 // The host reads the iteration's status record (the GPU is already busy with the direction update, the exchange and -- in the
 // next turn of the loop -- the SpMV). Returns true when the loop is over.
 bool SolveRun::read_status() {
-    if (!status_known) wait_for_status(s);
+    // Round 6: the host may run ONE iteration ahead of the records it has seen. While the residual it knows says the iteration
+    // just enqueued cannot be the converging one, the host does not wait for that iteration's record: it goes on to enqueue the
+    // next iteration and reads the record on the way. The GPU then always has an iteration's worth of work queued, and a host
+    // that answers late (a CPU-throttled container: profiles/r06_throttle_probe.txt) no longer leaves it idle between a
+    // direction update and the next SpMV. Near convergence every record is awaited before the next launch, as before.
+    // The decision must be the SAME ON EVERY RANK (an iteration carries collectives): it is taken from the residual history
+    // alone -- identical bits on all ranks -- never from whether a record happens to have arrived; and the verdict on an
+    // iteration whose record was read late comes from the history too (converged_at), not from the record's flag, which a
+    // later record may already have overwritten.
+    // (that includes a rank that already KNOWS the outcome of this iteration because its slab is large enough for the late
+    // bulk's lead / status / rest protocol: it follows the common rule too, and at worst enqueues an iteration of no-ops)
+    const int j = enqueued;
+    if (records_read < j - 1) {
+        await_record(j - 1);
+        if (converged_at(j - 1)) {  // the guess was wrong: iteration j was enqueued for nothing (its kernels saw the flag); the loop ends here
+            await_record(j);
+            return true;
+        }
+    }
+    // basis j - 1, the one residual every rank is sure to have at this point (verbose >= 2 prints every iteration's scalars: no run-ahead)
+    const bool deferred = s->run_ahead && config->verbose < 2 && j + 1 < s->hist_cap && far_from_convergence(j, j - 1);
+    if (!deferred) await_record(j);
     mailbox_check(s->comm);
     if (const int gave_up = __atomic_load_n(&s->h_poll->halo_late, __ATOMIC_ACQUIRE)) {
         if (s->selfcheck) {  // creation check: a hand-over that never came is a verdict, not the end of the process
@@ -1309,7 +1369,8 @@ bool SolveRun::read_status() {
         else
             printf("[Iter %3d] Residual: %.6e (rel: %.6e, alpha: %.4e)\n", now.iterations, now.residual, now.residual / now.b_norm, now.alpha);
     }
-    return s->h_poll->converged != 0;
+    // not deferred: record `enqueued` is the latest there can be (nothing of the next iteration is on the stream): its flag is exact
+    return deferred ? false : s->h_poll->converged != 0;
 }
 
 // Averages over the counted iterations of a timeline solve; order = kTimelineNames.
@@ -1356,7 +1417,7 @@ void SolveRun::finish() {
     if (L.slots > 1 && enqueued > window_start)  // x <- x + the directions of the last window
         timed(&stats->time_blas1_ms, nullptr, [&] {
             launch_cg_flush_x(nl, s->d_alpha_ring, ring_view, L.slots, window_start % L.slots, enqueued - window_start, window_start == 0 ? s->x0 : s->x,
-                              s->x, s->compute);
+                              s->x, s->compute, s->d_s, window_start);
         });
     s->p = s->ring[0];
     if (enqueued == 0)  // no iteration ran (max_iters == 0): the solution is the initial guess
@@ -1520,6 +1581,7 @@ extern "C" void spmv_amd_cg_slab_set_timeline(SpmvAmdCgSlab* s, int on) { s->tim
 extern "C" int spmv_amd_cg_slab_set_option(SpmvAmdCgSlab* s, const char* name, long long value) {
     if (strcmp(name, "late_bulk") == 0) s->late_bulk = value != 0, s->late_predict = value == 2;  // 1: the protocol in every iteration, 2: where convergence is near (the default rule)
     else if (strcmp(name, "lead_rows") == 0) s->lead_rows = value < 512 ? 512 : (size_t)value / 512 * 512;
+    else if (strcmp(name, "run_ahead") == 0) s->run_ahead = value != 0;
     else if (strcmp(name, "no_overlap") == 0) s->no_overlap = value != 0 || s->comm->pipeline_verdict < 0;  // a refused pipeline stays refused
     else if (strcmp(name, "stop_at") == 0) s->stop_at = value > 0 ? (int)value : 0;
     else if (strcmp(name, "spmv_event_stride") == 0) s->spmv_event_stride = (int)value;

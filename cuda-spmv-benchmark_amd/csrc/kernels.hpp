@@ -235,8 +235,10 @@ constexpr int kMaxRingSlots = 16;
 struct RingSlots {
     const double* p[kMaxRingSlots];
 };
+// s (may be null) / window_start: only terms of iterations window_start + 1 ... s->iterations are added (a host that ran one
+// iteration ahead may ask for one term too many: that iteration was never counted and its alpha slot holds an old value).
 void launch_cg_flush_x(size_t n, const double* alphas, const RingSlots& ring, int slots, int first_slot, int count,
-                       const double* x_in, double* x, hipStream_t stream);
+                       const double* x_in, double* x, hipStream_t stream, const CgScalars* s = nullptr, int window_start = 0);
 int cg_partial_count(size_t n);  // partial slots written by the two reducing kernels above
 // *d_out = sum of partials[0..count) and extra[0..extra_count) in a fixed order (reduce_device.hpp: slices of `partials`, then
 // [slice sums | extra]), in ONE launch. extra: the partials of a split SpMV's boundary rows (may be null).

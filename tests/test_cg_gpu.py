@@ -357,7 +357,10 @@ def test_both_loop_shapes_leave_every_bit_alone(Blab, monkeypatch, n, P, r):
     fallback). Plus the one split both may take: the direction update as a lead piece + (after the status record) the rest (late
     bulk), forced on with short leads so that small grids take it in both sweep directions. History and solution must be
     bit-identical under every combination, with the direction ring and with the in-place x / p update (ring 1), on a plain slab
-    (even and odd row counts) and on stand-in slabs of a larger job (one and two neighbours; LAB build). The A/B switches of
+    (even and odd row counts) and on stand-in slabs of a larger job (one and two neighbours; LAB build). Round 6's host-side
+    rules ride along: the host one iteration ahead of the status records while convergence is far (run_ahead, default on; a
+    stand-in solve with tolerance 0 is "far" in every iteration, a real one until its last few), and the late bulk by prediction
+    (late_bulk = 2) against the protocol in every iteration (1). The A/B switches of
     rounds 2-5 (two-launch reductions, event-ordered hand-overs, three-launch direction update, no sweep alternation) left with
     their code in round 6."""
     B = Blab
@@ -378,9 +381,11 @@ def test_both_loop_shapes_leave_every_bit_alone(Blab, monkeypatch, n, P, r):
         st0 = slab.solve(**kw)  # the default shape of this slab
         h0, x0 = slab.history().copy(), slab.gather() if P == 1 else None
         for opts in ({"late_bulk": 1, "lead_rows": 50000}, {"late_bulk": 1, "lead_rows": 512}, {"no_overlap": 1},
-                     {"no_overlap": 1, "late_bulk": 1, "lead_rows": 512}, {}):
+                     {"no_overlap": 1, "late_bulk": 1, "lead_rows": 512}, {}, {"run_ahead": 0}, {"late_bulk": 2, "lead_rows": 512},
+                     {"late_bulk": 2, "lead_rows": 512, "run_ahead": 0, "no_overlap": 1}):
             for k in ("late_bulk", "no_overlap"):
                 slab.set_option(k, opts.get(k, 0))
+            slab.set_option("run_ahead", opts.get("run_ahead", 1))  # default: the host one iteration ahead of the status records
             slab.set_option("lead_rows", opts.get("lead_rows", 1 << 24))
             st = slab.solve(**kw)
             assert (st.iterations, st.converged) == (st0.iterations, st0.converged) and np.array_equal(slab.history(), h0), (ring, opts)
