@@ -161,6 +161,7 @@ struct SpmvAmdCgSlab {
     // one direction update + halo exchange more than the rank of a real job, whose 14th iteration converges. Timing only.
     int stop_at = 0;
     int test_wedge_overlapped_exchange = 0;  // SPMV_AMD_TEST_WEDGE_OVERLAPPED_EXCHANGE=1 / 2, see exchange_halo
+    bool guess_far_always = false;  // set_option("run_ahead", 2): every iteration is guessed "cannot converge": each solve learns of its convergence one iteration late
 #endif
     // non-null while a solve runs on a communicator with a working peer mailbox: the last stage of every dot
     // product then completes the sum across the ranks itself (no all-reduce launch)
@@ -1230,6 +1231,7 @@ void SolveRun::stage_sum_rr_and_step() {
 // the margin. A wrong guess costs empty dispatches, never a result: every kernel tests the flag itself.
 bool SolveRun::far_from_convergence(int iteration, int basis) const {
 #ifdef SPMV_AMD_LAB
+    if (s->guess_far_always) return true;  // test hook: the wrong guess in every solve
     if (s->stop_at > 0) return iteration + 3 < s->stop_at;  // a stand-in's last iteration is declared: behave like a solve that converges there
 #endif
     if (basis < 0 || basis > records_read || basis >= s->hist_cap || iteration <= basis) return false;
@@ -1581,7 +1583,7 @@ extern "C" void spmv_amd_cg_slab_set_timeline(SpmvAmdCgSlab* s, int on) { s->tim
 extern "C" int spmv_amd_cg_slab_set_option(SpmvAmdCgSlab* s, const char* name, long long value) {
     if (strcmp(name, "late_bulk") == 0) s->late_bulk = value != 0, s->late_predict = value == 2;  // 1: the protocol in every iteration, 2: where convergence is near (the default rule)
     else if (strcmp(name, "lead_rows") == 0) s->lead_rows = value < 512 ? 512 : (size_t)value / 512 * 512;
-    else if (strcmp(name, "run_ahead") == 0) s->run_ahead = value != 0;
+    else if (strcmp(name, "run_ahead") == 0) s->run_ahead = value != 0, s->guess_far_always = value == 2;
     else if (strcmp(name, "no_overlap") == 0) s->no_overlap = value != 0 || s->comm->pipeline_verdict < 0;  // a refused pipeline stays refused
     else if (strcmp(name, "stop_at") == 0) s->stop_at = value > 0 ? (int)value : 0;
     else if (strcmp(name, "spmv_event_stride") == 0) s->spmv_event_stride = (int)value;

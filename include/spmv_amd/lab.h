@@ -29,8 +29,9 @@ SpmvAmdCgSlab* spmv_amd_cg_slab_create_stencil5_as(int n, int as_rank, int as_wo
 
 /* Options of an existing slab (A/B runs on the same allocations): "no_overlap" 0/1 (1 = the PLAIN loop shape: halo exchange on
  * the compute stream behind the whole direction update), "late_bulk" 0 / 1 / 2 (off / the lead-status-rest protocol in EVERY
- * iteration / only where the known residual says convergence is near: the default rule on slabs of >= 1e8 rows), "lead_rows" N, "run_ahead" 0/1
- * (1, the default: the host runs one iteration ahead of the status records while the known residual is far from the tolerance) --
+ * iteration / only where the known residual says convergence is near: the default rule on slabs of >= 1e8 rows), "lead_rows" N, "run_ahead" 0 / 1 / 2
+ * (1, the default: the host runs one iteration ahead of the status records while the known residual is far from the tolerance;
+ * 2: test hook, every iteration is guessed "far", so each solve learns of its convergence one iteration late) --
  * results are bit-identical under each --, "spmv_event_stride" N (time every N-th in-loop SpMV launch; default 7, phase advancing with every solve; 0 = none),
  * and the one option that is NOT result-neutral, a timing aid for stand-in slabs: "stop_at" K (iteration K counts as the
  * converging one whatever its residual; 0 = off). Returns 0, or -1 for an unknown name. */

@@ -409,6 +409,49 @@ def test_both_loop_shapes_leave_every_bit_alone(Blab, monkeypatch, n, P, r):
             comm.destroy()
 
 
+@pytest.mark.parametrize("n,P,r", [(1024, 1, 0), (1001, 1, 0), (1024, 4, 1)])
+def test_a_wrong_guess_costs_an_iteration_of_no_ops_and_nothing_else(Blab, monkeypatch, n, P, r):
+    """Round 6: the host does not wait for the status record of an iteration the known residual says cannot converge; it runs one
+    iteration ahead. If the guess is WRONG the iteration after the converging one is enqueued in full: its kernels -- SpMV, sums,
+    step, direction update, halo exchange, all-reduces -- see the flag and do nothing, the loop ends one record later, and the x
+    flush counts on the device how many directions are real. LAB hook run_ahead = 2 makes the guess wrong in EVERY solve. Iteration
+    count, verdict, residual history and solution must equal the solve that waits for every record (run_ahead = 0), bit for
+    bit, for every ring length (the x flush falls on, before and after the iteration that overshoots) and for the in-place form;
+    on a stand-in slab (stop_at declares the converging iteration) with the pipeline and with the plain order."""
+    B = Blab
+    comm = None
+    if P > 1:
+        monkeypatch.setenv("SPMV_AMD_SELF_NEIGHBOUR", "1")
+        monkeypatch.setenv("SPMV_AMD_FORCE_COLLECTIVES", "1")
+    for ring in ("16", "5", "4", "3", "2", "1"):
+        monkeypatch.setenv("SPMV_AMD_P_RING", ring)
+        if P > 1:
+            comm = B.Comm.rccl(0, 1, B.Comm.unique_id())
+            slab = B.CgSlab.stencil5_as(n, r, P, comm)
+            slab.set_option("stop_at", 8)
+            kw = dict(max_iters=30, tol=0.0)
+        else:
+            slab = B.CgSlab.stencil5(n)
+            kw = {}
+        slab.set_option("run_ahead", 0)
+        st0 = slab.solve(**kw)
+        want = (st0.iterations, st0.converged, slab.history().copy(), slab.gather() if P == 1 else None)
+        assert st0.converged == 1 and (P == 1 or st0.iterations == 8)
+        for ahead, no_overlap in ((2, 0), (1, 0), (2, 1)):
+            slab.set_option("run_ahead", ahead)
+            slab.set_option("no_overlap", no_overlap)
+            for _ in range(2):
+                st = slab.solve(**kw)
+                assert (st.iterations, st.converged) == want[:2] and np.array_equal(slab.history(), want[2]), (ring, ahead, no_overlap)
+                if P == 1:
+                    assert np.array_equal(slab.gather(), want[3]), (ring, ahead, no_overlap)
+            st_t, tl = slab.timeline_solve(**kw)
+            assert st_t.iterations == want[0] and np.array_equal(slab.history(), want[2]) and tl["iterations"] == want[0]
+        slab.destroy()
+        if comm is not None:
+            comm.destroy()
+
+
 @pytest.mark.parametrize("collectives", ["1", "0"])
 @pytest.mark.parametrize("n,P,r", [(4096, 2, 0), (4096, 2, 1), (6000, 4, 1)])
 def test_direction_update_in_one_launch_with_the_step(Blab, monkeypatch, collectives, n, P, r):
