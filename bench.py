@@ -58,6 +58,12 @@ configuration of reference docs/PROBLEM_SIZE_SCALING_RESULTS.md:40-47, on N row 
             at set-up, outside every timed region, the operator times its kernel on three allocations for y, one 32 GiB region apart, and keeps the fastest;
             the slab does the same for its coefficient stream, which must not share Ap's class (csrc/cg_slab.hip). Addresses only, same bits.
 
+  config.loop_shape  which shape the solver's loop took and who decided ("single rank", "pipeline (verified against the plain order
+            at creation)", "plain: ..."; include/spmv_amd/api.h): the library compares its overlapped pipeline with the plain order on
+            the first slab of every communicator and falls back by itself -- the line then says `degraded`.
+  config.host_throttled_periods_in_timed_steps / _usec_  CPU throttling of this container (cgroup cpu.stat) over the timed steps: a
+            stalled host thread idles the GPU (profiles/r06_throttle_probe.txt); zero rules the host out of a slow `value`.
+            The timed solves must agree on (iterations, verdict, final residual) or the run is UNMEASURED.
   parity_vs_golden  every run, every N: the residual history of the timed solves against the committed CPU-oracle
             history of the same grid (tests/golden/known_answers.json: 3, 81, 512, 2000, 10000, 15000, 20000); above 1e-10
             relative, or on another iteration count, the run is UNMEASURED (exit 3), whatever it timed.
